@@ -1,0 +1,158 @@
+/*
+ * psf_chord.h — C ABI of libpsf_chord.so: PSF-Attn's chord-sparse batched matmul on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE path of RuslanKhalitov/SparseFactorization: the call
+ *
+ *     V = spmm(chord_indicies, W.reshape(B, N*L), N, N, V)          (+ V = V + res_conn)
+ *
+ * that PSFNet.forward executes n_W times per forward
+ *   (SyntheticExperiments/psf.py:172-188, LRA/psf.py:224-240, Genome_Clf/psf.py:214-230,
+ *    attention_block.py:158-174, LRA/attention_maps/pathfinder_inference.py:66-81, imdb_inference.py:45-59),
+ * and the reference's own optional native statement of the same operator and its gradients
+ *   (spmul/spmul_cuda.cu:31-59 forward_host, :114-159 backward_host; spmul/spmul.py:12-31 SparseMultiply).
+ *
+ * Operator.  With link offsets off[0..L) (chord pattern: off[0]=0, off[k]=2^(k-1); taken mod N):
+ *
+ *   fwd : out[b,p,c] = sum_{k<L} W[b,p,k] * V[b,(p+off[k]) mod N, c]   (+ res[b,p,c])        spmul_cuda.cu:24
+ *   dV  : dV [b,q,c] = sum_{k<L} W[b,(q-off[k]) mod N,k] * dZ[b,(q-off[k]) mod N, c]         spmul_cuda.cu:79-80
+ *   dW  : dW [b,p,k] = sum_{c<C} dZ[b,p,c] * V[b,(p+off[k]) mod N, c]                        spmul_cuda.cu:105-108
+ *
+ * Sums run k (resp. c) ascending from 0 with a rounded product followed by a rounded add (no FMA
+ * contraction), i.e. the order a CPU scatter_add over the reference's row-major (i,k) index list produces
+ * (SyntheticExperiments/psf.py:7-32), so fp32 results are reproducible bit for bit against the oracle.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer to a contiguous row-major array; `offsets` and the step
+ *     pointer tables are HOST pointers, read before the call returns;
+ *   - the caller owns every buffer; the library allocates nothing on the device, keeps no pointer and
+ *     holds no state besides a thread-local error string and process-wide tuning knobs;
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*, NULL = default stream)
+ *     of the calling thread's current device; no call synchronises;
+ *   - outputs are fully overwritten (no pre-zero needed) and must not alias the gathered input
+ *     (out != V, dV != dZ): rows are gathered from other rows of the same array;
+ *   - return value: 0 = success; < 0 = invalid argument (PSF_E_*); > 0 = hipError_t of the failed HIP call.
+ *     No C++ exception crosses this boundary. psf_last_error() describes the last failure on this thread.
+ *
+ * Reference binding this replaces: pybind11 module `spmul_cuda` {forward_host, backward_host}
+ * (spmul/spmul_cuda.cu:163-166) and the Python call torch_sparse.spmm (SyntheticExperiments/psf.py:5,178).
+ * See INTEGRATION.md for the ctypes stub a maintainer of the reference would add.
+ */
+#ifndef PSF_CHORD_H
+#define PSF_CHORD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSF_ABI_VERSION 1
+
+#define PSF_MAX_LINKS 64 /* L <= 64: N = 2^63 would need 64 links */
+
+enum {
+  PSF_OK = 0,
+  PSF_E_NULL = -1,     /* a required pointer is NULL */
+  PSF_E_SHAPE = -2,    /* B, N, L or C out of range */
+  PSF_E_ALIAS = -3,    /* output aliases a gathered input */
+  PSF_E_ALIGN = -4,    /* pointer not aligned to its element size */
+  PSF_E_OFFSET = -5,   /* an explicit offset is not representable */
+  PSF_E_TUNING = -6    /* unknown tuning key / value */
+};
+
+/* ABI version of the loaded library (== PSF_ABI_VERSION it was built with). */
+int psf_version(void);
+
+/* Human-readable description of the last failure on the calling thread ("" if none). Never NULL. */
+const char* psf_last_error(void);
+
+/* Build description: target arch, compiler, kernel variants compiled in. Never NULL. */
+const char* psf_build_info(void);
+
+/*
+ * Chord link offsets — the integer pattern of get_chord_indices_assym (SyntheticExperiments/psf.py:7-32):
+ * offsets_out[0] = 0, offsets_out[k] = 2^(k-1) mod N for 1 <= k < L. Host-only, no GPU needed.
+ */
+int psf_chord_offsets(int64_t N, int32_t L, int64_t* offsets_out);
+
+/*
+ * The full COO index list of get_chord_indices_assym(n_vec=N, n_link=L): rows_out[i*L+k] = i,
+ * cols_out[i*L+k] = (i + off[k]) mod N. Both arrays hold N*L entries. Host-only. Duplicate links
+ * (off[k] == off[j] mod N) are kept, as in the reference.
+ */
+int psf_chord_indices(int64_t N, int32_t L, int64_t* rows_out, int64_t* cols_out);
+
+/*
+ * Forward step  out = W (.) V  [+ res].
+ *   W   [B,N,L]   link weights (the reference's `value` reshaped, spmm arg 2 / `F` of spmul_cuda.cu:32)
+ *   V   [B,N,C]   or [N,C] broadcast over the batch when v_batch_stride == 0 (the unbatched
+ *                 eye(N) first operand of pathfinder_inference.py:57,75-81); otherwise
+ *                 v_batch_stride must be N*C (elements)
+ *   res [B,N,C]   or NULL; fused `V = V + res_conn` of SyntheticExperiments/psf.py:187-188
+ *   out [B,N,C]
+ *   offsets       host array of L link offsets (any int64, reduced mod N here), or NULL for the
+ *                 chord pattern of psf_chord_offsets (what every PSFNet call site uses);
+ *                 an explicit array is the `offsets` argument of spmul/spmul.py:8-9,15
+ */
+int psf_chord_spmm_fwd_f32(const float* W, const float* V, const float* res, float* out,
+                           int64_t B, int64_t N, int32_t L, int64_t C, int64_t v_batch_stride,
+                           const int64_t* offsets, void* stream);
+int psf_chord_spmm_fwd_f64(const double* W, const double* V, const double* res, double* out,
+                           int64_t B, int64_t N, int32_t L, int64_t C, int64_t v_batch_stride,
+                           const int64_t* offsets, void* stream);
+
+/*
+ * Backward step (spmul_cuda.cu:114-159 backward_host). Either output may be NULL to skip it.
+ *   dZ [B,N,C]  gradient w.r.t. the step's output (also the gradient w.r.t. `res`, which is the identity)
+ *   W  [B,N,L]  needed for dV;   V [B,N,C] or [N,C] (v_batch_stride == 0) needed for dW
+ *   dW [B,N,L]
+ *   dV [B,N,C]  always per batch element; when V was broadcast the caller sums dV over b
+ */
+int psf_chord_spmm_bwd_f32(const float* dZ, const float* W, const float* V, float* dW, float* dV,
+                           int64_t B, int64_t N, int32_t L, int64_t C, int64_t v_batch_stride,
+                           const int64_t* offsets, void* stream);
+int psf_chord_spmm_bwd_f64(const double* dZ, const double* W, const double* V, double* dW, double* dV,
+                           int64_t B, int64_t N, int32_t L, int64_t C, int64_t v_batch_stride,
+                           const int64_t* offsets, void* stream);
+
+/*
+ * Whole forward chain of PSFNet.forward's hot loop (SyntheticExperiments/psf.py:172-188):
+ *     X_0 = V0;   X_{m+1} = W_m (.) X_m  [+ V0 if use_residual]      m = 0 .. M-1
+ *   W_steps   host table of M device pointers, W_steps[m] -> [B,N,L]
+ *   out_steps host table of M device pointers, out_steps[m] -> [B,N,C] receives X_{m+1}.
+ *             Training keeps all M (they are the saved inputs of the backward steps); inference may
+ *             alternate two buffers. out_steps[m] must differ from the step's input
+ *             (V0 for m = 0, out_steps[m-1] after) and, with use_residual, from V0.
+ *   V0 [B,N,C] or [N,C] with v0_batch_stride == 0 (then use_residual must be 0)
+ * Launches M dependent kernels on `stream`; the result is out_steps[M-1].
+ */
+int psf_chord_chain_fwd_f32(const float* const* W_steps, const float* V0, float* const* out_steps,
+                            int32_t M, int32_t use_residual,
+                            int64_t B, int64_t N, int32_t L, int64_t C, int64_t v0_batch_stride,
+                            const int64_t* offsets, void* stream);
+int psf_chord_chain_fwd_f64(const double* const* W_steps, const double* V0, double* const* out_steps,
+                            int32_t M, int32_t use_residual,
+                            int64_t B, int64_t N, int32_t L, int64_t C, int64_t v0_batch_stride,
+                            const int64_t* offsets, void* stream);
+
+/*
+ * Process-wide tuning knobs (benchmark / test use; defaults are the shipped configuration).
+ *   key "fwd_variant": 0 = auto, 1 = generic direct-gather kernel, 2 = LDS-window kernel
+ *   key "bwd_variant": 0 = auto, 1 = generic kernels
+ *   key "xcd_remap"  : 1 = keep a batch element's tiles on one XCD group (default), 0 = linear
+ * psf_get_tuning returns the value (>= 0) or PSF_E_TUNING.
+ */
+int psf_set_tuning(const char* key, int32_t value);
+int psf_get_tuning(const char* key);
+
+/*
+ * Name of the kernel variant the dispatcher would run for this forward shape (for profiles and bench
+ * logs; e.g. "chord_fwd_win<f32,L=15,C=8>"). Writes a NUL-terminated string of at most cap-1 chars.
+ */
+int psf_describe_fwd(int64_t B, int64_t N, int32_t L, int64_t C, int32_t elem_bytes,
+                     char* buf, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSF_CHORD_H */

@@ -1,0 +1,97 @@
+// psf_common.h — shared device/host definitions for the gfx950 chord-spmm kernels.
+//
+// Everything here is written for CDNA4 (wave64, 256 CUs in 8 XCDs, 160 KB LDS/CU); there is no other target.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/psf_chord.h"
+
+namespace psf {
+
+constexpr int kBlock = 256;  // 4 waves of 64 lanes; every kernel here uses 256-thread workgroups
+constexpr int kXcds = 8;     // workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2)
+
+// Link offsets, already reduced into [0, N). Passed by value: lives in the kernarg segment, so a
+// statically indexed offs.v[k] is one scalar load and costs no VGPR.
+struct Offsets {
+  int32_t v[PSF_MAX_LINKS];
+};
+
+// Work decomposition of one step. A tile is TR consecutive rows x TG channel groups of one batch element;
+// a channel group is VEC consecutive channels (one 16-byte access where C allows it).
+struct Geom {
+  int32_t N, L, C;
+  int32_t CG;        // channel groups per row = ceil(C / VEC)
+  int32_t tg_shift;  // TG = 1 << tg_shift threads share a row (TG <= 64 so a row never straddles a wave)
+  int32_t TR;        // rows per tile
+  int32_t tiles_n;   // ceil(N / TR)
+  int32_t chunks_c;  // ceil(CG / TG)
+  int32_t per_b;     // tiles_n * chunks_c : workgroups per batch element
+  uint32_t nblocks;  // B * per_b
+  uint32_t xq, xr;   // nblocks / 8, nblocks % 8 for the bijective XCD remap
+  int32_t remap;     // 1: logical block order is contiguous per XCD group
+  int64_t v_bstride; // elements between batch elements of the gathered operand (0 = broadcast)
+};
+
+// Logical workgroup index for this hardware workgroup.
+// Hardware deals blockIdx.x round-robin over the XCDs; we want all tiles of a batch element on one XCD so
+// that the L re-reads of each V row hit that XCD's 4 MB L2 instead of going out to Infinity Cache / HBM.
+// The map is a bijection for any nblocks (speed only, never correctness).
+__device__ __forceinline__ uint32_t logical_block(const Geom& gm) {
+  const uint32_t bid = blockIdx.x;
+  if (!gm.remap) return bid;
+  const uint32_t xcd = bid % kXcds, idx = bid / kXcds;
+  const uint32_t base = xcd < gm.xr ? xcd * (gm.xq + 1) : gm.xr * (gm.xq + 1) + (xcd - gm.xr) * gm.xq;
+  return base + idx;
+}
+
+__device__ __forceinline__ void decode_block(const Geom& gm, int& b, int& tile, int& chunk) {
+  const uint32_t lb = logical_block(gm);
+  b = (int)(lb / (uint32_t)gm.per_b);
+  const uint32_t rem = lb - (uint32_t)b * (uint32_t)gm.per_b;
+  tile = (int)(rem / (uint32_t)gm.chunks_c);
+  chunk = (int)(rem - (uint32_t)tile * (uint32_t)gm.chunks_c);
+}
+
+// ---- exact (uncontracted) arithmetic: a rounded product followed by a rounded sum, like the CPU path ----
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+
+// ---- VEC-wide register vectors ----
+template <typename T, int VEC>
+struct Vec {
+  T e[VEC];
+};
+template <>
+struct __attribute__((aligned(16))) Vec<float, 4> {
+  float e[4];
+};
+template <>
+struct __attribute__((aligned(16))) Vec<double, 2> {
+  double e[2];
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ Vec<T, VEC> ld(const T* p) {
+  return *reinterpret_cast<const Vec<T, VEC>*>(p);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void st(T* p, const Vec<T, VEC>& v) {
+  *reinterpret_cast<Vec<T, VEC>*>(p) = v;
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void axpy_rn(Vec<T, VEC>& acc, T w, const Vec<T, VEC>& x) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc.e[i] = add_rn(acc.e[i], mul_rn(w, x.e[i]));
+}
+
+constexpr int ilog2_floor(int x) { return x <= 1 ? 0 : 1 + ilog2_floor(x >> 1); }
+constexpr int imin(int a, int b) { return a < b ? a : b; }
+constexpr int imax(int a, int b) { return a > b ? a : b; }
+
+}  // namespace psf

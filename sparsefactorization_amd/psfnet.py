@@ -1,0 +1,306 @@
+"""PSFNet module surface on top of the HIP chord-spmm kernels.
+
+Four constructor signatures exist in the reference, all wrapping the same hot loop; each is mirrored by a
+class here with the same argument names, attribute names and state_dict keys, so the reference's training /
+inference scripts and its shipped checkpoints work unchanged:
+
+=====================  =================================================  ==========================
+class                  reference                                          drop-in module
+=====================  =================================================  ==========================
+``SyntheticPSFNet``    SyntheticExperiments/psf.py:62-191                  ``synthetic_psf.PSFNet``
+``LRAPSFNet``          LRA/psf.py:63-250 (== LRA/attention_maps/psf.py)    ``lra_psf.PSFNet``
+``GenomePSFNet``       Genome_Clf/psf.py:63-240                            ``genome_psf.PSFNet``
+``AttentionBlockPSF``  attention_block.py:70-178                           ``attention_block.PSFNet``
+=====================  =================================================  ==========================
+
+State-dict layout kept: ``embedding.weight``, ``pos_embedding.weight`` (``apc_embedding`` in
+the attention block), ``fs.{m}.network.{0,2}.{weight,bias}``, ``g.network.{0,2}.{weight,bias}``,
+``final.*``, ``init_linear.*``. ``chord_indicies`` (sic) stays a plain attribute outside the state_dict.
+
+What differs from the reference, on purpose: the M sparse products are not M calls into a generic
+gather/multiply/scatter (torch_sparse.spmm) with a separate residual kernel each, but one call into
+libpsf_chord.so that enqueues M HIP kernels with the residual fused (``chord_chain``). All W_m = fs[m](data)
+depend only on ``data`` (psf.py:175), never on V, so they are produced first and the chain runs back to back.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Sequence, Union
+
+import torch
+from torch import nn
+
+from .chord import chord_chain, chord_spmm, get_chord_indices_assym
+
+LayerSpec = Sequence[Union[str, int]]
+
+
+def MakeMLP(cfg: LayerSpec, in_channels: int, out_channels: int) -> nn.Sequential:
+    """An int in ``cfg`` is a Linear to that width, any string is a GELU; a closing Linear maps to
+    ``out_channels`` (SyntheticExperiments/psf.py:35-47). ``[32, 'GELU']`` gives Linear, GELU, Linear, i.e.
+    parameter indices 0 and 2."""
+    stack: List[nn.Module] = []
+    width = in_channels
+    for item in cfg:
+        if isinstance(item, int):
+            stack.append(nn.Linear(width, item))
+            width = item
+        else:
+            stack.append(nn.GELU())
+    stack.append(nn.Linear(width, out_channels))
+    return nn.Sequential(*stack)
+
+
+class MLPBlock(nn.Module):
+    """Token-wise MLP; the submodule is called ``network`` (SyntheticExperiments/psf.py:50-60)."""
+
+    def __init__(self, cfg: LayerSpec, in_dim: int, out_dim: int):
+        super().__init__()
+        self.network = MakeMLP(cfg, in_dim, out_dim)
+
+    def forward(self, data: torch.Tensor) -> torch.Tensor:
+        return self.network(data)
+
+
+class _ChordMixer(nn.Module):
+    """Shared machinery: the f/g networks and the chain V <- W_m V (+ V_0)."""
+
+    #: run all M products in one library call (default) instead of one autograd node per factor
+    fused_chain: bool = True
+
+    def _build_mixer(self, seq_len: int, n_W: int, Ws: LayerSpec, V: LayerSpec, width_in: int, channels: int,
+                     use_cuda: bool) -> None:
+        self.fs = nn.ModuleList([MLPBlock(Ws, width_in, n_W + 1) for _ in range(n_W)])
+        self.g = MLPBlock(V, width_in, channels)
+        self._seq_len = seq_len
+
+    def _build_indices(self, seq_len: int, n_links: int, use_cuda: bool) -> None:
+        # Kept for scripts that pass it to spmm themselves (e.g. ChangedPSF, pathfinder_inference.py:66-81).
+        # A plain attribute like in the reference (psf.py:143-145): not a parameter, not in the state_dict.
+        idx = torch.tensor(get_chord_indices_assym(seq_len, n_links), dtype=torch.int64)
+        self.chord_indicies = idx.cuda() if use_cuda else idx
+
+    def _apply(self, fn, *args, **kwargs):
+        # net.cuda() / net.to(device) also moves the index attribute (the reference leaves it behind).
+        super()._apply(fn, *args, **kwargs)
+        idx = getattr(self, "chord_indicies", None)
+        if isinstance(idx, torch.Tensor):
+            moved = fn(idx)
+            if moved.dtype == torch.int64:
+                self.chord_indicies = moved
+        return self
+
+    def link_weights(self, data: torch.Tensor) -> List[torch.Tensor]:
+        """W_m = fs[m](data), each [B, N, L] (psf.py:175)."""
+        return [f(data) for f in self.fs]
+
+    def mix(self, data: torch.Tensor, V: torch.Tensor, use_residuals: bool, links=None) -> torch.Tensor:
+        """The hot loop of PSFNet.forward (SyntheticExperiments/psf.py:167-188). ``links`` may carry
+        precomputed W_m (from ``link_weights``)."""
+        if self.fused_chain or links is not None:
+            return chord_chain(self.link_weights(data) if links is None else links, V, use_residuals)
+        res_conn = V if use_residuals else None
+        for f in self.fs:
+            V = chord_spmm(f(data), V, res_conn)
+        return V
+
+
+class SyntheticPSFNet(_ChordMixer):
+    """Adding / Temporal-Order model — SyntheticExperiments/psf.py:62-191."""
+
+    def __init__(self, vocab_size, add_init_linear_layer, embedding_size, n_vec, n_W, Ws, V, n_channels_V,
+                 n_class, pooling_type, head, use_cuda, use_residuals, use_pos_embedding, problem):
+        super().__init__()
+        self.vocab_size = vocab_size
+        self.add_init_linear_layer = add_init_linear_layer
+        self.embedding_size = embedding_size
+        self.n_vec = n_vec
+        self.n_W = n_W
+        self.n_links = n_W + 1
+        self.Ws = Ws
+        self.V = V
+        self.n_channels_V = n_channels_V
+        self.n_class = n_class
+        self.pooling_type = pooling_type
+        self.head = head
+        self.use_cuda = use_cuda
+        self.use_residuals = use_residuals
+        self.use_pos_embedding = use_pos_embedding
+        self.problem = problem
+
+        # construction order follows the reference so a given torch seed draws the same initial weights
+        self.embedding = nn.Embedding(vocab_size, embedding_size)
+        self.pos_embedding = nn.Embedding(n_vec, embedding_size)
+        self._build_mixer(n_vec, n_W, Ws, V, embedding_size, n_channels_V, use_cuda)
+        if head[0] == 'linear':
+            self.final = nn.Linear(n_vec * n_channels_V, n_class, bias=True)
+        if add_init_linear_layer:
+            self.init_linear = nn.Linear(2, embedding_size, bias=True)
+        self._build_indices(n_vec, self.n_links, use_cuda)
+
+    def forward(self, data):
+        if self.problem == 'order':
+            data = self.embedding(data).squeeze(-2)
+        if self.add_init_linear_layer:
+            data = self.init_linear(data)
+        if self.use_pos_embedding:
+            data = data + self.pos_embedding.weight.unsqueeze(0)  # == pos_embedding(arange(n_vec)) per sample
+        V = self.g(data)
+        V = self.mix(data, V, self.use_residuals)
+        return self.final(V.reshape(V.size(0), -1))
+
+
+class _TokenPSFNet(_ChordMixer):
+    """Common body of the LRA and Genome models (LRA/psf.py:63-250, Genome_Clf/psf.py:63-240)."""
+
+    def _init_common(self, vocab_size, embedding_size, n_vec, n_W, Ws, V, n_channels_V, n_class, pooling_type,
+                     head, use_cuda, use_residuals, dropout1_p, dropout2_p, dropout3_p, init_embedding_weights,
+                     use_pos_embedding, padding_idx):
+        self.vocab_size = vocab_size
+        self.embedding_size = embedding_size
+        self.n_vec = n_vec
+        self.n_W = n_W
+        self.n_links = n_W + 1
+        self.Ws = Ws
+        self.V = V
+        self.n_channels_V = n_channels_V
+        self.n_class = n_class
+        self.pooling_type = pooling_type
+        self.head = head
+        self.use_cuda = use_cuda
+        self.use_residuals = use_residuals
+        self.dropout1_p = dropout1_p
+        self.dropout2_p = dropout2_p
+        self.dropout3_p = dropout3_p
+        self.init_embedding_weights = init_embedding_weights
+        self.use_pos_embedding = use_pos_embedding
+
+        if padding_idx is None:
+            self.embedding = nn.Embedding(vocab_size, embedding_size)
+        else:
+            self.embedding = nn.Embedding(vocab_size, embedding_size, padding_idx=padding_idx)
+        self.pos_embedding = nn.Embedding(n_vec, embedding_size)
+        if init_embedding_weights:
+            self.init_embed_weights()
+        self._build_mixer(n_vec, n_W, Ws, V, embedding_size, n_channels_V, use_cuda)
+
+        pooled = n_vec * n_channels_V if pooling_type == 'FLATTEN' else n_channels_V
+        if pooling_type in ('FLATTEN', 'CLS'):
+            if head[0] == 'linear':
+                self.final = nn.Linear(pooled, n_class)
+            elif head[0] == 'non-linear':
+                self.final = nn.Sequential(nn.Linear(pooled, head[1]), nn.GELU(), nn.Linear(head[1], n_class))
+
+        self.dropout1 = nn.Dropout(dropout1_p)
+        self.dropout2 = nn.Dropout(dropout2_p)
+        self.dropout3 = nn.Dropout(dropout3_p)
+        self._build_indices(n_vec, self.n_links, use_cuda)
+
+    def init_embed_weights(self):
+        """uniform(-0.1, 0.1) token embeddings (LRA/psf.py:192-195)."""
+        self.embedding.weight.data.uniform_(-0.1, 0.1)
+        self.embedding.weight.requires_grad = True
+
+    def features(self, data, links=None):
+        """Everything up to and including the chain and dropout3: returns V [B,N,C]. When ``links`` is a
+        list it is filled with the W_m that were used."""
+        data = self.embedding(data)
+        if self.use_pos_embedding:
+            data = data + self.pos_embedding.weight.unsqueeze(0)
+        data = self.dropout1(data)
+        V = self.dropout2(self.g(data))
+        if links is not None:
+            links.extend(self.link_weights(data))
+        V = self.mix(data, V, self.use_residuals, links)
+        return self.dropout3(V)
+
+    def pool_and_classify(self, V):
+        if self.pooling_type == 'CLS':
+            V = V[:, 0, :]
+        return self.final(V.reshape(V.size(0), -1))
+
+    def forward(self, data):
+        return self.pool_and_classify(self.features(data))
+
+
+class LRAPSFNet(_TokenPSFNet):
+    """LRA model (ListOps / IMDb / CIFAR-10 / Pathfinder) — LRA/psf.py:63-250."""
+
+    def __init__(self, vocab_size, embedding_size, n_vec, n_W, Ws, V, n_channels_V, n_class, pooling_type, head,
+                 use_cuda, use_residuals, dropout1_p, dropout2_p, dropout3_p, init_embedding_weights,
+                 use_pos_embedding, problem):
+        super().__init__()
+        self.problem = problem
+        if problem in ('imdb', 'listops'):
+            padding_idx = vocab_size - 2  # LRA/psf.py:106-111
+        elif problem in ('cifar10', 'pathfinder'):
+            padding_idx = None
+        else:
+            raise ValueError(f"unknown LRA problem '{problem}' (imdb, listops, cifar10, pathfinder)")
+        self._init_common(vocab_size, embedding_size, n_vec, n_W, Ws, V, n_channels_V, n_class, pooling_type,
+                          head, use_cuda, use_residuals, dropout1_p, dropout2_p, dropout3_p,
+                          init_embedding_weights, use_pos_embedding, padding_idx)
+
+
+class GenomePSFNet(_TokenPSFNet):
+    """Genome classification model — Genome_Clf/psf.py:63-240 (the LRA model without ``problem``)."""
+
+    def __init__(self, vocab_size, embedding_size, n_vec, n_W, Ws, V, n_channels_V, n_class, pooling_type, head,
+                 use_cuda, use_residuals, dropout1_p, dropout2_p, dropout3_p, init_embedding_weights,
+                 use_pos_embedding):
+        super().__init__()
+        self._init_common(vocab_size, embedding_size, n_vec, n_W, Ws, V, n_channels_V, n_class, pooling_type,
+                          head, use_cuda, use_residuals, dropout1_p, dropout2_p, dropout3_p,
+                          init_embedding_weights, use_pos_embedding, None)
+
+
+class AttentionBlockPSF(_ChordMixer):
+    """Stand-alone PSF attention block — attention_block.py:70-178. n_W = ceil(log2(max_seq_len)),
+    C = embedding_size, returns the mixed sequence [B, N, E] instead of logits."""
+
+    def __init__(self, vocab_size, embedding_size, max_seq_len, use_cuda, use_residuals, dropout1_p, dropout2_p,
+                 dropout3_p):
+        super().__init__()
+        self.vocab_size = vocab_size
+        self.embedding_size = embedding_size
+        self.max_seq_len = max_seq_len
+        self.n_W = math.ceil(math.log2(max_seq_len))
+        self.n_links = self.n_W + 1
+        self.Ws = [embedding_size, 'GELU']
+        self.V = [embedding_size, 'GELU']
+        self.use_cuda = use_cuda
+        self.use_residuals = use_residuals
+        self.dropout1_p = dropout1_p
+        self.dropout2_p = dropout2_p
+        self.dropout3_p = dropout3_p
+
+        self._build_mixer(max_seq_len, self.n_W, self.Ws, self.V, embedding_size, embedding_size, use_cuda)
+        self.dropout1 = nn.Dropout(dropout1_p)
+        self.dropout2 = nn.Dropout(dropout2_p)
+        self.dropout3 = nn.Dropout(dropout3_p)
+        self._build_indices(max_seq_len, self.n_links, use_cuda)
+        self.embedding = nn.Embedding(vocab_size, embedding_size)
+        self.apc_embedding = nn.Embedding(max_seq_len, embedding_size)
+
+    def forward(self, data):
+        data = self.embedding(data) + self.apc_embedding.weight.unsqueeze(0)
+        data = self.dropout1(data)
+        V = self.dropout2(self.g(data))
+        V = self.mix(data, V, self.use_residuals)
+        return self.dropout3(V)
+
+
+class ChangedPSF(LRAPSFNet):
+    """LRAPSFNet that also returns the dense attention map ``W_M ... W_1`` — the ``ChangedPSF`` class of
+    LRA/attention_maps/pathfinder_inference.py:30-94 and imdb_inference.py:24-71.
+
+    The map is the same operator applied to ``eye(N)``: C = N channels, first operand unbatched
+    (pathfinder_inference.py:57,75-81), no residual on the map.
+    """
+
+    def forward(self, data):
+        Ws: List[torch.Tensor] = []
+        V = self.features(data, Ws)  # dropout3 after the chain, as in the reference
+        eye = torch.eye(self.n_vec, self.n_vec, dtype=V.dtype, device=V.device)
+        W_final = chord_chain(Ws, eye, False)
+        return self.pool_and_classify(V), W_final
