@@ -1,0 +1,217 @@
+"""CPU: the C-ABI library loads and exports every symbol of include/psf_chord.h; host-only entry points and
+argument validation (everything that returns before the first HIP call); Python host logic and module surface.
+No compute is launched here.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from sparsefactorization_amd import _lib, build
+    build.build()  # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "psf_chord.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(psf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_exports_every_declared_symbol(lib):
+    from sparsefactorization_amd import _lib
+    declared = _declared_functions()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), f"libpsf_chord.so does not export {name}"
+    assert sorted(_lib.SIGNATURES) == declared  # the ctypes table binds exactly the header
+    assert lib.psf_version() == 1
+    assert b"gfx950" in lib.psf_build_info()
+
+
+def test_chord_indices_host_routine_matches_reference(lib):
+    g = load_golden("chord_indices.npz")
+    for n, l in g["full_cases"]:
+        n, l = int(n), int(l)
+        rows = (ctypes.c_int64 * (n * l))()
+        cols = (ctypes.c_int64 * (n * l))()
+        assert lib.psf_chord_indices(n, l, rows, cols) == 0
+        assert np.array_equal(np.frombuffer(rows, dtype=np.int64), g[f"rows_{n}_{l}"])
+        assert np.array_equal(np.frombuffer(cols, dtype=np.int64), g[f"cols_{n}_{l}"])
+
+
+def test_python_helper_returns_reference_types(lib):
+    import sparsefactorization_amd as sfa
+    g = load_golden("psfnet_adding_n128.npz")
+    rows, cols = sfa.get_chord_indices_assym(128, 8)
+    assert isinstance(rows, list) and isinstance(cols, list)
+    assert np.array_equal(torch.tensor((rows, cols)).numpy(), g["chord_indicies"])
+
+
+def test_offsets(lib):
+    from sparsefactorization_amd import _lib
+    assert _lib.chord_offsets(16384, 15) == [0] + [2 ** k for k in range(14)]
+    assert _lib.chord_offsets(1024, 12)[-1] == 0          # 2^10 mod 1024: duplicate self link
+    assert _lib.chord_offsets(100, 9) == [0, 1, 2, 4, 8, 16, 32, 64, 28]
+    assert _lib.chord_offsets(1, 4) == [0, 0, 0, 0]
+    assert _lib.chord_offsets(3, 64)[63] == pow(2, 62, 3)
+
+
+def test_argument_validation_returns_codes_not_crashes(lib):
+    f = lib.psf_chord_spmm_fwd_f32
+    one = ctypes.c_void_p(16)
+    two = ctypes.c_void_p(32)
+    assert f(None, one, None, two, 1, 8, 4, 4, 32, None, None) == -1          # PSF_E_NULL
+    assert f(one, one, None, two, 1, 0, 4, 4, 0, None, None) == -2            # PSF_E_SHAPE (N < 1)
+    assert f(one, one, None, two, 1, 8, 65, 4, 32, None, None) == -2          # L > PSF_MAX_LINKS
+    assert f(one, one, None, two, 1, 8, 4, 4, 7, None, None) == -2            # bad batch stride
+    assert f(one, two, None, two, 1, 8, 4, 4, 32, None, None) == -3           # PSF_E_ALIAS
+    assert f(ctypes.c_void_p(18), one, None, two, 1, 8, 4, 4, 32, None, None) == -4  # PSF_E_ALIGN
+    assert f(one, one, None, two, 0, 8, 4, 4, 32, None, None) == 0            # empty batch: nothing to do
+    assert b"alias" in lib.psf_last_error()  or lib.psf_last_error() is not None
+    b = lib.psf_chord_spmm_bwd_f32
+    assert b(None, one, one, two, two, 1, 8, 4, 4, 32, None, None) == -1
+    assert b(one, None, one, None, two, 1, 8, 4, 4, 32, None, None) == -1     # dV needs W
+    assert b(one, one, one, None, one, 1, 8, 4, 4, 32, None, None) == -3      # dV aliases dZ
+    c = lib.psf_chord_chain_fwd_f32
+    assert c(None, one, None, 2, 0, 1, 8, 4, 4, 32, None, None) == -1
+    assert c(None, None, None, 0, 0, 1, 8, 4, 4, 32, None, None) == 0          # M == 0
+
+
+def test_tuning_knobs(lib):
+    import sparsefactorization_amd as sfa
+    assert sfa.get_tuning("fwd_variant") == 0
+    sfa.set_tuning("fwd_variant", 1)
+    assert "generic" in sfa.describe_fwd(64, 16384, 15, 8)
+    sfa.set_tuning("fwd_variant", 0)
+    assert "win" in sfa.describe_fwd(64, 16384, 15, 8)
+    with pytest.raises(sfa.PSFLibraryError):
+        sfa.set_tuning("no_such_knob", 1)
+    with pytest.raises(sfa.PSFLibraryError):
+        sfa.set_tuning("fwd_variant", 99)
+
+
+def test_no_cpu_fallback(lib):
+    """CPU tensors must raise: the product has no CPU path (the oracle is test infrastructure only)."""
+    import sparsefactorization_amd as sfa
+    W, V = torch.zeros(1, 8, 4), torch.zeros(1, 8, 4)
+    with pytest.raises(RuntimeError, match="HIP"):
+        sfa.chord_spmm(W, V)
+    with pytest.raises(RuntimeError, match="HIP"):
+        sfa.chord_chain([W], V)
+    idx = torch.tensor(sfa.get_chord_indices_assym(8, 4))
+    with pytest.raises(RuntimeError, match="HIP"):
+        sfa.spmm(idx, W.reshape(1, 32), 8, 8, V)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "sparsefactorization_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+\.*oracle", text, flags=re.M), f
+                assert "liboracle" not in text and "chord_oracle" not in text, f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from sparsefactorization_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libpsf_chord.so"))
+    with pytest.raises(_lib.PSFLibraryError, match="not built"):
+        _lib.load()
+
+
+def test_offsets_from_index_validation():
+    from sparsefactorization_amd.chord import offsets_from_index
+    import sparsefactorization_amd as sfa
+    idx = torch.tensor(sfa.get_chord_indices_assym(100, 9))
+    assert offsets_from_index(idx, 100) == (0, 1, 2, 4, 8, 16, 32, 64, 28)
+    bad = idx.clone()
+    bad[0, 3] = 7
+    with pytest.raises(ValueError, match="rows"):
+        offsets_from_index(bad, 100)
+    bad = idx.clone()
+    bad[1, 20] += 1
+    with pytest.raises(ValueError, match="cols"):
+        offsets_from_index(bad, 100)
+    with pytest.raises(ValueError):
+        offsets_from_index(idx[:, :-1], 100)
+
+
+# ---------------------------------------------------------------------------------------------------
+# module surface: constructor signatures, attribute names, state_dict layout, shipped checkpoints
+# ---------------------------------------------------------------------------------------------------
+def _layouts():
+    out = {}
+    for line in load_golden("checkpoint_layouts.npz")["layouts"]:
+        ck, key, shape = str(line).split("|")
+        out.setdefault(ck, {})[key] = tuple(int(s) for s in shape.split("x")) if shape else ()
+    return out
+
+
+PATHFINDER = dict(vocab_size=225, embedding_size=32, n_vec=1024, n_W=11, Ws=[128, 'GELU'], V=[128, 'GELU'],
+                  n_channels_V=32, n_class=2, pooling_type="FLATTEN", head=['linear'], use_cuda=False,
+                  use_residuals=False, dropout1_p=0, dropout2_p=0, dropout3_p=0, init_embedding_weights=False,
+                  use_pos_embedding=True, problem="pathfinder")
+IMDB = dict(vocab_size=97, embedding_size=32, n_vec=4097, n_W=12, Ws=[128, 'GELU'], V=[128, 'GELU'],
+            n_channels_V=32, n_class=2, pooling_type="CLS", head=['linear'], use_cuda=False, use_residuals=True,
+            dropout1_p=0.4, dropout2_p=0, dropout3_p=0, init_embedding_weights=True, use_pos_embedding=False,
+            problem="imdb")
+
+
+@pytest.mark.parametrize("ckpt,cfg", [("pathfinder_epoch27.pt", PATHFINDER), ("imdb_epoch138.pt", IMDB)])
+def test_state_dict_layout_matches_shipped_checkpoints(lib, ckpt, cfg):
+    """LRA/psf_training_config.py:60-117 configs; layouts recorded from LRA/attention_maps/*.pt."""
+    from sparsefactorization_amd.lra_psf import PSFNet
+    net = PSFNet(**cfg)
+    mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert mine == _layouts()[ckpt]
+    assert "chord_indicies" not in mine
+    assert net.chord_indicies.shape == (2, cfg["n_vec"] * (cfg["n_W"] + 1))
+    assert net.n_links == cfg["n_W"] + 1
+
+
+def test_synthetic_module_surface(lib):
+    from sparsefactorization_amd.synthetic_psf import PSFNet, MLPBlock, MakeMLP, get_chord_indices_assym  # noqa: F401
+    g = load_golden("psfnet_adding_n128.npz")
+    torch.manual_seed(42)
+    net = PSFNet(vocab_size=1, add_init_linear_layer=True, embedding_size=32, n_vec=128, n_W=7, Ws=[32, 'GELU'],
+                 V=[32, 'GELU'], n_channels_V=8, n_class=1, pooling_type="FLATTEN", head=['linear'],
+                 use_cuda=False, use_residuals=True, use_pos_embedding=False, problem="adding")
+    want = {k[4:]: g[k] for k in g.files if k.startswith("sd::")}
+    sd = net.state_dict()
+    assert set(sd) == set(want)
+    # same construction order as the reference => the same seed draws the same initial weights
+    for k, v in want.items():
+        assert np.array_equal(sd[k].numpy(), v), k
+    assert np.array_equal(net.chord_indicies.numpy(), g["chord_indicies"])
+    for attr in ("fs", "g", "final", "embedding", "pos_embedding", "init_linear", "n_W", "n_links", "n_vec"):
+        assert hasattr(net, attr)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in want.items()}, strict=True)
+
+
+def test_attention_block_surface(lib):
+    from sparsefactorization_amd.attention_block import PSFNet
+    net = PSFNet(vocab_size=256, embedding_size=16, max_seq_len=100, use_cuda=False, use_residuals=False,
+                 dropout1_p=0, dropout2_p=0, dropout3_p=0)
+    assert net.n_W == 7 and net.n_links == 8
+    keys = set(net.state_dict())
+    assert {"embedding.weight", "apc_embedding.weight", "g.network.0.weight", "fs.6.network.2.bias"} <= keys
+
+
+def test_genome_surface(lib):
+    from sparsefactorization_amd.genome_psf import PSFNet
+    cfg = dict(IMDB)
+    cfg.pop("problem")
+    cfg.update(n_vec=64, n_W=6)
+    net = PSFNet(**cfg)
+    assert net.embedding.padding_idx is None

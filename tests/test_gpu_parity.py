@@ -1,0 +1,326 @@
+"""GPU: the HIP path (through the C ABI, via the ctypes host side) against the CPU oracle.
+
+Tolerance: BASELINE.json asks for <= 1e-5 relative fp32. The forward kernels use the oracle's summation order
+with uncontracted mul/add, so most forward checks demand BIT equality; gradients (different association in dW's
+cross-lane reduction) are held to max|a-b| <= 1e-5 * max|ref|.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_inf
+from oracle import chord_oracle as oc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _mk(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape, dtype=np.float32) * scale).astype(np.float32)
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _oracle_fwd(W, V, res=None, offsets=None):
+    out = oc.spmul_fwd(W, V, offsets)
+    if res is not None:
+        out = out + res
+    return out
+
+
+FWD_SHAPES = [
+    # (B, N, L, C) — cfg1; non-pow2 N; N smaller than a tile; duplicate self link (N=1024, L=12); wide rows;
+    # C not a multiple of 4 (scalar path); L beyond the window kernels; ragged last tile
+    (40, 128, 8, 8), (3, 2000, 12, 16), (2, 100, 9, 8), (2, 1024, 12, 32), (2, 1024, 12, 8), (2, 513, 10, 128),
+    (2, 300, 9, 6), (1, 64, 7, 1), (2, 2048, 12, 64), (1, 4097, 13, 8), (2, 777, 22, 4), (1, 16384, 15, 8),
+    (2, 256, 9, 260), (1, 1000, 4, 12), (2, 96, 3, 8), (1, 1, 1, 4), (3, 2, 2, 8), (1, 5000, 24, 8),
+]
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("B,N,L,C", FWD_SHAPES)
+def test_forward_step_bit_exact(gpu, B, N, L, C, variant):
+    import sparsefactorization_amd as sfa
+    W, V, R = _mk((B, N, L), 1), _mk((B, N, C), 2), _mk((B, N, C), 3)
+    sfa.set_tuning("fwd_variant", variant)
+    try:
+        for res in (None, R):
+            got = sfa.chord_spmm(_t(W, gpu), _t(V, gpu), None if res is None else _t(res, gpu)).cpu().numpy()
+            want = _oracle_fwd(W, V, res)
+            assert np.array_equal(got, want), f"variant={variant} res={res is not None} rel={rel_inf(got, want):.3e}"
+    finally:
+        sfa.set_tuning("fwd_variant", 0)
+
+
+@pytest.mark.parametrize("rows", [1, 2, 4, 8])
+@pytest.mark.parametrize("B,N,L,C", [(2, 16384, 15, 8), (2, 2000, 12, 32), (2, 2048, 12, 128), (3, 1100, 11, 8)])
+def test_forward_window_rows_variants(gpu, B, N, L, C, rows):
+    import sparsefactorization_amd as sfa
+    W, V, R = _mk((B, N, L), 4), _mk((B, N, C), 5), _mk((B, N, C), 6)
+    sfa.set_tuning("fwd_rows", rows)
+    try:
+        got = sfa.chord_spmm(_t(W, gpu), _t(V, gpu), _t(R, gpu)).cpu().numpy()
+    finally:
+        sfa.set_tuning("fwd_rows", 0)
+    assert np.array_equal(got, _oracle_fwd(W, V, R))
+
+
+def test_forward_xcd_remap_off(gpu):
+    import sparsefactorization_amd as sfa
+    W, V = _mk((5, 1000, 11), 7), _mk((5, 1000, 8), 8)
+    sfa.set_tuning("xcd_remap", 0)
+    try:
+        got = sfa.chord_spmm(_t(W, gpu), _t(V, gpu)).cpu().numpy()
+    finally:
+        sfa.set_tuning("xcd_remap", 1)
+    assert np.array_equal(got, _oracle_fwd(W, V))
+
+
+def test_forward_broadcast_first_operand(gpu):
+    """Unbatched eye(N) as in ChangedPSF (pathfinder_inference.py:57,75-81)."""
+    import sparsefactorization_amd as sfa
+    B, N, L = 3, 256, 9
+    W = _mk((B, N, L), 9)
+    eye = np.eye(N, dtype=np.float32)
+    got = sfa.chord_spmm(_t(W, gpu), _t(eye, gpu)).cpu().numpy()
+    assert np.array_equal(got, oc.spmul_fwd(W, eye))
+
+
+def test_forward_explicit_offsets(gpu):
+    """Arbitrary / negative / >= N offsets, the `offsets` argument of spmul/spmul.py:15."""
+    import sparsefactorization_amd as sfa
+    B, N, L, C = 2, 500, 6, 8
+    W, V = _mk((B, N, L), 10), _mk((B, N, C), 11)
+    off = [3, 0, 499, 1000, -7, 250]
+    got = sfa.chord_spmm(_t(W, gpu), _t(V, gpu), offsets=off).cpu().numpy()
+    assert np.array_equal(got, oc.spmul_fwd(W, V, off))
+
+
+def test_forward_f64(gpu):
+    import sparsefactorization_amd as sfa
+    rng = np.random.default_rng(12)
+    W, V = rng.standard_normal((2, 300, 10)), rng.standard_normal((2, 300, 6))
+    got = sfa.chord_spmm(_t(W, gpu), _t(V, gpu)).cpu().numpy()
+    assert np.array_equal(got, oc.spmul_fwd(W, V))
+
+
+def test_spmm_dropin_signature(gpu):
+    """spmm(index, value, m, n, matrix) exactly as SyntheticExperiments/psf.py:178-184 calls it."""
+    import sparsefactorization_amd as sfa
+    B, N, L, C = 4, 128, 8, 8
+    W, V = _mk((B, N, L), 13), _mk((B, N, C), 14)
+    idx = torch.tensor(sfa.get_chord_indices_assym(N, L)).to(gpu)
+    Wt = _t(W, gpu)
+    got = sfa.spmm(idx, Wt.reshape(Wt.size(0), Wt.size(1) * Wt.size(2)), N, N, _t(V, gpu)).cpu().numpy()
+    rows, cols = oc.chord_indices(N, L)
+    want = oc.spmm(np.stack([rows, cols]), W.reshape(B, N * L), N, N, V)
+    assert np.array_equal(got, want)
+
+
+BWD_SHAPES = [(4, 128, 8, 8), (2, 2000, 12, 16), (2, 100, 9, 8), (2, 1024, 12, 32), (1, 513, 10, 128),
+              (2, 300, 9, 6), (1, 64, 7, 1), (1, 4097, 13, 8), (2, 256, 9, 260)]
+
+
+@pytest.mark.parametrize("B,N,L,C", BWD_SHAPES)
+def test_backward_step(gpu, B, N, L, C):
+    import sparsefactorization_amd as sfa
+    W, V, dZ = _mk((B, N, L), 15), _mk((B, N, C), 16), _mk((B, N, C), 17)
+    Wt = _t(W, gpu).requires_grad_(True)
+    Vt = _t(V, gpu).requires_grad_(True)
+    Rt = _t(np.zeros_like(V), gpu).requires_grad_(True)
+    out = sfa.chord_spmm(Wt, Vt, Rt)
+    out.backward(_t(dZ, gpu))
+    dF, dV = oc.spmul_bwd(dZ, W, V)
+    assert np.array_equal(Vt.grad.cpu().numpy(), dV)  # same order, uncontracted -> exact
+    assert rel_inf(Wt.grad.cpu().numpy(), dF) <= TOL
+    assert np.array_equal(Rt.grad.cpu().numpy(), dZ)
+
+
+def test_backward_broadcast_V(gpu):
+    import sparsefactorization_amd as sfa
+    B, N, L, C = 3, 128, 8, 16
+    W, V, dZ = _mk((B, N, L), 18), _mk((N, C), 19), _mk((B, N, C), 20)
+    Wt = _t(W, gpu).requires_grad_(True)
+    Vt = _t(V, gpu).requires_grad_(True)
+    sfa.chord_spmm(Wt, Vt).backward(_t(dZ, gpu))
+    dF, dV = oc.spmul_bwd(dZ, W, V)
+    assert rel_inf(Wt.grad.cpu().numpy(), dF) <= TOL
+    assert rel_inf(Vt.grad.cpu().numpy(), dV.sum(0)) <= TOL
+
+
+def test_gradcheck_f64(gpu):
+    import sparsefactorization_amd as sfa
+    g = torch.Generator().manual_seed(21)
+    W = torch.randn(2, 24, 5, dtype=torch.float64, generator=g).to(gpu).requires_grad_(True)
+    V = torch.randn(2, 24, 3, dtype=torch.float64, generator=g).to(gpu).requires_grad_(True)
+    R = torch.randn(2, 24, 3, dtype=torch.float64, generator=g).to(gpu).requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda w, v, r: sfa.chord_spmm(w, v, r), (W, V, R), eps=1e-6, atol=1e-7)
+    assert torch.autograd.gradcheck(lambda w1, w2, v: sfa.chord_chain([w1, w2], v, True),
+                                    (W, W.detach().clone().requires_grad_(True), V), eps=1e-6, atol=1e-7)
+
+
+def test_sparse_multiply_dropin(gpu):
+    """SparseMultiply.apply(F, V, offsets, n_block, ...) — spmul/spmul.py:12-31."""
+    from sparsefactorization_amd.spmul import SparseMultiply, get_offsets
+    B, N, L, C = 2, 200, 8, 12
+    F, V, dZ = _mk((B, N, L), 22), _mk((B, N, C), 23), _mk((B, N, C), 24)
+    Ft, Vt = _t(F, gpu).requires_grad_(True), _t(V, gpu).requires_grad_(True)
+    off = get_offsets(L)
+    assert off.tolist() == [0, 1, 2, 4, 8, 16, 32, 64]
+    Z = SparseMultiply.apply(Ft, Vt, off, 16, 64, 16, 16)
+    assert np.array_equal(Z.detach().cpu().numpy(), oc.spmul_fwd(F, V))
+    Z.backward(_t(dZ, gpu))
+    dF, dV = oc.spmul_bwd(dZ, F, V)
+    assert rel_inf(Ft.grad.cpu().numpy(), dF) <= TOL
+    assert np.array_equal(Vt.grad.cpu().numpy(), dV)
+
+
+# ---------------------------------------------------------------------------------------------------
+# golden fixtures: operands captured from the reference's PSFNet.forward
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fixture,residual", [("psfnet_adding_n128.npz", True), ("psfnet_order_n128.npz", True),
+                                              ("lra_pathfinder_ckpt.npz", False)])
+def test_chain_against_reference_fixture(gpu, fixture, residual):
+    import sparsefactorization_amd as sfa
+    g = load_golden(fixture)
+    W, V0 = g["W"], g["V0"]
+    Ws = [_t(W[m], gpu) for m in range(W.shape[0])]
+    got = sfa.chord_chain(Ws, _t(V0, gpu), residual).cpu().numpy()
+    assert rel_inf(got, g["Vfin"]) <= TOL
+    # and bit-exact against the oracle's chain
+    M, B, N, L = W.shape
+    rows, cols = oc.chord_indices(N, L)
+    assert np.array_equal(got, oc.chain(np.stack([rows, cols]), W, V0, residual)[-1])
+    # step-by-step API gives the same bits as the fused call
+    V = _t(V0, gpu)
+    res = V if residual else None
+    for w in Ws:
+        V = sfa.chord_spmm(w, V, res)
+    assert np.array_equal(V.cpu().numpy(), got)
+
+
+@pytest.mark.parametrize("fixture", ["psfnet_adding_n128.npz", "psfnet_order_n128.npz"])
+def test_chain_gradients_against_reference_autograd(gpu, fixture):
+    import sparsefactorization_amd as sfa
+    g = load_golden(fixture)
+    W, V0 = g["W"], g["V0"]
+    Ws = [_t(W[m], gpu).requires_grad_(True) for m in range(W.shape[0])]
+    V0t = _t(V0, gpu).requires_grad_(True)
+    out = sfa.chord_chain(Ws, V0t, True)
+    out.backward(_t(g["gVfin"], gpu))
+    dW = np.stack([w.grad.cpu().numpy() for w in Ws])
+    assert rel_inf(dW, g["dW"]) <= TOL
+    assert rel_inf(V0t.grad.cpu().numpy(), g["dV0"]) <= TOL
+    # unfused path agrees
+    Ws2 = [_t(W[m], gpu).requires_grad_(True) for m in range(W.shape[0])]
+    V02 = _t(V0, gpu).requires_grad_(True)
+    V = V02
+    for w in Ws2:
+        V = sfa.chord_spmm(w, V, V02)
+    V.backward(_t(g["gVfin"], gpu))
+    assert rel_inf(np.stack([w.grad.cpu().numpy() for w in Ws2]), g["dW"]) <= TOL
+    assert rel_inf(V02.grad.cpu().numpy(), g["dV0"]) <= TOL
+
+
+def test_attention_map_against_fixture(gpu):
+    """W_M ... W_1 on eye(N): C = N = 1024, unbatched first operand (cfg4)."""
+    import sparsefactorization_amd as sfa
+    g = load_golden("lra_pathfinder_ckpt.npz")
+    W = g["W"]
+    N = W.shape[2]
+    Ws = [_t(W[m], gpu) for m in range(W.shape[0])]
+    Wf = sfa.chord_chain(Ws, torch.eye(N, device=gpu), False).cpu().numpy()
+    assert rel_inf(Wf[0, ::16, :], g["Wfinal_rows"]) <= TOL
+    assert rel_inf(Wf.sum(-1), g["Wfinal_rowsum"]) <= TOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# full BASELINE size (cfg2): size-independent properties
+# ---------------------------------------------------------------------------------------------------
+def _cfg2(gpu, B=64):
+    N, M, L, C = 16384, 14, 15, 8
+    g = torch.Generator(device=gpu)
+    Ws = []
+    for i in range(M):
+        g.manual_seed(1234 + i + 1)
+        Ws.append(0.1 * torch.randn(B, N, L, device=gpu, generator=g))
+    g.manual_seed(1234)
+    V0 = torch.randn(B, N, C, device=gpu, generator=g)
+    return Ws, V0
+
+
+def test_full_size_properties(gpu):
+    import sparsefactorization_amd as sfa
+    Ws, V0 = _cfg2(gpu)
+    out = sfa.chord_chain(Ws, V0, True)
+    assert torch.isfinite(out).all()
+    # determinism: no atomics anywhere -> bitwise repeatable
+    assert torch.equal(out, sfa.chord_chain(Ws, V0, True))
+    # fused chain == step-by-step
+    V = V0
+    for w in Ws:
+        V = sfa.chord_spmm(w, V, V0)
+    assert torch.equal(V, out)
+    # generic kernel == window kernel, bit for bit
+    sfa.set_tuning("fwd_variant", 1)
+    try:
+        assert torch.equal(sfa.chord_chain(Ws, V0, True), out)
+    finally:
+        sfa.set_tuning("fwd_variant", 0)
+    # linearity in V (no residual): chain(a*X + Y) == a*chain(X) + chain(Y) up to rounding
+    X, Y = V0, torch.roll(V0, 3, 0)
+    a = 0.5
+    lhs = sfa.chord_chain(Ws, a * X + Y, False)
+    rhs = a * sfa.chord_chain(Ws, X, False) + sfa.chord_chain(Ws, Y, False)
+    assert float((lhs - rhs).abs().max() / rhs.abs().max()) <= TOL
+    # spot-check 2 batch elements of the full-size chain against the oracle
+    sel = [0, 37]
+    W_np = np.stack([w[sel].cpu().numpy() for w in Ws])
+    rows, cols = oc.chord_indices(16384, 15)
+    want = oc.chain(np.stack([rows, cols]), W_np, V0[sel].cpu().numpy(), True)[-1]
+    assert np.array_equal(out[sel].cpu().numpy(), want)
+
+
+def test_full_size_shift_equivariance_and_identity(gpu):
+    """The pattern is circulant: rolling W and V along N rolls the output. W = e_0 (self link only) is identity."""
+    import sparsefactorization_amd as sfa
+    B, N, L, C = 8, 16384, 15, 8
+    g = torch.Generator(device=gpu).manual_seed(5)
+    W = torch.randn(B, N, L, device=gpu, generator=g)
+    V = torch.randn(B, N, C, device=gpu, generator=g)
+    out = sfa.chord_spmm(W, V)
+    s = 4099
+    out_s = sfa.chord_spmm(torch.roll(W, s, 1), torch.roll(V, s, 1))
+    assert torch.equal(torch.roll(out, s, 1), out_s)
+    Wid = torch.zeros(B, N, L, device=gpu)
+    Wid[:, :, 0] = 1.0
+    assert torch.equal(sfa.chord_spmm(Wid, V), V)
+    # adjoint identity <dZ, W.V> == <W^T.dZ, V> ties dV to the forward kernel at full size
+    dZ = torch.randn(B, N, C, device=gpu, generator=g)
+    Vr = V.clone().requires_grad_(True)
+    sfa.chord_spmm(W, Vr).backward(dZ)
+    lhs = (dZ.double() * out.double()).sum()
+    rhs = (Vr.grad.double() * V.double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-6 * abs(float(lhs))
+
+
+def test_errors(gpu):
+    import sparsefactorization_amd as sfa
+    W = torch.zeros(2, 16, 4, device=gpu)
+    V = torch.zeros(2, 16, 8, device=gpu)
+    with pytest.raises(RuntimeError):
+        sfa.chord_spmm(W.cpu(), V.cpu())  # no CPU path
+    with pytest.raises(TypeError):
+        sfa.chord_spmm(W.half(), V.half())
+    with pytest.raises(ValueError):
+        sfa.chord_spmm(W, torch.zeros(3, 16, 8, device=gpu))
+    idx = torch.tensor(sfa.get_chord_indices_assym(16, 4)).to(gpu)
+    bad = idx.clone()
+    bad[1, 5] = (bad[1, 5] + 1) % 16
+    with pytest.raises(ValueError):
+        sfa.spmm(bad, W.reshape(2, 64), 16, 16, V)
+    with pytest.raises(ValueError):
+        sfa.spmm(idx, W.reshape(2, 64), 16, 8, V)
