@@ -38,6 +38,7 @@ std::atomic<int> g_fwd_variant{0};  // 0 auto, 1 generic, 2 window
 std::atomic<int> g_bwd_variant{0};  // 0 auto, 1 generic
 std::atomic<int> g_xcd_remap{1};
 std::atomic<int> g_fwd_rows{0};     // 0 = table default, else rows per thread (R) of the window kernel
+std::atomic<int> g_fwd_dma{1};      // 1 = stage W tile / V window with LDS-DMA, 0 = through registers
 
 struct Knob {
   const char* key;
@@ -49,6 +50,7 @@ Knob g_knobs[] = {
     {"bwd_variant", &g_bwd_variant, 0, 1},
     {"xcd_remap", &g_xcd_remap, 0, 1},
     {"fwd_rows", &g_fwd_rows, 0, 8},
+    {"fwd_dma", &g_fwd_dma, 0, 1},
 };
 
 int ceil_log2(int64_t x) {
@@ -123,11 +125,11 @@ constexpr int kWinLmin = 4, kWinLmax = 20;
 // (measured r01, cfg2 C=8: R=2 32.7 us vs R=1 34.3 us vs R=4 41.8 us per launch)
 constexpr int default_rows(int tgs) { return tgs == 1 ? 2 : (tgs <= 2 ? 1 : (tgs <= 4 ? 2 : 4)); }
 
-template <typename T, int L, int TGS, int R>
-hipError_t launch_win(const T* W, const T* V, const T* res, T* out, const Geom& gm, const Offsets& offs,
-                      hipStream_t s) {
+template <typename T, int L, int TGS, int R, bool DMA>
+hipError_t launch_win_dma(const T* W, const T* V, const T* res, T* out, const Geom& gm, const Offsets& offs,
+                          int64_t w_total, hipStream_t s) {
   using Cfg = FwdWinCfg<T, L, TGS, R>;
-  auto kern = chord_fwd_win_k<T, L, TGS, R>;
+  auto kern = chord_fwd_win_k<T, L, TGS, R, DMA>;
   if (Cfg::lds_bytes > 48 * 1024) {
     static std::atomic<int> done{0};
     if (!done.load()) {
@@ -137,8 +139,15 @@ hipError_t launch_win(const T* W, const T* V, const T* res, T* out, const Geom& 
       done.store(1);
     }
   }
-  hipLaunchKernelGGL(kern, dim3(gm.nblocks), dim3(kBlock), Cfg::lds_bytes, s, W, V, res, out, gm, offs);
+  hipLaunchKernelGGL(kern, dim3(gm.nblocks), dim3(kBlock), Cfg::lds_bytes, s, W, V, res, out, gm, offs, w_total);
   return hipGetLastError();
+}
+
+template <typename T, int L, int TGS, int R>
+hipError_t launch_win(const T* W, const T* V, const T* res, T* out, const Geom& gm, const Offsets& offs,
+                      int64_t w_total, hipStream_t s) {
+  return g_fwd_dma.load() ? launch_win_dma<T, L, TGS, R, true>(W, V, res, out, gm, offs, w_total, s)
+                          : launch_win_dma<T, L, TGS, R, false>(W, V, res, out, gm, offs, w_total, s);
 }
 
 struct WinPick {
@@ -147,11 +156,11 @@ struct WinPick {
 
 template <typename T, int TGS, int R>
 hipError_t launch_win_L(int L, const T* W, const T* V, const T* res, T* out, const Geom& gm,
-                        const Offsets& offs, hipStream_t s) {
+                        const Offsets& offs, int64_t w_total, hipStream_t s) {
   switch (L) {
 #define PSF_CASE(LL) \
   case LL:           \
-    return launch_win<T, LL, TGS, R>(W, V, res, out, gm, offs, s);
+    return launch_win<T, LL, TGS, R>(W, V, res, out, gm, offs, w_total, s);
     PSF_CASE(4) PSF_CASE(5) PSF_CASE(6) PSF_CASE(7) PSF_CASE(8) PSF_CASE(9) PSF_CASE(10) PSF_CASE(11)
     PSF_CASE(12) PSF_CASE(13) PSF_CASE(14) PSF_CASE(15) PSF_CASE(16) PSF_CASE(17) PSF_CASE(18)
     PSF_CASE(19) PSF_CASE(20)
@@ -174,9 +183,9 @@ constexpr bool win_compiled(int tgs, int r) {
 
 template <typename T>
 hipError_t launch_win_any(int tgs, int rows, int L, const T* W, const T* V, const T* res, T* out,
-                          const Geom& gm, const Offsets& offs, hipStream_t s) {
+                          const Geom& gm, const Offsets& offs, int64_t w_total, hipStream_t s) {
 #define PSF_WIN(TGS, R) \
-  if (tgs == TGS && rows == R) return launch_win_L<T, TGS, R>(L, W, V, res, out, gm, offs, s);
+  if (tgs == TGS && rows == R) return launch_win_L<T, TGS, R>(L, W, V, res, out, gm, offs, w_total, s);
   PSF_WIN(0, 1)
   PSF_WIN(1, 1) PSF_WIN(1, 2) PSF_WIN(1, 4)
   PSF_WIN(2, 1)
@@ -235,7 +244,7 @@ int fwd_impl(const T* W, const T* V, const T* res, T* out, int64_t B, int64_t N,
     if (variant != 1 && pick_window<T>(N, L, C, offs, vec_ok, &pick)) {
       Geom gm;
       if (int rc = make_geom(B, N, L, C, VECW, pick.tgs, pick.TR, true, v_batch_stride, &gm)) return rc;
-      hipError_t e = launch_win_any<T>(pick.tgs, pick.rows, L, W, V, res, out, gm, offs, s);
+      hipError_t e = launch_win_any<T>(pick.tgs, pick.rows, L, W, V, res, out, gm, offs, B * N * (int64_t)L, s);
       if (e != hipSuccess) return fail_hip(e, "chord_fwd_win launch");
       return PSF_OK;
     }
@@ -428,8 +437,8 @@ int psf_describe_fwd(int64_t B, int64_t N, int32_t L, int64_t C, int32_t elem_by
   WinPick pick;
   const int variant = g_fwd_variant.load();
   if (variant != 1 && elem_bytes == 4 && pick_window<float>(N, L, C, offs, vec_ok, &pick)) {
-    snprintf(buf, cap, "chord_fwd_win_k<f32,L=%d,TG=%d,R=%d> TR=%d near=%d far=%d", (int)L, 1 << pick.tgs, pick.rows,
-             pick.TR, pick.KN, (int)L - pick.KN);
+    snprintf(buf, cap, "chord_fwd_win_k<f32,L=%d,TG=%d,R=%d,%s> TR=%d near=%d far=%d", (int)L, 1 << pick.tgs,
+             pick.rows, g_fwd_dma.load() ? "dma" : "reg", pick.TR, pick.KN, (int)L - pick.KN);
   } else {
     snprintf(buf, cap, "chord_fwd_generic_k<%s,VEC=%d>", elem_bytes == 4 ? "f32" : "f64", vec_ok ? vecw : 1);
   }

@@ -68,6 +68,40 @@ def test_forward_window_rows_variants(gpu, B, N, L, C, rows):
     assert np.array_equal(got, _oracle_fwd(W, V, R))
 
 
+@pytest.mark.parametrize("dma", [0, 1])
+@pytest.mark.parametrize("B,N,L,C,shift", [(3, 1101, 11, 8, 0), (3, 1101, 11, 8, 1), (2, 2000, 12, 16, 3),
+                                           (1, 515, 9, 32, 2), (5, 777, 13, 8, 1)])
+def test_forward_window_w_alignment_edges(gpu, B, N, L, C, shift, dma):
+    """W tiles are staged in 16-byte chunks: cover a W buffer whose start is not 16-byte aligned (a view
+    `shift` elements into an allocation), whose size is not a multiple of 16 bytes, and both staging paths."""
+    import sparsefactorization_amd as sfa
+    W, V, R = _mk((B, N, L), 31), _mk((B, N, C), 32), _mk((B, N, C), 33)
+    backing = torch.full((B * N * L + 8,), float("nan"), device=gpu)
+    Wt = backing[shift:shift + B * N * L].view(B, N, L)
+    Wt.copy_(_t(W, gpu))
+    assert Wt.data_ptr() % 16 == (4 * shift) % 16
+    sfa.set_tuning("fwd_dma", dma)
+    try:
+        assert "win" in sfa.describe_fwd(B, N, L, C)
+        got = sfa.chord_spmm(Wt, _t(V, gpu), _t(R, gpu)).cpu().numpy()
+    finally:
+        sfa.set_tuning("fwd_dma", 1)
+    assert np.array_equal(got, _oracle_fwd(W, V, R))
+
+
+@pytest.mark.parametrize("dma", [0, 1])
+def test_forward_staging_paths_agree_on_all_shapes(gpu, dma):
+    import sparsefactorization_amd as sfa
+    sfa.set_tuning("fwd_dma", dma)
+    try:
+        for (B, N, L, C) in [(40, 128, 8, 8), (2, 1024, 12, 32), (2, 513, 10, 128), (1, 16384, 15, 8), (2, 2048, 12, 64)]:
+            W, V = _mk((B, N, L), 34), _mk((B, N, C), 35)
+            got = sfa.chord_spmm(_t(W, gpu), _t(V, gpu)).cpu().numpy()
+            assert np.array_equal(got, _oracle_fwd(W, V)), (B, N, L, C)
+    finally:
+        sfa.set_tuning("fwd_dma", 1)
+
+
 def test_forward_xcd_remap_off(gpu):
     import sparsefactorization_amd as sfa
     W, V = _mk((5, 1000, 11), 7), _mk((5, 1000, 8), 8)
