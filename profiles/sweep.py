@@ -41,11 +41,9 @@ VARIANTS = [
     ("win_r4", {"fwd_variant": 2, "fwd_rows": 4}),
     ("win_r8", {"fwd_variant": 2, "fwd_rows": 8}),
     ("auto_noremap", {"xcd_remap": 0}),
-    ("auto_reg", {"fwd_dma": 0}),
-    ("win_r1_reg", {"fwd_variant": 2, "fwd_rows": 1, "fwd_dma": 0}),
-    ("win_r2_reg", {"fwd_variant": 2, "fwd_rows": 2, "fwd_dma": 0}),
+    ("auto_alledge", {"fwd_split": 0}),
 ]
-DEFAULTS = {"fwd_variant": 0, "fwd_rows": 0, "xcd_remap": 1, "fwd_dma": 1}
+DEFAULTS = {"fwd_variant": 0, "fwd_rows": 0, "xcd_remap": 1, "fwd_split": 1}
 
 
 def set_knobs(kn):
@@ -105,7 +103,7 @@ def main():
         seen = {}
         uniq = []
         for vname, kn, desc in usable:  # drop knob settings that resolve to an identical kernel
-            key = (desc, kn.get("xcd_remap", 1), kn.get("fwd_dma", 1) if "win" in desc else 1)
+            key = (desc, kn.get("xcd_remap", 1), kn.get("fwd_split", 1) if "win" in desc else 1)
             if key in seen:
                 continue
             seen[key] = vname

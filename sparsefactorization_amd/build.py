@@ -4,6 +4,10 @@ The analogue of the reference's spmul/setup.py (CUDAExtension('spmul_cuda', ['sp
 except that the product is a plain C-ABI shared object bound with ctypes — no torch headers, no pybind11.
 
     python -m sparsefactorization_amd.build [--force]
+
+Translation units: psf_chord.hip (C ABI, dispatch, generic kernels) and fwd_window_inst.hip compiled once per
+channel-group shift (-DPSF_TGS=0..6) — the window kernels are a few hundred template instances, so they are
+compiled in parallel and linked into one library.
 """
 from __future__ import annotations
 
@@ -11,18 +15,22 @@ import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
+OBJ_DIR = os.path.join(PKG_DIR, "build")
 LIB_PATH = os.path.join(PKG_DIR, "libpsf_chord.so")
 ARCH = "gfx950"
+WIN_TGS = list(range(7))
 
-SOURCES = ["psf_chord.hip"]
-HEADERS = ["psf_common.h", "fwd_kernels.h", "bwd_kernels.h", os.path.join("..", "..", "include", "psf_chord.h")]
+HEADERS = ["psf_common.h", "fwd_kernels.h", "fwd_window.h", "fwd_window_launch.h", "bwd_kernels.h",
+           os.path.join("..", "..", "include", "psf_chord.h")]
+SOURCES = ["psf_chord.hip", "fwd_window_inst.hip"]
 
 # -ffp-contract=off: products and sums stay separate roundings (bitwise parity with the CPU oracle).
-HIPCC_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-Wall", "-Wno-pass-failed"]
+HIPCC_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
+               "-Wno-pass-failed"]
 
 
 def hipcc() -> str:
@@ -30,6 +38,15 @@ def hipcc() -> str:
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found (looked at $HIPCC, PATH and /opt/rocm/bin/hipcc)")
+
+
+def _units():
+    """(object path, source, extra flags) for every translation unit."""
+    units = [(os.path.join(OBJ_DIR, "psf_chord.o"), os.path.join(CSRC, "psf_chord.hip"), [])]
+    for t in WIN_TGS:
+        units.append((os.path.join(OBJ_DIR, f"fwd_window_tgs{t}.o"), os.path.join(CSRC, "fwd_window_inst.hip"),
+                      [f"-DPSF_TGS={t}"]))
+    return units
 
 
 def needs_build() -> bool:
@@ -40,16 +57,33 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > lib_m for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into sparsefactorization_amd/libpsf_chord.so. Returns its path."""
-    if not force and not needs_build():
-        return LIB_PATH
-    cmd = [hipcc(), *HIPCC_FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH + ".tmp"]
+def _compile(unit, cc, verbose):
+    obj, src, extra = unit
+    cmd = [cc, *HIPCC_FLAGS, *extra, "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
+        raise RuntimeError(f"hipcc failed on {os.path.basename(src)} {extra} ({proc.returncode}):\n{proc.stderr[-4000:]}")
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
+    """Compile every HIP source for gfx950 into sparsefactorization_amd/libpsf_chord.so. Returns its path."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cc = hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    units = _units()
+    jobs = jobs or min(len(units), max(1, (os.cpu_count() or 2)))
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        objs = list(pool.map(lambda u: _compile(u, cc, verbose), units))
+    link = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(link), file=sys.stderr)
+    proc = subprocess.run(link, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"link failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 

@@ -1,0 +1,66 @@
+// fwd_window_inst.hip — instantiates the LDS-window forward kernels for ONE channel-group shift.
+// Built seven times (-DPSF_TGS=0 .. 6) so the instances compile in parallel; see build.py.
+#ifndef PSF_TGS
+#error "compile with -DPSF_TGS=<0..6>"
+#endif
+
+#include <atomic>
+
+#include "fwd_window.h"
+#include "fwd_window_launch.h"
+
+namespace psf {
+namespace {
+
+template <int L, int TGS, int R, bool RES, bool EDGE>
+hipError_t launch_one(const FwdWinArgs& a) {
+  using Cfg = FwdWinCfg<float, L, TGS, R, kWinThreads>;
+  auto kern = chord_fwd_win_k<float, L, TGS, R, kWinThreads, /*DMA=*/true, RES, EDGE>;
+  if (Cfg::lds_bytes > 48 * 1024) {
+    static std::atomic<int> done{0};
+    if (!done.load()) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::lds_bytes);
+      if (e != hipSuccess) return e;
+      done.store(1);
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(kWinThreads), Cfg::lds_bytes, a.stream, a.W, a.V, a.res, a.out,
+                     a.gm, a.offs, a.w_total);
+  return hipGetLastError();
+}
+
+template <int L, int TGS, int R>
+hipError_t launch_flags(const FwdWinArgs& a) {
+  if (a.res != nullptr) return a.edge ? launch_one<L, TGS, R, true, true>(a) : launch_one<L, TGS, R, true, false>(a);
+  return a.edge ? launch_one<L, TGS, R, false, true>(a) : launch_one<L, TGS, R, false, false>(a);
+}
+
+template <int TGS, int R>
+hipError_t launch_L(int L, const FwdWinArgs& a) {
+  switch (L) {
+#define PSF_CASE(LL) \
+  case LL:           \
+    return launch_flags<LL, TGS, R>(a);
+    PSF_CASE(4) PSF_CASE(5) PSF_CASE(6) PSF_CASE(7) PSF_CASE(8) PSF_CASE(9) PSF_CASE(10) PSF_CASE(11)
+    PSF_CASE(12) PSF_CASE(13) PSF_CASE(14) PSF_CASE(15) PSF_CASE(16) PSF_CASE(17) PSF_CASE(18)
+    PSF_CASE(19) PSF_CASE(20)
+#undef PSF_CASE
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace
+
+template <int TGS>
+hipError_t launch_fwd_win_tgs(int rows, int L, const FwdWinArgs& a) {
+  static_assert(kWinLmin == 4 && kWinLmax == 20, "keep the PSF_CASE list in step with kWinLmin/kWinLmax");
+  if (rows == 1) return launch_L<TGS, 1>(L, a);
+  if (rows == 2) return launch_L<TGS, 2>(L, a);
+  return hipErrorInvalidValue;
+}
+
+template hipError_t launch_fwd_win_tgs<PSF_TGS>(int rows, int L, const FwdWinArgs& a);
+
+}  // namespace psf

@@ -1,0 +1,41 @@
+// fwd_window_launch.h — host-side launcher interface of the LDS-window forward kernels.
+//
+// The kernels are templates over (L, TGS, R, RES, EDGE): a few hundred instances. They are compiled in one
+// translation unit per channel-group shift TGS (fwd_window_inst.hip built with -DPSF_TGS=0..6, in parallel) and
+// reached through launch_fwd_win_tgs<TGS>, which this header declares for the dispatcher in psf_chord.hip.
+#pragma once
+
+#include "psf_common.h"
+
+namespace psf {
+
+constexpr int kWinLmin = 4, kWinLmax = 20;  // compiled link counts
+constexpr int kWinTgsMax = 6;               // TG = 1 << TGS <= 64 lanes share a row
+constexpr int kWinThreads = 256;            // threads per workgroup (r01: 512/1024-thread tiles were no faster)
+
+// Rows per thread R that are compiled for every TGS, and the default.
+// r01 measurements (us per launch): cfg2 (C=8) R=2 27.5 < R=1 29.1; cfg3 (C=128) R=2 16.1 < R=4 16.9 < R=8 19.8;
+// cfg4 (C=32) R=1 6.0 ~ R=2 6.1 < R=4 6.4.
+constexpr bool win_rows_compiled(int r) { return r == 1 || r == 2; }
+constexpr int win_default_rows(int /*tgs*/) { return 2; }
+
+struct FwdWinArgs {
+  const float* W;
+  const float* V;
+  const float* res;  // nullptr: no residual (selects the RES = false kernels)
+  float* out;
+  Geom gm;
+  Offsets offs;
+  int64_t w_total;  // B*N*L
+  bool edge;        // true: the launch contains tiles that are not full (EDGE = true kernels)
+  hipStream_t stream;
+};
+
+// Launch the instance (L, TGS, R = rows). Returns hipErrorInvalidValue when that instance is not compiled.
+template <int TGS>
+hipError_t launch_fwd_win_tgs(int rows, int L, const FwdWinArgs& a);
+
+// window geometry for a (TGS, rows) pair — mirrors FwdWinCfg
+inline int win_tile_rows(int tgs, int rows) { return (kWinThreads >> tgs) * rows; }
+
+}  // namespace psf

@@ -26,7 +26,8 @@ struct Geom {
   int32_t CG;        // channel groups per row = ceil(C / VEC)
   int32_t tg_shift;  // TG = 1 << tg_shift threads share a row (TG <= 64 so a row never straddles a wave)
   int32_t TR;        // rows per tile
-  int32_t tiles_n;   // ceil(N / TR)
+  int32_t tiles_n;   // row tiles per batch element covered by THIS launch
+  int32_t tile0;     // index of the first of them (a launch may cover only the full or only the ragged tiles)
   int32_t chunks_c;  // ceil(CG / TG)
   int32_t per_b;     // tiles_n * chunks_c : workgroups per batch element
   uint32_t nblocks;  // B * per_b
@@ -51,8 +52,9 @@ __device__ __forceinline__ void decode_block(const Geom& gm, int& b, int& tile, 
   const uint32_t lb = logical_block(gm);
   b = (int)(lb / (uint32_t)gm.per_b);
   const uint32_t rem = lb - (uint32_t)b * (uint32_t)gm.per_b;
-  tile = (int)(rem / (uint32_t)gm.chunks_c);
-  chunk = (int)(rem - (uint32_t)tile * (uint32_t)gm.chunks_c);
+  const uint32_t t = rem / (uint32_t)gm.chunks_c;
+  chunk = (int)(rem - t * (uint32_t)gm.chunks_c);
+  tile = (int)t + gm.tile0;
 }
 
 // ---- exact (uncontracted) arithmetic: a rounded product followed by a rounded sum, like the CPU path ----

@@ -68,10 +68,10 @@ def test_forward_window_rows_variants(gpu, B, N, L, C, rows):
     assert np.array_equal(got, _oracle_fwd(W, V, R))
 
 
-@pytest.mark.parametrize("dma", [0, 1])
+@pytest.mark.parametrize("split", [0, 1])
 @pytest.mark.parametrize("B,N,L,C,shift", [(3, 1101, 11, 8, 0), (3, 1101, 11, 8, 1), (2, 2000, 12, 16, 3),
                                            (1, 515, 9, 32, 2), (5, 777, 13, 8, 1)])
-def test_forward_window_w_alignment_edges(gpu, B, N, L, C, shift, dma):
+def test_forward_window_w_alignment_edges(gpu, B, N, L, C, shift, split):
     """W tiles are staged in 16-byte chunks: cover a W buffer whose start is not 16-byte aligned (a view
     `shift` elements into an allocation), whose size is not a multiple of 16 bytes, and both staging paths."""
     import sparsefactorization_amd as sfa
@@ -80,26 +80,26 @@ def test_forward_window_w_alignment_edges(gpu, B, N, L, C, shift, dma):
     Wt = backing[shift:shift + B * N * L].view(B, N, L)
     Wt.copy_(_t(W, gpu))
     assert Wt.data_ptr() % 16 == (4 * shift) % 16
-    sfa.set_tuning("fwd_dma", dma)
+    sfa.set_tuning("fwd_split", split)
     try:
         assert "win" in sfa.describe_fwd(B, N, L, C)
         got = sfa.chord_spmm(Wt, _t(V, gpu), _t(R, gpu)).cpu().numpy()
     finally:
-        sfa.set_tuning("fwd_dma", 1)
+        sfa.set_tuning("fwd_split", 1)
     assert np.array_equal(got, _oracle_fwd(W, V, R))
 
 
-@pytest.mark.parametrize("dma", [0, 1])
-def test_forward_staging_paths_agree_on_all_shapes(gpu, dma):
+@pytest.mark.parametrize("split", [0, 1])
+def test_forward_split_and_edge_kernels_agree_on_all_shapes(gpu, split):
     import sparsefactorization_amd as sfa
-    sfa.set_tuning("fwd_dma", dma)
+    sfa.set_tuning("fwd_split", split)
     try:
         for (B, N, L, C) in [(40, 128, 8, 8), (2, 1024, 12, 32), (2, 513, 10, 128), (1, 16384, 15, 8), (2, 2048, 12, 64)]:
             W, V = _mk((B, N, L), 34), _mk((B, N, C), 35)
             got = sfa.chord_spmm(_t(W, gpu), _t(V, gpu)).cpu().numpy()
             assert np.array_equal(got, _oracle_fwd(W, V)), (B, N, L, C)
     finally:
-        sfa.set_tuning("fwd_dma", 1)
+        sfa.set_tuning("fwd_split", 1)
 
 
 def test_forward_xcd_remap_off(gpu):
