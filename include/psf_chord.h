@@ -138,8 +138,9 @@ int psf_chord_chain_fwd_f64(const double* const* W_steps, const double* V0, doub
 /*
  * Process-wide tuning knobs (benchmark / test use; defaults are the shipped configuration).
  *   key "fwd_variant": 0 = auto, 1 = generic direct-gather kernel, 2 = LDS-window kernel
- *   key "bwd_variant": 0 = auto, 1 = generic kernels
+ *   key "bwd_variant": 0 = auto (LDS-window dV / dW kernels where they apply), 1 = generic kernels
  *   key "fwd_rows"   : 0 = per-shape default, else rows per thread of the LDS-window kernel (1, 2)
+ *   key "bwd_rows"   : 0 = defaults (dV 2, dW 1), else rows per thread of both backward window kernels
  *   key "fwd_split"  : 1 = full tiles on the predicate-free kernel, ragged tiles in a second launch (default);
  *                      0 = every tile on the general (edge) kernel
  *   key "xcd_remap"  : 1 = keep a batch element's tiles on one XCD group (default), 0 = linear

@@ -129,13 +129,25 @@ def main():
         dZ = torch.randn_like(out)
         from sparsefactorization_amd.chord import _launch_bwd
         dW, dV = torch.empty_like(W), torch.empty_like(V)
-        fn = lambda: _launch_bwd(dZ, W.detach(), V.detach(), dW, dV, B, N, L, C, N * C, None)  # noqa: E731
-        fn()
-        bw = [time_ms(fn, args.iters) * 1e3 for _ in range(args.rounds)]
-        bytes_bwd = 4 * B * N * (2 * L + 3 * C)
-        entry["bwd"] = {"us_median": statistics.median(bw), "bytes": bytes_bwd,
-                        "GBs_median": bytes_bwd / statistics.median(bw) / 1e3}
-        print(f"{name:11s} bwd(dW+dV)    {statistics.median(bw):8.2f} us        {entry['bwd']['GBs_median']:7.0f} GB/s", flush=True)
+        Wd, Vd = W.detach(), V.detach()
+        bytes_dv = 4 * B * N * (L + 2 * C)   # read W, dZ; write dV
+        bytes_dw = 4 * B * N * (L + 2 * C)   # read dZ, V; write dW
+        entry["bwd"] = {}
+        for label, kn in (("win", {"bwd_variant": 0}), ("win_r1", {"bwd_variant": 0, "bwd_rows": 1}),
+                          ("generic", {"bwd_variant": 1})):
+            for k, v in {"bwd_variant": 0, "bwd_rows": 0, **kn}.items():
+                sfa.set_tuning(k, v)
+            f_dv = lambda: _launch_bwd(dZ, Wd, Vd, None, dV, B, N, L, C, N * C, None)  # noqa: E731
+            f_dw = lambda: _launch_bwd(dZ, Wd, Vd, dW, None, B, N, L, C, N * C, None)  # noqa: E731
+            f_dv(), f_dw()
+            t_dv = statistics.median([time_ms(f_dv, args.iters) * 1e3 for _ in range(args.rounds)])
+            t_dw = statistics.median([time_ms(f_dw, args.iters) * 1e3 for _ in range(args.rounds)])
+            entry["bwd"][label] = {"dV_us": t_dv, "dW_us": t_dw, "dV_GBs": bytes_dv / t_dv / 1e3,
+                                   "dW_GBs": bytes_dw / t_dw / 1e3}
+            print(f"{name:11s} bwd {label:8s} dV {t_dv:8.2f} us {bytes_dv / t_dv / 1e3:6.0f} GB/s   "
+                  f"dW {t_dw:8.2f} us {bytes_dw / t_dw / 1e3:6.0f} GB/s", flush=True)
+        sfa.set_tuning("bwd_variant", 0)
+        sfa.set_tuning("bwd_rows", 0)
         results["shapes"][name] = entry
         del Ws, V0
 

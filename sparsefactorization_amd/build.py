@@ -25,8 +25,8 @@ ARCH = "gfx950"
 WIN_TGS = list(range(7))
 
 HEADERS = ["psf_common.h", "fwd_kernels.h", "fwd_window.h", "fwd_window_launch.h", "bwd_kernels.h",
-           os.path.join("..", "..", "include", "psf_chord.h")]
-SOURCES = ["psf_chord.hip", "fwd_window_inst.hip"]
+           "bwd_window.h", "bwd_window_launch.h", os.path.join("..", "..", "include", "psf_chord.h")]
+SOURCES = ["psf_chord.hip", "fwd_window_inst.hip", "bwd_window_inst.hip"]
 
 # -ffp-contract=off: products and sums stay separate roundings (bitwise parity with the CPU oracle).
 HIPCC_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
@@ -45,6 +45,8 @@ def _units():
     units = [(os.path.join(OBJ_DIR, "psf_chord.o"), os.path.join(CSRC, "psf_chord.hip"), [])]
     for t in WIN_TGS:
         units.append((os.path.join(OBJ_DIR, f"fwd_window_tgs{t}.o"), os.path.join(CSRC, "fwd_window_inst.hip"),
+                      [f"-DPSF_TGS={t}"]))
+        units.append((os.path.join(OBJ_DIR, f"bwd_window_tgs{t}.o"), os.path.join(CSRC, "bwd_window_inst.hip"),
                       [f"-DPSF_TGS={t}"]))
     return units
 

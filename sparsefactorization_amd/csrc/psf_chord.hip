@@ -10,6 +10,7 @@
 #include <cstring>
 
 #include "bwd_kernels.h"
+#include "bwd_window_launch.h"
 #include "fwd_kernels.h"
 #include "fwd_window_launch.h"
 
@@ -40,6 +41,7 @@ std::atomic<int> g_bwd_variant{0};  // 0 auto, 1 generic
 std::atomic<int> g_xcd_remap{1};
 std::atomic<int> g_fwd_rows{0};     // 0 = default, else rows per thread (R) of the window kernel
 std::atomic<int> g_fwd_split{1};    // 1 = full tiles on the predicate-free kernel + ragged tiles separately
+std::atomic<int> g_bwd_rows{0};     // 0 = default, else rows per thread (R) of the backward window kernels
 
 struct Knob {
   const char* key;
@@ -48,7 +50,7 @@ struct Knob {
 };
 Knob g_knobs[] = {
     {"fwd_variant", &g_fwd_variant, 0, 2}, {"bwd_variant", &g_bwd_variant, 0, 1}, {"xcd_remap", &g_xcd_remap, 0, 1},
-    {"fwd_rows", &g_fwd_rows, 0, 8},       {"fwd_split", &g_fwd_split, 0, 1},
+    {"fwd_rows", &g_fwd_rows, 0, 8},       {"fwd_split", &g_fwd_split, 0, 1},     {"bwd_rows", &g_bwd_rows, 0, 8},
 };
 
 int ceil_log2(int64_t x) {
@@ -149,13 +151,40 @@ hipError_t launch_win(int tgs, int rows, int L, const FwdWinArgs& a) {
   }
 }
 
-// Decide whether the window kernel applies (f32, vectorisable, chord-like near links); fills pick on success.
+hipError_t launch_dw_win(int tgs, int rows, int L, const BwdWinArgs& a) {
+  switch (tgs) {
+    case 0: return launch_dw_win_tgs<0>(rows, L, a);
+    case 1: return launch_dw_win_tgs<1>(rows, L, a);
+    case 2: return launch_dw_win_tgs<2>(rows, L, a);
+    case 3: return launch_dw_win_tgs<3>(rows, L, a);
+    case 4: return launch_dw_win_tgs<4>(rows, L, a);
+    case 5: return launch_dw_win_tgs<5>(rows, L, a);
+    case 6: return launch_dw_win_tgs<6>(rows, L, a);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_dv_win(int tgs, int rows, int L, const BwdWinArgs& a) {
+  switch (tgs) {
+    case 0: return launch_dv_win_tgs<0>(rows, L, a);
+    case 1: return launch_dv_win_tgs<1>(rows, L, a);
+    case 2: return launch_dv_win_tgs<2>(rows, L, a);
+    case 3: return launch_dv_win_tgs<3>(rows, L, a);
+    case 4: return launch_dv_win_tgs<4>(rows, L, a);
+    case 5: return launch_dv_win_tgs<5>(rows, L, a);
+    case 6: return launch_dv_win_tgs<6>(rows, L, a);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// Decide whether a window kernel applies (f32, vectorisable, chord-like near links); fills pick on success.
+// `W` is the flat [B,N,L] array the kernel copies in 16-byte chunks (W itself, or dW for the dW kernel).
 bool pick_window(const void* W, int64_t B, int64_t N, int32_t L, int64_t C, const Offsets& offs, bool vec_ok,
-                 WinPick* pick) {
+                 WinPick* pick, int rows_pref = -1) {
   if (!vec_ok || L < kWinLmin || L > kWinLmax) return false;
   const int64_t CG = C / 4;
   const int tgs = ceil_log2(CG) > kWinTgsMax ? kWinTgsMax : ceil_log2(CG);
-  int rows = g_fwd_rows.load();
+  int rows = rows_pref >= 0 ? rows_pref : g_fwd_rows.load();
   if (rows == 0 || !win_rows_compiled(rows)) rows = win_default_rows(tgs);
   const int TR = win_tile_rows(tgs, rows);
   if (N < 2 * (int64_t)TR) return false;  // the window may wrap at most once
@@ -178,6 +207,35 @@ bool pick_window(const void* W, int64_t B, int64_t N, int32_t L, int64_t C, cons
 // ------------------------------------------------------------------------------------------------------
 // typed entry points
 // ------------------------------------------------------------------------------------------------------
+// Issue the one to two launches of a window kernel: full tiles on the predicate-free instance, the ragged last
+// tile of every sequence (if any) on the EDGE instance; everything on the EDGE instance when `all_edge`.
+// `launch` reads *gm and *edge, which are filled in before each call.
+template <typename F>
+int window_launches(const WinPick& pk, bool all_edge, int64_t B, int64_t N, int32_t L, int64_t C,
+                    int64_t v_bstride, bool split_channels, Geom* gm, bool* edge, F launch, const char* what) {
+  const int tiles_all = pk.tiles_full + (pk.ragged ? 1 : 0);
+  struct Part {
+    int tile0, tiles;
+    bool edge;
+  };
+  Part parts[2];
+  int np = 0;
+  if (all_edge) {
+    parts[np++] = {0, tiles_all, true};
+  } else {
+    if (pk.tiles_full > 0) parts[np++] = {0, pk.tiles_full, false};
+    if (pk.ragged) parts[np++] = {pk.tiles_full, 1, true};
+  }
+  for (int i = 0; i < np; ++i) {
+    if (int rc = make_geom(B, N, L, C, 4, pk.tgs, pk.TR, split_channels, v_bstride, parts[i].tile0, parts[i].tiles, gm))
+      return rc;
+    *edge = parts[i].edge;
+    hipError_t e = launch();
+    if (e != hipSuccess) return fail_hip(e, what);
+  }
+  return PSF_OK;
+}
+
 int fwd_window_f32(const WinPick& pk, const float* W, const float* V, const float* res, float* out, int64_t B,
                    int64_t N, int32_t L, int64_t C, int64_t v_batch_stride, const Offsets& offs, hipStream_t s) {
   FwdWinArgs a;
@@ -188,26 +246,8 @@ int fwd_window_f32(const WinPick& pk, const float* W, const float* V, const floa
   a.offs = offs;
   a.w_total = B * N * (int64_t)L;
   a.stream = s;
-  const int tiles_all = pk.tiles_full + (pk.ragged ? 1 : 0);
-  if (pk.all_edge) {
-    if (int rc = make_geom(B, N, L, C, 4, pk.tgs, pk.TR, true, v_batch_stride, 0, tiles_all, &a.gm)) return rc;
-    a.edge = true;
-    hipError_t e = launch_win(pk.tgs, pk.rows, L, a);
-    return e == hipSuccess ? PSF_OK : fail_hip(e, "chord_fwd_win (edge) launch");
-  }
-  if (pk.tiles_full > 0) {
-    if (int rc = make_geom(B, N, L, C, 4, pk.tgs, pk.TR, true, v_batch_stride, 0, pk.tiles_full, &a.gm)) return rc;
-    a.edge = false;
-    hipError_t e = launch_win(pk.tgs, pk.rows, L, a);
-    if (e != hipSuccess) return fail_hip(e, "chord_fwd_win launch");
-  }
-  if (pk.ragged) {
-    if (int rc = make_geom(B, N, L, C, 4, pk.tgs, pk.TR, true, v_batch_stride, pk.tiles_full, 1, &a.gm)) return rc;
-    a.edge = true;
-    hipError_t e = launch_win(pk.tgs, pk.rows, L, a);
-    if (e != hipSuccess) return fail_hip(e, "chord_fwd_win (ragged tiles) launch");
-  }
-  return PSF_OK;
+  return window_launches(pk, pk.all_edge, B, N, L, C, v_batch_stride, true, &a.gm, &a.edge,
+                         [&] { return launch_win(pk.tgs, pk.rows, L, a); }, "chord_fwd_win launch");
 }
 
 template <typename T>
@@ -265,6 +305,36 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
   make_offsets(N, L, offsets, &offs);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   constexpr int VECW = 16 / (int)sizeof(T);
+
+  if constexpr (sizeof(T) == 4) {  // LDS-window kernels (f32). Whatever they handle is cleared below.
+    if (g_bwd_variant.load() != 1) {
+      const int64_t w_total = B * N * (int64_t)L;
+      const int TGmax = 1 << kWinTgsMax;
+      WinPick pk;
+      // default rows per thread (r01 sweep, us at cfg2): dV R=2 31.3 vs R=1 32.7; dW R=1 22.9 vs R=2 28.7
+      const int knob = g_bwd_rows.load();
+      const int rows_dv = knob ? knob : 2, rows_dw = knob ? knob : 1;
+      if (dV && pick_window(W, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(dV, 16), &pk,
+                            rows_dv)) {
+        BwdWinArgs a{dZ, W, dV, Geom{}, offs, w_total, false, s};
+        int rc = window_launches(pk, pk.all_edge, B, N, L, C, N * C, true, &a.gm, &a.edge,
+                                 [&] { return launch_dv_win(pk.tgs, pk.rows, L, a); }, "chord_dv_win");
+        if (rc) return rc;
+        dV = nullptr;
+      }
+      if (dW && C / 4 <= TGmax &&
+          pick_window(dW, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(V, 16), &pk,
+                      rows_dw)) {
+        // the dW tile store is chunk-clean only if every sequence starts on a 16-byte boundary
+        const bool all_edge = pk.all_edge || ((N * (int64_t)L) % 4) != 0;
+        BwdWinArgs a{dZ, V, dW, Geom{}, offs, w_total, false, s};
+        int rc = window_launches(pk, all_edge, B, N, L, C, v_batch_stride, false, &a.gm, &a.edge,
+                                 [&] { return launch_dw_win(pk.tgs, pk.rows, L, a); }, "chord_dw_win");
+        if (rc) return rc;
+        dW = nullptr;
+      }
+    }
+  }
 
   if (dV) {
     const bool vec_ok = (C % VECW == 0) && aligned_to(dZ, 16) && aligned_to(dV, 16);

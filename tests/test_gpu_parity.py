@@ -173,6 +173,55 @@ def test_backward_step(gpu, B, N, L, C):
     assert np.array_equal(Rt.grad.cpu().numpy(), dZ)
 
 
+BWD_WIN_SHAPES = [(3, 16384, 15, 8), (2, 2048, 12, 64), (2, 1101, 11, 8), (2, 2000, 12, 128), (1, 4097, 13, 8),
+                  (2, 1024, 12, 32), (2, 777, 9, 16), (2, 640, 10, 260), (5, 1000, 7, 4), (2, 515, 20, 24)]
+
+
+@pytest.mark.parametrize("rows", [1, 2])
+@pytest.mark.parametrize("B,N,L,C", BWD_WIN_SHAPES)
+def test_backward_window_kernels(gpu, B, N, L, C, rows):
+    """LDS-window dV / dW kernels (full, ragged and all-edge launches) vs the oracle and vs the generic kernels."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.chord import _launch_bwd
+    W, V, dZ = _mk((B, N, L), 41), _mk((B, N, C), 42), _mk((B, N, C), 43)
+    Wt, Vt, dZt = _t(W, gpu), _t(V, gpu), _t(dZ, gpu)
+    dF, dV = oc.spmul_bwd(dZ, W, V)
+    got = {}
+    for variant in (0, 1):
+        sfa.set_tuning("bwd_variant", variant)
+        sfa.set_tuning("bwd_rows", rows)
+        try:
+            gW = torch.full_like(Wt, float("nan"))
+            gV = torch.full_like(Vt, float("nan"))
+            _launch_bwd(dZt, Wt, Vt, gW, gV, B, N, L, C, N * C, None)
+            got[variant] = (gW.cpu().numpy(), gV.cpu().numpy())
+        finally:
+            sfa.set_tuning("bwd_variant", 0)
+            sfa.set_tuning("bwd_rows", 0)
+    for variant, (gW, gV) in got.items():
+        assert np.array_equal(gV, dV), f"dV variant={variant}"
+        assert rel_inf(gW, dF) <= TOL, f"dW variant={variant}"
+
+
+def test_backward_window_misaligned_buffers(gpu):
+    """W and dW as views that start 4 bytes into an allocation (all-edge launches, partial 16-byte chunks)."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.chord import _launch_bwd
+    B, N, L, C = 3, 1101, 11, 8
+    W, V, dZ = _mk((B, N, L), 44), _mk((B, N, C), 45), _mk((B, N, C), 46)
+    backing = torch.zeros(B * N * L + 8, device=gpu)
+    Wt = backing[1:1 + B * N * L].view(B, N, L)
+    Wt.copy_(_t(W, gpu))
+    gbuf = torch.full((B * N * L + 8,), float("nan"), device=gpu)
+    gW = gbuf[3:3 + B * N * L].view(B, N, L)
+    gV = torch.empty(B, N, C, device=gpu)
+    _launch_bwd(_t(dZ, gpu), Wt, _t(V, gpu), gW, gV, B, N, L, C, N * C, None)
+    dF, dV = oc.spmul_bwd(dZ, W, V)
+    assert np.array_equal(gV.cpu().numpy(), dV)
+    assert rel_inf(gW.cpu().numpy(), dF) <= TOL
+    assert torch.isnan(gbuf[:3]).all() and torch.isnan(gbuf[3 + B * N * L:]).all()  # nothing written outside
+
+
 def test_backward_broadcast_V(gpu):
     import sparsefactorization_amd as sfa
     B, N, L, C = 3, 128, 8, 16
