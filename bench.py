@@ -109,9 +109,10 @@ def main():
     torch.cuda.set_device(device)
 
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with a single rank)
         import torch.distributed as dist  # backend "nccl" is RCCL on ROCm
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import sparsefactorization_amd as sfa

@@ -1,0 +1,122 @@
+"""Adding / Temporal-Order training driver — counterpart of ``SyntheticExperiments/psf_training.py``.
+
+    python -m sparsefactorization_amd.psf_training --problem order --n-vec 16384 --epochs 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+           -m sparsefactorization_amd.psf_training --problem order --n-vec 16384
+
+Same model construction as the reference driver (psf_training.py:29-45: ``n_W = int(log2(n_vec))``, config keys
+of synthetic_training_config.py), same optimiser / loss choice (50-58), ``seed_everything(42)`` (16),
+``drop_last=True`` loaders (80-114). What changes: data come from the on-device generators
+(``synth_data``: there are no ``.pt`` files here), the loaders are ``torch.utils.data.DataLoader`` (the
+reference's ``torch_geometric.data.DataLoader`` is a subclass that adds nothing for tensor pairs), and under
+``torch.distributed.run`` every rank trains on its shard of each global batch with ONE flat gradient
+all-reduce per step (``dp.FlatGradAllReduce``, RCCL over xGMI).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import time
+
+import numpy as np
+import torch
+from torch import nn, optim
+from torch.utils.data import DataLoader
+
+from . import dp, synth_data
+from .synthetic_psf import PSFNet
+from .train import DatasetCreator, TrainModel, count_params, seed_everything, train_epoch
+
+# PSF entries of SyntheticExperiments/synthetic_training_config.py (same keys and values)
+config = {
+    "adding": {
+        "model": {"add_init_linear_layer": True, "vocab_size": 1, "dim": 32, "Ws": [32, 'GELU'], "V": [32, 'GELU'],
+                  "pooling_type": "FLATTEN", "head": ['linear'], "n_class": 1, "n_channels_V": 8, "use_cuda": True,
+                  "use_residuals": True, "use_pos_embedding": False, "problem": "adding"},
+        "training": {"device_id": 0, "batch_size": 40, "learning_rate": 0.001, "eval_frequency": 1,
+                     "num_train_steps": 20},
+    },
+    "order": {
+        "model": {"add_init_linear_layer": False, "vocab_size": 6, "dim": 32, "Ws": [32, 'GELU'], "V": [32, 'GELU'],
+                  "pooling_type": "FLATTEN", "head": ['linear'], "n_class": 4, "n_channels_V": 8, "use_cuda": True,
+                  "use_residuals": True, "use_pos_embedding": True, "problem": "order"},
+        "training": {"device_id": 0, "batch_size": 40, "learning_rate": 0.001, "eval_frequency": 1,
+                     "num_train_steps": 20},
+    },
+}
+
+
+def build_model(problem: str, n_vec: int, use_cuda: bool = True) -> PSFNet:
+    cfg = config[problem]["model"]
+    return PSFNet(vocab_size=cfg["vocab_size"], add_init_linear_layer=cfg["add_init_linear_layer"],
+                  embedding_size=cfg["dim"], n_vec=n_vec, n_W=int(np.log2(n_vec)), Ws=cfg["Ws"], V=cfg["V"],
+                  n_channels_V=cfg["n_channels_V"], n_class=cfg["n_class"], pooling_type=cfg["pooling_type"],
+                  head=cfg["head"], use_cuda=use_cuda, use_residuals=cfg["use_residuals"],
+                  use_pos_embedding=cfg["use_pos_embedding"], problem=problem)
+
+
+def make_split(problem: str, n_seq: int, n_vec: int, device, seed: int):
+    g = torch.Generator(device=device).manual_seed(seed)
+    fn = synth_data.adding if problem == "adding" else synth_data.temporal_order
+    return fn(n_seq, n_vec, device=device, generator=g)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--problem", choices=["adding", "order"], default="adding")
+    ap.add_argument("--n-vec", type=int, default=128)
+    ap.add_argument("--epochs", type=int, default=None)
+    ap.add_argument("--train-seqs", type=int, default=4000)
+    ap.add_argument("--eval-seqs", type=int, default=400)
+    ap.add_argument("--batch-size", type=int, default=None, help="per-rank batch (reference: 40)")
+    ap.add_argument("--max-steps", type=int, default=None, help="stop an epoch early (benchmarking)")
+    ap.add_argument("--json", action="store_true", help="print one JSON line with training throughput")
+    args = ap.parse_args(argv)
+
+    rank, world, device = dp.init_from_env()
+    if device.type != "cuda":
+        raise SystemExit("training needs an MI355X: the chord-spmm path has no CPU implementation")
+    cfg_training = config[args.problem]["training"]
+    batch = args.batch_size or cfg_training["batch_size"]
+    epochs = args.epochs if args.epochs is not None else cfg_training["num_train_steps"]
+
+    seed_everything(42)
+    net = build_model(args.problem, args.n_vec).to(device)
+    dp.broadcast_parameters(net)
+    if rank == 0:
+        print('Number of trainable parameters', count_params(net))
+    optimizer = optim.Adam(net.parameters(), lr=cfg_training["learning_rate"])
+    loss = nn.MSELoss() if args.problem == "adding" else nn.CrossEntropyLoss()
+    reducer = dp.FlatGradAllReduce(net.parameters()) if world > 1 else None
+
+    # every rank draws its own shard of the global data (rank-offset seed), validation/test are replicated
+    lo, hi = dp.shard_bounds(args.train_seqs, rank, world)
+    Xtr, Ytr = make_split(args.problem, hi - lo, args.n_vec, device, 1000 + rank)
+    Xva, Yva = make_split(args.problem, args.eval_seqs, args.n_vec, device, 2000)
+    Xte, Yte = make_split(args.problem, args.eval_seqs, args.n_vec, device, 3000)
+    mk = lambda X, Y, shuffle: DataLoader(DatasetCreator(X, Y), batch_size=batch, shuffle=shuffle,  # noqa: E731
+                                          drop_last=True, num_workers=0)
+    trainloader, valloader, testloader = mk(Xtr, Ytr, True), mk(Xva, Yva, False), mk(Xte, Yte, False)
+
+    if args.json:
+        train_epoch(net, trainloader, optimizer, loss, reducer, max_steps=3)  # warm-up
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        stats = train_epoch(net, trainloader, optimizer, loss, reducer, max_steps=args.max_steps)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            print(json.dumps({"metric": "PSF train tokens/sec", "problem": args.problem, "n_vec": args.n_vec,
+                              "n_gpus": world, "batch_per_gpu": batch, "steps": stats["steps"],
+                              "ms_per_step": dt * 1e3 / max(stats["steps"], 1),
+                              "value": world * batch * args.n_vec * stats["steps"] / dt, "unit": "tokens/s",
+                              "loss": stats["loss"]}))
+        return
+
+    TrainModel(net=net, trainloader=trainloader, valloader=valloader, testloader=testloader, n_epochs=epochs,
+               test_freq=cfg_training["eval_frequency"], optimizer=optimizer, loss=loss, problem=args.problem,
+               saving_criteria=99.5, reducer=reducer, is_main=rank == 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+"""Train / eval harness around PSFNet — the caller of the hot path.
+
+Mirrors ``SyntheticExperiments/psf_utils.py`` (``seed_everything`` 10-20, ``DatasetCreator`` 23-43,
+``count_params`` 44-46, ``TrainModel`` 48-137) and ``LRA/psf_utils.py`` (``TrainPSF`` 48-128: the same loop,
+always arg-max accuracy): Adam steps on ``loss(net(X).squeeze(), Y)``, evaluation every ``test_freq`` epochs
+over validation and test loaders, the Adding tolerance ``|pred - Y| < 0.04``, a state_dict checkpoint named
+``{problem}_epoch{e}_acc{a}.pt`` whenever test accuracy beats ``saving_criteria``.
+
+Differences, all on purpose: no ``.cuda()`` hard-wiring (tensors go to the model's device, so the loop runs
+unchanged on one process per GPU); an optional gradient reducer (``dp.FlatGradAllReduce``) is called between
+``backward()`` and ``step()`` for batch-sharded data parallelism; metrics are accumulated on the device and
+read back once per epoch instead of one ``.item()`` sync per batch (psf_utils.py:73).
+"""
+from __future__ import annotations
+
+import os
+import random
+import time
+from typing import Callable, Dict, Iterable, Optional
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+
+def seed_everything(seed: int = 1234) -> None:
+    """Seed python, numpy and torch (CPU + GPU) — psf_utils.py:10-20."""
+    random.seed(seed)
+    os.environ['PYTHONHASHSEED'] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+class DatasetCreator(Dataset):
+    """(sample, target) pairs from two indexable tensors — psf_utils.py:23-43."""
+
+    def __init__(self, data, labels):
+        self.data = data
+        self.labels = labels
+
+    def __getitem__(self, index):
+        return self.data[index], self.labels[index]
+
+    def __len__(self):
+        return len(self.labels)
+
+
+def count_params(net: torch.nn.Module) -> int:
+    return sum(p.numel() for p in net.parameters() if p.requires_grad)
+
+
+def _device_of(net: torch.nn.Module) -> torch.device:
+    return next(net.parameters()).device
+
+
+def _count_correct(pred: torch.Tensor, Y: torch.Tensor, problem: str) -> torch.Tensor:
+    if problem == 'adding':
+        return (torch.abs(pred.squeeze() - Y) < 0.04).sum()  # psf_utils.py:103
+    return pred.max(1)[1].eq(Y).sum()                         # psf_utils.py:105-106
+
+
+@torch.no_grad()
+def evaluate(net, loader: Iterable, loss, problem: str) -> Dict[str, float]:
+    """Mean loss and accuracy (%) over a loader, as the validation / test loops of TrainModel (92-121)."""
+    dev = _device_of(net)
+    was_training = net.training
+    net.eval()
+    total = 0
+    loss_sum = torch.zeros((), device=dev)
+    correct = torch.zeros((), device=dev)
+    batches = 0
+    for X, Y in loader:
+        X, Y = X.to(dev, non_blocking=True), Y.to(dev, non_blocking=True)
+        pred = net(X)
+        loss_sum += loss(pred.squeeze(), Y)
+        correct += _count_correct(pred, Y, problem)
+        total += Y.size(0)
+        batches += 1
+    net.train(was_training)
+    return {"loss": float(loss_sum) / max(batches, 1), "accuracy": 100.0 * float(correct) / max(total, 1)}
+
+
+def train_epoch(net, loader: Iterable, optimizer, loss, reducer: Optional[Callable[[], None]] = None,
+                max_steps: Optional[int] = None) -> Dict[str, float]:
+    """One pass of the training loop (psf_utils.py:60-74). Returns mean loss, steps and seconds."""
+    dev = _device_of(net)
+    running = torch.zeros((), device=dev)
+    steps = 0
+    t0 = time.perf_counter()
+    for X, Y in loader:
+        X, Y = X.to(dev, non_blocking=True), Y.to(dev, non_blocking=True)
+        optimizer.zero_grad(set_to_none=True)
+        pred = net(X)
+        output = loss(pred.squeeze(), Y)
+        output.backward()
+        if reducer is not None:
+            reducer()
+        optimizer.step()
+        running += output.detach()
+        steps += 1
+        if max_steps is not None and steps >= max_steps:
+            break
+    mean = float(running) / max(steps, 1)  # the only host sync of the epoch
+    return {"loss": mean, "steps": steps, "seconds": time.perf_counter() - t0}
+
+
+def TrainModel(net, trainloader, valloader, testloader, n_epochs, test_freq, optimizer, loss, problem,
+               saving_criteria, reducer: Optional[Callable[[], None]] = None, save_dir: str = ".",
+               log: Callable[[str], None] = print, is_main: bool = True):
+    """Same arguments and behaviour as ``TrainModel`` (SyntheticExperiments/psf_utils.py:48-137); for LRA use
+    ``problem`` = the task name (arg-max accuracy, as ``TrainPSF``). Returns the per-epoch history."""
+    history = []
+    for epoch in range(n_epochs):
+        stats = train_epoch(net, trainloader, optimizer, loss, reducer)
+        if is_main:
+            log("Epoch {} - Training loss:  {} — Time:  {}sec".format(epoch, stats["loss"], stats["seconds"]))
+        record = {"epoch": epoch, "train": stats}
+        if epoch % test_freq == 0:
+            val = evaluate(net, valloader, loss, problem)
+            test = evaluate(net, testloader, loss, problem)
+            record.update(val=val, test=test)
+            if is_main:
+                log("Val  loss: {}".format(val["loss"]))
+                log("Test loss: {}".format(test["loss"]))
+                log("Val  accuracy: {}".format(val["accuracy"]))
+                log("Test accuracy: {}".format(test["accuracy"]))
+                log('_' * 40)
+                if test["accuracy"] > saving_criteria:
+                    path = os.path.join(save_dir, '{}_epoch{}_acc{}.pt'.format(problem, epoch, test["accuracy"]))
+                    torch.save(net.state_dict(), path)
+                    record["checkpoint"] = path
+        history.append(record)
+    return history
+
+
+TrainPSF = TrainModel  # LRA/psf_utils.py:48 name

@@ -1,0 +1,109 @@
+"""Host logic of the callers of the hot path: synthetic data generators and the
+train / eval harness. CPU for the logic, one GPU test that trains the real model for a few steps.
+"""
+import os
+
+import pytest
+import torch
+from torch.utils.data import DataLoader
+
+from sparsefactorization_amd import synth_data
+from sparsefactorization_amd.train import DatasetCreator, TrainModel, count_params, evaluate, seed_everything
+
+
+def test_adding_distribution():
+    """synth_data_generation.py:8-28: x in (-1,1), exactly two distinct markers, label 0.5 + (x1+x2)/4."""
+    g = torch.Generator().manual_seed(0)
+    data, labels = synth_data.adding(5000, 64, generator=g)
+    assert data.shape == (5000, 64, 2) and data.dtype == torch.float32 and labels.shape == (5000,)
+    x, y = data[..., 0], data[..., 1]
+    assert float(x.min()) >= -1 and float(x.max()) <= 1 and abs(float(x.mean())) < 0.01
+    assert torch.all((y == 0) | (y == 1)) and torch.all(y.sum(1) == 2)
+    assert torch.allclose(labels, 0.5 + (x * y).sum(1) / 4, atol=1e-6)
+    # marker positions are uniform over unordered pairs: first marker index mean = (N-2)/3 + ...
+    first = y.argmax(1).float().mean()
+    assert abs(float(first) - (64 - 2) / 3) < 1.0
+
+
+def test_temporal_order_distribution():
+    """synth_data_generation.py:30-70: tokens 0..3, two ordered special positions from {4,5}, 4 classes."""
+    g = torch.Generator().manual_seed(1)
+    data, labels = synth_data.temporal_order(4000, 32, generator=g)
+    assert data.shape == (4000, 32, 1) and data.dtype == torch.int64
+    x = data[..., 0]
+    special = x >= 4
+    assert torch.all(special.sum(1) == 2) and int(x.max()) <= 5 and int(x.min()) >= 0
+    idx = special.float().argsort(dim=1, descending=True, stable=True)[:, :2].sort(dim=1).values
+    v1, v2 = x.gather(1, idx[:, :1]).squeeze(1), x.gather(1, idx[:, 1:]).squeeze(1)
+    assert torch.equal(labels, 2 * (v1 == 5).long() + (v2 == 5).long())
+    counts = torch.bincount(labels, minlength=4).float() / 4000
+    assert torch.all((counts - 0.25).abs() < 0.04)
+    assert torch.all((torch.bincount(x[~special], minlength=4).float() / (~special).sum() - 0.25).abs() < 0.01)
+
+
+def test_generators_are_seeded():
+    a = synth_data.adding(10, 16, generator=torch.Generator().manual_seed(5))
+    b = synth_data.adding(10, 16, generator=torch.Generator().manual_seed(5))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+class _Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(8 * 2, 1)
+
+    def forward(self, x):
+        return self.lin(x.reshape(x.size(0), -1))
+
+
+def test_train_model_loop_and_checkpoint_naming(tmp_path):
+    """TrainModel semantics (psf_utils.py:48-137) on a toy regressor: loss falls, 0.04-tolerance accuracy,
+    checkpoint named {problem}_epoch{e}_acc{a}.pt once the threshold is beaten."""
+    seed_everything(3)
+    g = torch.Generator().manual_seed(3)
+    X, _ = synth_data.adding(512, 8, generator=g)
+    Y = X.reshape(512, -1) @ torch.linspace(-0.2, 0.2, 16)  # learnable target
+    mk = lambda: DataLoader(DatasetCreator(X, Y), batch_size=32, shuffle=True, drop_last=True)  # noqa: E731
+    net = _Toy()
+    assert count_params(net) == 17
+    opt = torch.optim.Adam(net.parameters(), lr=0.05)
+    logs = []
+    hist = TrainModel(net, mk(), mk(), mk(), n_epochs=8, test_freq=2, optimizer=opt, loss=torch.nn.MSELoss(),
+                      problem="adding", saving_criteria=50.0, save_dir=str(tmp_path), log=logs.append)
+    assert hist[-1]["train"]["loss"] < 0.1 * hist[0]["train"]["loss"]
+    assert [h["epoch"] for h in hist if "test" in h] == [0, 2, 4, 6]
+    saved = [f for f in os.listdir(tmp_path) if f.startswith("adding_epoch") and f.endswith(".pt")]
+    assert saved, logs
+    sd = torch.load(tmp_path / saved[0])
+    assert set(sd) == {"lin.weight", "lin.bias"}
+    ev = evaluate(net, mk(), torch.nn.MSELoss(), "adding")
+    assert ev["accuracy"] > 50.0
+
+
+def test_order_accuracy_is_argmax():
+    class Const(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, x):
+            out = torch.zeros(x.size(0), 4)
+            out[:, 2] = 1.0
+            return out + self.p
+    Y = torch.tensor([2, 2, 0, 1])
+    loader = DataLoader(DatasetCreator(torch.zeros(4, 3, 1), Y), batch_size=2)
+    ev = evaluate(Const(), loader, torch.nn.CrossEntropyLoss(), "order")
+    assert ev["accuracy"] == 50.0
+
+
+@pytest.mark.gpu
+def test_training_driver_runs_on_gpu(gpu, capsys):
+    from sparsefactorization_amd import psf_training
+    psf_training.main(["--problem", "order", "--n-vec", "512", "--train-seqs", "400", "--eval-seqs", "80",
+                       "--json", "--max-steps", "6"])
+    out = capsys.readouterr().out
+    assert '"metric": "PSF train tokens/sec"' in out
+    psf_training.main(["--problem", "adding", "--n-vec", "256", "--train-seqs", "200", "--eval-seqs", "80",
+                       "--epochs", "1"])
+    out = capsys.readouterr().out
+    assert "Training loss" in out and "Test accuracy" in out
