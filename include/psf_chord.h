@@ -136,6 +136,19 @@ int psf_chord_chain_fwd_f64(const double* const* W_steps, const double* V0, doub
                             const int64_t* offsets, void* stream);
 
 /*
+ * Producer side: weight / bias gradient of the token-wise Linear layers of MLPBlock
+ * (SyntheticExperiments/psf.py:35-60) that produce W_m = fs[m](data) and V = g(data) — a reduction over
+ * T = B*N tokens into an n x m tile, done on the f32 matrix core (exact f32) with a fixed-order reduction:
+ *     dWt[j,i] = sum_t dY[t,j] * X[t,i]     (nn.Linear.weight.grad layout, [n = out_features, m = in_features])
+ *     db[j]    = sum_t dY[t,j]              (db may be NULL)
+ *   X [T,m], dY [T,n] contiguous; 1 <= m, n <= 128. `workspace` is caller-owned device scratch of at least
+ *   psf_linear_wgrad_workspace(T, m, n) bytes (that function returns -1 for unsupported sizes).
+ */
+int64_t psf_linear_wgrad_workspace(int64_t T, int32_t m, int32_t n);
+int psf_linear_wgrad_f32(const float* X, const float* dY, int64_t T, int32_t m, int32_t n, float* dWt, float* db,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * Process-wide tuning knobs (benchmark / test use; defaults are the shipped configuration).
  *   key "fwd_variant": 0 = auto, 1 = generic direct-gather kernel, 2 = LDS-window kernel
  *   key "bwd_variant": 0 = auto (LDS-window dV / dW kernels where they apply), 1 = generic kernels

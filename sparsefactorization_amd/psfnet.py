@@ -31,6 +31,7 @@ import torch
 from torch import nn
 
 from .chord import chord_chain, chord_spmm, get_chord_indices_assym
+from .token_linear import TokenEmbedding, TokenLinear
 
 LayerSpec = Sequence[Union[str, int]]
 
@@ -39,15 +40,17 @@ def MakeMLP(cfg: LayerSpec, in_channels: int, out_channels: int) -> nn.Sequentia
     """An int in ``cfg`` is a Linear to that width, any string is a GELU; a closing Linear maps to
     ``out_channels`` (SyntheticExperiments/psf.py:35-47). ``[32, 'GELU']`` gives Linear, GELU, Linear, i.e.
     parameter indices 0 and 2."""
+    # TokenLinear is nn.Linear (same parameters / state_dict) whose weight and bias gradients over the ~1e6
+    # tokens run on the tall-skinny MFMA kernel instead of a library GEMM (token_linear.py)
     stack: List[nn.Module] = []
     width = in_channels
     for item in cfg:
         if isinstance(item, int):
-            stack.append(nn.Linear(width, item))
+            stack.append(TokenLinear(width, item))
             width = item
         else:
             stack.append(nn.GELU())
-    stack.append(nn.Linear(width, out_channels))
+    stack.append(TokenLinear(width, out_channels))
     return nn.Sequential(*stack)
 
 
@@ -129,13 +132,13 @@ class SyntheticPSFNet(_ChordMixer):
         self.problem = problem
 
         # construction order follows the reference so a given torch seed draws the same initial weights
-        self.embedding = nn.Embedding(vocab_size, embedding_size)
+        self.embedding = TokenEmbedding(vocab_size, embedding_size)
         self.pos_embedding = nn.Embedding(n_vec, embedding_size)
         self._build_mixer(n_vec, n_W, Ws, V, embedding_size, n_channels_V, use_cuda)
         if head[0] == 'linear':
             self.final = nn.Linear(n_vec * n_channels_V, n_class, bias=True)
         if add_init_linear_layer:
-            self.init_linear = nn.Linear(2, embedding_size, bias=True)
+            self.init_linear = TokenLinear(2, embedding_size, bias=True)
         self._build_indices(n_vec, self.n_links, use_cuda)
 
     def forward(self, data):
@@ -176,9 +179,9 @@ class _TokenPSFNet(_ChordMixer):
         self.use_pos_embedding = use_pos_embedding
 
         if padding_idx is None:
-            self.embedding = nn.Embedding(vocab_size, embedding_size)
+            self.embedding = TokenEmbedding(vocab_size, embedding_size)
         else:
-            self.embedding = nn.Embedding(vocab_size, embedding_size, padding_idx=padding_idx)
+            self.embedding = TokenEmbedding(vocab_size, embedding_size, padding_idx=padding_idx)
         self.pos_embedding = nn.Embedding(n_vec, embedding_size)
         if init_embedding_weights:
             self.init_embed_weights()
@@ -279,7 +282,7 @@ class AttentionBlockPSF(_ChordMixer):
         self.dropout2 = nn.Dropout(dropout2_p)
         self.dropout3 = nn.Dropout(dropout3_p)
         self._build_indices(max_seq_len, self.n_links, use_cuda)
-        self.embedding = nn.Embedding(vocab_size, embedding_size)
+        self.embedding = TokenEmbedding(vocab_size, embedding_size)
         self.apc_embedding = nn.Embedding(max_seq_len, embedding_size)
 
     def forward(self, data):

@@ -1,0 +1,107 @@
+"""``TokenLinear`` — ``nn.Linear`` for the token-wise MLPs that produce the chain's operands
+(``MLPBlock``, SyntheticExperiments/psf.py:35-60: ``W_m = fs[m](data)``, ``V = g(data)``).
+
+Same parameters, same state_dict keys, same forward (``addmm`` on rocBLAS/hipBLASLt). Only the weight and bias
+gradients differ: for T = B*N tokens and layer widths of 2..128 they are a reduction over ~10^6 rows into a tile
+of a few hundred numbers, for which library GEMMs take ~1 ms per layer (84 % of a training step at
+Order/Adding N = 16384 — profiles/r01_train_step_profile.log). ``psf_linear_wgrad_f32`` (csrc/linear_wgrad.hip)
+streams X and dY once through the f32 matrix core instead. Layers outside its range (wide ListOps layers,
+fp64, CPU tensors) use the stock autograd formulas.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import _lib
+
+MAX_WIDTH = 128   # kernel limit on in_features / out_features
+MIN_TOKENS = 4096  # below this the stock path is fine
+
+
+def wgrad_supported(x2d: torch.Tensor, out_features: int) -> bool:
+    return (x2d.is_cuda and x2d.dtype == torch.float32 and x2d.shape[0] >= MIN_TOKENS
+            and x2d.shape[1] <= MAX_WIDTH and out_features <= MAX_WIDTH)
+
+
+def linear_wgrad(x2d: torch.Tensor, dy2d: torch.Tensor, need_bias: bool = True):
+    """(dWeight [n, m], dBias [n] or None) for X [T, m], dY [T, n] on the HIP kernel."""
+    T, m = x2d.shape
+    n = dy2d.shape[1]
+    lib = _lib.load()
+    ws_bytes = lib.psf_linear_wgrad_workspace(T, m, n)
+    if ws_bytes < 0:
+        raise ValueError(f"psf_linear_wgrad does not support T={T}, m={m}, n={n}")
+    x2d, dy2d = x2d.contiguous(), dy2d.contiguous()
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x2d.device)
+    dW = torch.empty((n, m), dtype=torch.float32, device=x2d.device)
+    db = torch.empty(n, dtype=torch.float32, device=x2d.device) if need_bias else None
+    with torch.cuda.device(x2d.device):
+        rc = lib.psf_linear_wgrad_f32(x2d.data_ptr(), dy2d.data_ptr(), T, m, n, dW.data_ptr(),
+                                      db.data_ptr() if db is not None else None, ws.data_ptr(), ws_bytes,
+                                      torch.cuda.current_stream(x2d.device).cuda_stream)
+    _lib.check(rc, "psf_linear_wgrad_f32")
+    return dW, db
+
+
+class _TokenLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = dy.matmul(weight) if need_x else None
+        dW = db = None
+        if need_w or need_b:
+            dW, db = linear_wgrad(x.reshape(-1, x.shape[-1]), dy.reshape(-1, dy.shape[-1]), need_b)
+            if not need_w:
+                dW = None
+        return dx, dW, db
+
+
+class _TokenEmbeddingFn(torch.autograd.Function):
+    """weight[idx] whose weight gradient is one_hot(idx)^T @ dOut on the tall-skinny kernel instead of PyTorch's
+    sort-and-scatter (4.5 ms per step for the 6-token vocabulary of Temporal Order at T = 655 360)."""
+
+    @staticmethod
+    def forward(ctx, idx, weight, padding_idx):
+        ctx.save_for_backward(idx)
+        ctx.vocab, ctx.padding_idx = weight.shape[0], padding_idx
+        return torch.nn.functional.embedding(idx, weight, padding_idx)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        onehot = torch.nn.functional.one_hot(idx.reshape(-1), ctx.vocab).to(torch.float32)
+        dWt, _ = linear_wgrad(onehot, dout.reshape(-1, dout.shape[-1]), need_bias=False)  # [E, vocab]
+        dW = dWt.t().contiguous()
+        if ctx.padding_idx is not None and ctx.padding_idx >= 0:
+            dW[ctx.padding_idx].zero_()
+        return None, dW, None
+
+
+class TokenEmbedding(nn.Embedding):
+    """Drop-in ``nn.Embedding`` (same parameters / state_dict / forward values) for small vocabularies looked up
+    at ~1e6 positions; larger vocabularies, CPU tensors and exotic options use the stock path."""
+
+    def forward(self, idx: torch.Tensor) -> torch.Tensor:
+        if (torch.is_grad_enabled() and self.weight.requires_grad and idx.is_cuda and self.weight.dtype == torch.float32
+                and self.num_embeddings <= MAX_WIDTH and self.embedding_dim <= MAX_WIDTH and idx.numel() >= MIN_TOKENS
+                and self.max_norm is None and not self.scale_grad_by_freq and not self.sparse):
+            return _TokenEmbeddingFn.apply(idx, self.weight, self.padding_idx)
+        return super().forward(idx)
+
+
+class TokenLinear(nn.Linear):
+    """Drop-in ``nn.Linear`` (``isinstance(layer, nn.Linear)`` holds; identical parameters and state_dict)."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and (self.weight.requires_grad or (self.bias is not None and self.bias.requires_grad)) \
+                and x.dim() >= 2 and wgrad_supported(x.reshape(-1, x.shape[-1]), self.out_features):
+            return _TokenLinearFn.apply(x, self.weight, self.bias)
+        return super().forward(x)
