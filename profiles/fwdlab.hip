@@ -121,7 +121,7 @@ void launch_lab(const float* W, const float* V, const float* res, float* out, co
 template <int R, int NT, bool DMA>
 void launch_prod(const float* W, const float* V, const float* res, float* out, const Geom& gm, const Offsets& offs, int64_t wt) {
   using Cfg = FwdWinCfg<float, 15, 1, R, NT>;
-  auto k = chord_fwd_win_k<float, 15, 1, R, NT, DMA, true>;
+  auto k = chord_fwd_win_k<float, 15, 1, R, NT, DMA, /*RES=*/true, /*EDGE=*/false>;
   static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::lds_bytes), true);
   (void)once;
   hipLaunchKernelGGL(k, dim3(gm.nblocks), dim3(NT), Cfg::lds_bytes, 0, W, V, res, out, gm, offs, wt);

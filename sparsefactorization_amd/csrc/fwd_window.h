@@ -28,6 +28,12 @@
 
 #include "psf_common.h"
 
+// cache policy of the W-tile DMA (W is read exactly once per step): 0 = default, 2 = non-temporal.
+// r01 lab (profiles/fwdlab.hip, A/B/A in one call): nt 27.2 us vs default 27.6 us per launch at cfg2.
+#ifndef PSF_W_DMA_AUX
+#define PSF_W_DMA_AUX 2
+#endif
+
 namespace psf {
 
 template <typename T, int L, int TGS, int R, int NT>
@@ -49,11 +55,12 @@ struct FwdWinCfg {
 };
 
 // one 16-byte element per lane: global (per-lane address) -> LDS (wave-uniform base + lane*16)
-template <typename T, int VEC, bool DMA>
+// AUX = cache-policy bits of the DMA (0 = default, 2 = nt: streamed-once data).
+template <typename T, int VEC, bool DMA, int AUX = 0>
 __device__ __forceinline__ void stage16(const T* __restrict__ gsrc, Vec<T, VEC>* sdst_wave_base, int lane) {
   if constexpr (DMA) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)sdst_wave_base, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)sdst_wave_base, 16, 0, AUX);
   } else {
     sdst_wave_base[lane] = ld<T, VEC>(gsrc);
   }
@@ -104,7 +111,7 @@ __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* _
             if (e0 + u >= 0 && e0 + u < w_total) se[u] = Wal[(int64_t)i * VEC + u];
         }
       }
-      if (whole) stage16<T, VEC, DMA>(Wal + (int64_t)i * VEC, sWv + n * NT + wave64, lane);
+      if (whole) stage16<T, VEC, DMA, PSF_W_DMA_AUX>(Wal + (int64_t)i * VEC, sWv + n * NT + wave64, lane);
     }
   }
 

@@ -96,6 +96,31 @@ def test_order_accuracy_is_argmax():
     assert ev["accuracy"] == 50.0
 
 
+def test_lra_driver_host_logic():
+    """CLS prepend (listops_training.py:65-72), synthetic token ranges, config -> model on the CPU."""
+    from sparsefactorization_amd import lra_training
+    X, Y = lra_training.synthetic_split("listops", 6, "cpu", 0)
+    assert X.shape == (6, 1999) and X.dtype == torch.int64 and int(X.max()) < 15 and Y.shape == (6,)
+    Xc = lra_training.add_cls_token(X, 17)
+    assert Xc.shape == (6, 2000) and torch.all(Xc[:, 0] == 16) and torch.equal(Xc[:, 1:], X)
+    Xp, _ = lra_training.synthetic_split("pathfinder", 2, "cpu", 0)
+    assert Xp.shape == (2, 1024) and int(Xp.max()) < 225
+    net = lra_training.build_model("cifar10", use_cuda=False)
+    assert net.n_W == 10 and net.final[0].in_features == 1024 * 16 and net.dropout3.p == 0.8
+    assert lra_training.build_model("imdb", use_cuda=False, n_vec=129, n_W=7).embedding.padding_idx == 95
+
+
+@pytest.mark.gpu
+def test_lra_training_driver_runs_on_gpu(gpu, capsys):
+    from sparsefactorization_amd import lra_training
+    lra_training.main(["--task", "listops", "--train-seqs", "160", "--eval-seqs", "32", "--json", "--max-steps", "3"])
+    out = capsys.readouterr().out
+    assert '"task": "listops"' in out and '"n_vec": 2000' in out
+    lra_training.main(["--task", "pathfinder", "--train-seqs", "128", "--eval-seqs", "64", "--epochs", "1"])
+    out = capsys.readouterr().out
+    assert "Training loss" in out and "Test accuracy" in out
+
+
 @pytest.mark.gpu
 def test_training_driver_runs_on_gpu(gpu, capsys):
     from sparsefactorization_amd import psf_training
