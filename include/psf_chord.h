@@ -156,6 +156,9 @@ int psf_linear_wgrad_f32(const float* X, const float* dY, int64_t T, int32_t m, 
  *   key "bwd_rows"   : 0 = defaults (dV 2, dW 1), else rows per thread of both backward window kernels
  *   key "fwd_split"  : 1 = full tiles on the predicate-free kernel, ragged tiles in a second launch (default);
  *                      0 = every tile on the general (edge) kernel
+ *   key "fwd_wide"   : rows of >= 64 channels: 0 = one workgroup spans the whole row (default, fastest measured);
+ *                      1 = 32-channel chunks on 1024-thread workgroups (256-row tiles); 2 = 32-channel chunks
+ *                      on 256-thread workgroups
  *   key "xcd_remap"  : 1 = keep a batch element's tiles on one XCD group (default), 0 = linear
  * psf_get_tuning returns the value (>= 0) or PSF_E_TUNING.
  */

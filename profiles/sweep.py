@@ -42,8 +42,12 @@ VARIANTS = [
     ("win_r8", {"fwd_variant": 2, "fwd_rows": 8}),
     ("auto_noremap", {"xcd_remap": 0}),
     ("auto_alledge", {"fwd_split": 0}),
+    ("wide0_wholerow", {"fwd_wide": 0}),
+    ("wide1_nt1024", {"fwd_wide": 1}),
+    ("wide2_chunk256", {"fwd_wide": 2}),
+    ("wide2_chunk_r1", {"fwd_wide": 2, "fwd_rows": 1}),
 ]
-DEFAULTS = {"fwd_variant": 0, "fwd_rows": 0, "xcd_remap": 1, "fwd_split": 1}
+DEFAULTS = {"fwd_variant": 0, "fwd_rows": 0, "xcd_remap": 1, "fwd_split": 1, "fwd_wide": 0}
 
 
 def set_knobs(kn):
@@ -103,7 +107,7 @@ def main():
         seen = {}
         uniq = []
         for vname, kn, desc in usable:  # drop knob settings that resolve to an identical kernel
-            key = (desc, kn.get("xcd_remap", 1), kn.get("fwd_split", 1) if "win" in desc else 1)
+            key = (desc, kn.get("xcd_remap", 1))  # desc already names tile shape, NT and full/edge split
             if key in seen:
                 continue
             seen[key] = vname

@@ -49,6 +49,10 @@ def _units():
                       [f"-DPSF_TGS={t}"]))
         units.append((os.path.join(OBJ_DIR, f"bwd_window_tgs{t}.o"), os.path.join(CSRC, "bwd_window_inst.hip"),
                       [f"-DPSF_TGS={t}"]))
+    # wide-row configuration (fwd_window_launch.h: kWideTgs, kWideThreads)
+    wide = ["-DPSF_TGS=3", "-DPSF_NT=1024"]
+    units.append((os.path.join(OBJ_DIR, "fwd_window_wide.o"), os.path.join(CSRC, "fwd_window_inst.hip"), wide))
+    units.append((os.path.join(OBJ_DIR, "bwd_window_wide.o"), os.path.join(CSRC, "bwd_window_inst.hip"), wide))
     return units
 
 

@@ -1,7 +1,10 @@
-// bwd_window_inst.hip — instantiates the LDS-window backward kernels for ONE channel-group shift.
-// Built seven times (-DPSF_TGS=0 .. 6) so the instances compile in parallel; see build.py.
+// bwd_window_inst.hip — instantiates the LDS-window backward kernels for ONE (channel-group shift, workgroup
+// size) pair. Built once per compiled pair (-DPSF_TGS=0..6 [-DPSF_NT=1024]); see build.py.
 #ifndef PSF_TGS
 #error "compile with -DPSF_TGS=<0..6>"
+#endif
+#ifndef PSF_NT
+#define PSF_NT 256
 #endif
 
 #include <atomic>
@@ -22,35 +25,35 @@ hipError_t raise_lds_limit(K kern, int bytes, std::atomic<int>& done) {
   return hipSuccess;
 }
 
-template <int L, int TGS, int R, bool EDGE>
+template <int L, int TGS, int R, int NT, bool EDGE>
 hipError_t launch_dw(const BwdWinArgs& a) {
-  using Cfg = BwdWinCfg<float, L, TGS, R, kWinThreads>;
-  auto kern = chord_dw_win_k<float, L, TGS, R, kWinThreads, EDGE>;
+  using Cfg = BwdWinCfg<float, L, TGS, R, NT>;
+  auto kern = chord_dw_win_k<float, L, TGS, R, NT, EDGE>;
   static std::atomic<int> done{0};
   if (hipError_t e = raise_lds_limit(kern, Cfg::lds_dw, done); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(kWinThreads), Cfg::lds_dw, a.stream, a.dZ, a.WV, a.out, a.gm,
-                     a.offs, a.w_total);
+  hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(NT), Cfg::lds_dw, a.stream, a.dZ, a.WV, a.out, a.gm, a.offs,
+                     a.w_total);
   return hipGetLastError();
 }
 
-template <int L, int TGS, int R, bool EDGE>
+template <int L, int TGS, int R, int NT, bool EDGE>
 hipError_t launch_dv(const BwdWinArgs& a) {
-  using Cfg = BwdWinCfg<float, L, TGS, R, kWinThreads>;
-  auto kern = chord_dv_win_k<float, L, TGS, R, kWinThreads, EDGE>;
+  using Cfg = BwdWinCfg<float, L, TGS, R, NT>;
+  auto kern = chord_dv_win_k<float, L, TGS, R, NT, EDGE>;
   static std::atomic<int> done{0};
   if (hipError_t e = raise_lds_limit(kern, Cfg::lds_dv, done); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(kWinThreads), Cfg::lds_dv, a.stream, a.dZ, a.WV, a.out, a.gm,
-                     a.offs, a.w_total);
+  hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(NT), Cfg::lds_dv, a.stream, a.dZ, a.WV, a.out, a.gm, a.offs,
+                     a.w_total);
   return hipGetLastError();
 }
 
-template <int TGS, int R, bool DW>
+template <int TGS, int R, int NT, bool DW>
 hipError_t launch_L(int L, const BwdWinArgs& a) {
   switch (L) {
-#define PSF_CASE(LL)                                                                                  \
-  case LL:                                                                                            \
-    if constexpr (DW) return a.edge ? launch_dw<LL, TGS, R, true>(a) : launch_dw<LL, TGS, R, false>(a); \
-    else return a.edge ? launch_dv<LL, TGS, R, true>(a) : launch_dv<LL, TGS, R, false>(a);
+#define PSF_CASE(LL)                                                                                            \
+  case LL:                                                                                                      \
+    if constexpr (DW) return a.edge ? launch_dw<LL, TGS, R, NT, true>(a) : launch_dw<LL, TGS, R, NT, false>(a); \
+    else return a.edge ? launch_dv<LL, TGS, R, NT, true>(a) : launch_dv<LL, TGS, R, NT, false>(a);
     PSF_CASE(4) PSF_CASE(5) PSF_CASE(6) PSF_CASE(7) PSF_CASE(8) PSF_CASE(9) PSF_CASE(10) PSF_CASE(11)
     PSF_CASE(12) PSF_CASE(13) PSF_CASE(14) PSF_CASE(15) PSF_CASE(16) PSF_CASE(17) PSF_CASE(18)
     PSF_CASE(19) PSF_CASE(20)
@@ -62,20 +65,23 @@ hipError_t launch_L(int L, const BwdWinArgs& a) {
 
 }  // namespace
 
+#if PSF_NT == 256
 template <int TGS>
-hipError_t launch_dw_win_tgs(int rows, int L, const BwdWinArgs& a) {
-  if (rows == 1) return launch_L<TGS, 1, true>(L, a);
-  if (rows == 2) return launch_L<TGS, 2, true>(L, a);
+hipError_t launch_dw_win(int rows, int L, const BwdWinArgs& a) {
+  if (rows == 1) return launch_L<TGS, 1, 256, true>(L, a);
+  if (rows == 2) return launch_L<TGS, 2, 256, true>(L, a);
   return hipErrorInvalidValue;
 }
-template <int TGS>
-hipError_t launch_dv_win_tgs(int rows, int L, const BwdWinArgs& a) {
-  if (rows == 1) return launch_L<TGS, 1, false>(L, a);
-  if (rows == 2) return launch_L<TGS, 2, false>(L, a);
-  return hipErrorInvalidValue;
-}
+template hipError_t launch_dw_win<PSF_TGS>(int rows, int L, const BwdWinArgs& a);
+#endif
 
-template hipError_t launch_dw_win_tgs<PSF_TGS>(int rows, int L, const BwdWinArgs& a);
-template hipError_t launch_dv_win_tgs<PSF_TGS>(int rows, int L, const BwdWinArgs& a);
+template <int TGS, int NT>
+hipError_t launch_dv_win(int rows, int L, const BwdWinArgs& a) {
+  static_assert(win_pair_compiled(TGS, NT), "not a compiled (TGS, NT) pair");
+  if (rows == 1) return launch_L<TGS, 1, NT, false>(L, a);
+  if (rows == 2) return launch_L<TGS, 2, NT, false>(L, a);
+  return hipErrorInvalidValue;
+}
+template hipError_t launch_dv_win<PSF_TGS, PSF_NT>(int rows, int L, const BwdWinArgs& a);
 
 }  // namespace psf

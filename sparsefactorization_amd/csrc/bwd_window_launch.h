@@ -1,5 +1,7 @@
 // bwd_window_launch.h — host-side launcher interface of the LDS-window backward kernels (see bwd_window.h).
-// Compiled once per channel-group shift, like the forward instances (bwd_window_inst.hip, -DPSF_TGS=0..6).
+// Compiled per (TGS, NT) pair like the forward instances (bwd_window_inst.hip, -DPSF_TGS=.. [-DPSF_NT=1024]).
+// dW is compiled at 256 threads only: its per-row reduction needs every channel of a row in one workgroup, so it
+// cannot use the channel-chunked wide-row configuration.
 #pragma once
 
 #include "fwd_window_launch.h"
@@ -18,8 +20,8 @@ struct BwdWinArgs {
 };
 
 template <int TGS>
-hipError_t launch_dw_win_tgs(int rows, int L, const BwdWinArgs& a);
-template <int TGS>
-hipError_t launch_dv_win_tgs(int rows, int L, const BwdWinArgs& a);
+hipError_t launch_dw_win(int rows, int L, const BwdWinArgs& a);
+template <int TGS, int NT>
+hipError_t launch_dv_win(int rows, int L, const BwdWinArgs& a);
 
 }  // namespace psf

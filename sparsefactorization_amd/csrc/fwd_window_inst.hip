@@ -1,7 +1,11 @@
-// fwd_window_inst.hip — instantiates the LDS-window forward kernels for ONE channel-group shift.
-// Built seven times (-DPSF_TGS=0 .. 6) so the instances compile in parallel; see build.py.
+// fwd_window_inst.hip — instantiates the LDS-window forward kernels for ONE (channel-group shift, workgroup
+// size) pair. Built once per compiled pair (-DPSF_TGS=0..6 [-DPSF_NT=1024]) so the instances compile in
+// parallel; see build.py.
 #ifndef PSF_TGS
 #error "compile with -DPSF_TGS=<0..6>"
+#endif
+#ifndef PSF_NT
+#define PSF_NT 256
 #endif
 
 #include <atomic>
@@ -12,10 +16,10 @@
 namespace psf {
 namespace {
 
-template <int L, int TGS, int R, bool RES, bool EDGE>
+template <int L, int TGS, int R, int NT, bool RES, bool EDGE>
 hipError_t launch_one(const FwdWinArgs& a) {
-  using Cfg = FwdWinCfg<float, L, TGS, R, kWinThreads>;
-  auto kern = chord_fwd_win_k<float, L, TGS, R, kWinThreads, /*DMA=*/true, RES, EDGE>;
+  using Cfg = FwdWinCfg<float, L, TGS, R, NT>;
+  auto kern = chord_fwd_win_k<float, L, TGS, R, NT, /*DMA=*/true, RES, EDGE>;
   if (Cfg::lds_bytes > 48 * 1024) {
     static std::atomic<int> done{0};
     if (!done.load()) {
@@ -25,23 +29,24 @@ hipError_t launch_one(const FwdWinArgs& a) {
       done.store(1);
     }
   }
-  hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(kWinThreads), Cfg::lds_bytes, a.stream, a.W, a.V, a.res, a.out,
-                     a.gm, a.offs, a.w_total);
+  hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(NT), Cfg::lds_bytes, a.stream, a.W, a.V, a.res, a.out, a.gm,
+                     a.offs, a.w_total);
   return hipGetLastError();
 }
 
-template <int L, int TGS, int R>
+template <int L, int TGS, int R, int NT>
 hipError_t launch_flags(const FwdWinArgs& a) {
-  if (a.res != nullptr) return a.edge ? launch_one<L, TGS, R, true, true>(a) : launch_one<L, TGS, R, true, false>(a);
-  return a.edge ? launch_one<L, TGS, R, false, true>(a) : launch_one<L, TGS, R, false, false>(a);
+  if (a.res != nullptr)
+    return a.edge ? launch_one<L, TGS, R, NT, true, true>(a) : launch_one<L, TGS, R, NT, true, false>(a);
+  return a.edge ? launch_one<L, TGS, R, NT, false, true>(a) : launch_one<L, TGS, R, NT, false, false>(a);
 }
 
-template <int TGS, int R>
+template <int TGS, int R, int NT>
 hipError_t launch_L(int L, const FwdWinArgs& a) {
   switch (L) {
 #define PSF_CASE(LL) \
   case LL:           \
-    return launch_flags<LL, TGS, R>(a);
+    return launch_flags<LL, TGS, R, NT>(a);
     PSF_CASE(4) PSF_CASE(5) PSF_CASE(6) PSF_CASE(7) PSF_CASE(8) PSF_CASE(9) PSF_CASE(10) PSF_CASE(11)
     PSF_CASE(12) PSF_CASE(13) PSF_CASE(14) PSF_CASE(15) PSF_CASE(16) PSF_CASE(17) PSF_CASE(18)
     PSF_CASE(19) PSF_CASE(20)
@@ -53,14 +58,15 @@ hipError_t launch_L(int L, const FwdWinArgs& a) {
 
 }  // namespace
 
-template <int TGS>
-hipError_t launch_fwd_win_tgs(int rows, int L, const FwdWinArgs& a) {
+template <int TGS, int NT>
+hipError_t launch_fwd_win(int rows, int L, const FwdWinArgs& a) {
   static_assert(kWinLmin == 4 && kWinLmax == 20, "keep the PSF_CASE list in step with kWinLmin/kWinLmax");
-  if (rows == 1) return launch_L<TGS, 1>(L, a);
-  if (rows == 2) return launch_L<TGS, 2>(L, a);
+  static_assert(win_pair_compiled(TGS, NT), "not a compiled (TGS, NT) pair");
+  if (rows == 1) return launch_L<TGS, 1, NT>(L, a);
+  if (rows == 2) return launch_L<TGS, 2, NT>(L, a);
   return hipErrorInvalidValue;
 }
 
-template hipError_t launch_fwd_win_tgs<PSF_TGS>(int rows, int L, const FwdWinArgs& a);
+template hipError_t launch_fwd_win<PSF_TGS, PSF_NT>(int rows, int L, const FwdWinArgs& a);
 
 }  // namespace psf

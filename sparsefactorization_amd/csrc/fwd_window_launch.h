@@ -1,8 +1,9 @@
 // fwd_window_launch.h — host-side launcher interface of the LDS-window forward kernels.
 //
-// The kernels are templates over (L, TGS, R, RES, EDGE): a few hundred instances. They are compiled in one
-// translation unit per channel-group shift TGS (fwd_window_inst.hip built with -DPSF_TGS=0..6, in parallel) and
-// reached through launch_fwd_win_tgs<TGS>, which this header declares for the dispatcher in psf_chord.hip.
+// The kernels are templates over (L, TGS, R, NT, RES, EDGE): several hundred instances. They are compiled in one
+// translation unit per (channel-group shift TGS, workgroup size NT) pair (fwd_window_inst.hip built with
+// -DPSF_TGS=.. -DPSF_NT=.., in parallel) and reached through launch_fwd_win<TGS, NT>, which this header declares
+// for the dispatcher in psf_chord.hip.
 #pragma once
 
 #include "psf_common.h"
@@ -11,9 +12,16 @@ namespace psf {
 
 constexpr int kWinLmin = 4, kWinLmax = 20;  // compiled link counts
 constexpr int kWinTgsMax = 6;               // TG = 1 << TGS <= 64 lanes share a row
-constexpr int kWinThreads = 256;            // threads per workgroup (r01: 512/1024-thread tiles were no faster)
 
-// Rows per thread R that are compiled for every TGS, and the default.
+// Compiled (TGS, NT) pairs: every TGS at 256 threads, plus the "wide-row" configuration: 8 lanes per row
+// (32 channels = one 128-byte line per row chunk; wider rows are split into channel chunks) at 1024 threads,
+// i.e. 256-row tiles. For C >= 64 that turns all but L-10 links into near links (see fwd_window.h).
+constexpr int kWideTgs = 3, kWideThreads = 1024;
+constexpr bool win_pair_compiled(int tgs, int nt) {
+  return (nt == 256 && tgs >= 0 && tgs <= kWinTgsMax) || (nt == kWideThreads && tgs == kWideTgs);
+}
+
+// Rows per thread R that are compiled, and the default.
 // r01 measurements (us per launch): cfg2 (C=8) R=2 27.5 < R=1 29.1; cfg3 (C=128) R=2 16.1 < R=4 16.9 < R=8 19.8;
 // cfg4 (C=32) R=1 6.0 ~ R=2 6.1 < R=4 6.4.
 constexpr bool win_rows_compiled(int r) { return r == 1 || r == 2; }
@@ -31,11 +39,11 @@ struct FwdWinArgs {
   hipStream_t stream;
 };
 
-// Launch the instance (L, TGS, R = rows). Returns hipErrorInvalidValue when that instance is not compiled.
-template <int TGS>
-hipError_t launch_fwd_win_tgs(int rows, int L, const FwdWinArgs& a);
+// Launch the instance (L, TGS, R = rows, NT). Returns hipErrorInvalidValue when that instance is not compiled.
+template <int TGS, int NT>
+hipError_t launch_fwd_win(int rows, int L, const FwdWinArgs& a);
 
-// window geometry for a (TGS, rows) pair — mirrors FwdWinCfg
-inline int win_tile_rows(int tgs, int rows) { return (kWinThreads >> tgs) * rows; }
+// window geometry for a (TGS, rows, NT) triple — mirrors FwdWinCfg
+inline int win_tile_rows(int tgs, int rows, int nt) { return (nt >> tgs) * rows; }
 
 }  // namespace psf

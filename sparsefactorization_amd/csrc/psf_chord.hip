@@ -42,6 +42,11 @@ std::atomic<int> g_xcd_remap{1};
 std::atomic<int> g_fwd_rows{0};     // 0 = default, else rows per thread (R) of the window kernel
 std::atomic<int> g_fwd_split{1};    // 1 = full tiles on the predicate-free kernel + ragged tiles separately
 std::atomic<int> g_bwd_rows{0};     // 0 = default, else rows per thread (R) of the backward window kernels
+// Rows of >= 64 channels: 0 = one workgroup spans the whole row (default); 1 = 32-channel chunks on 1024-thread
+// workgroups (256-row tiles, far links 6 -> 2 at L=12); 2 = 32-channel chunks on 256-thread workgroups.
+// r01 sweep (us/launch): cfg3 C=128: 18.9 / 23.2 / 21.8; attention map C=1024: 19.2 / 20.5 / 20.9; C=64: 10.2 / 9.4 /
+// 10.0 — contiguous whole-row bursts beat fewer far links, so 0 stays the default.
+std::atomic<int> g_fwd_wide{0};
 
 struct Knob {
   const char* key;
@@ -51,6 +56,7 @@ struct Knob {
 Knob g_knobs[] = {
     {"fwd_variant", &g_fwd_variant, 0, 2}, {"bwd_variant", &g_bwd_variant, 0, 1}, {"xcd_remap", &g_xcd_remap, 0, 1},
     {"fwd_rows", &g_fwd_rows, 0, 8},       {"fwd_split", &g_fwd_split, 0, 1},     {"bwd_rows", &g_bwd_rows, 0, 8},
+    {"fwd_wide", &g_fwd_wide, 0, 2},
 };
 
 int ceil_log2(int64_t x) {
@@ -132,61 +138,68 @@ int generic_geom(int64_t B, int64_t N, int32_t L, int64_t C, int vec, bool split
 // window-kernel selection
 // ------------------------------------------------------------------------------------------------------
 struct WinPick {
-  int tgs, rows, TR, KN;
+  int tgs, rows, nt, TR, KN;
   int tiles_full;  // row tiles per sequence with all TR rows < N
   bool ragged;     // N % TR != 0: one more, partial, tile per sequence
   bool all_edge;   // every tile must take the EDGE kernel (channel groups not a multiple of TG, or W not chunk-clean)
 };
 
-hipError_t launch_win(int tgs, int rows, int L, const FwdWinArgs& a) {
-  switch (tgs) {
-    case 0: return launch_fwd_win_tgs<0>(rows, L, a);
-    case 1: return launch_fwd_win_tgs<1>(rows, L, a);
-    case 2: return launch_fwd_win_tgs<2>(rows, L, a);
-    case 3: return launch_fwd_win_tgs<3>(rows, L, a);
-    case 4: return launch_fwd_win_tgs<4>(rows, L, a);
-    case 5: return launch_fwd_win_tgs<5>(rows, L, a);
-    case 6: return launch_fwd_win_tgs<6>(rows, L, a);
-    default: return hipErrorInvalidValue;
+#define PSF_TGS_SWITCH(FN, ARGS)                 \
+  switch (pk.tgs) {                              \
+    case 0: return FN<0, 256> ARGS;              \
+    case 1: return FN<1, 256> ARGS;              \
+    case 2: return FN<2, 256> ARGS;              \
+    case 3: return FN<3, 256> ARGS;              \
+    case 4: return FN<4, 256> ARGS;              \
+    case 5: return FN<5, 256> ARGS;              \
+    case 6: return FN<6, 256> ARGS;              \
+    default: return hipErrorInvalidValue;        \
   }
+
+hipError_t launch_win(const WinPick& pk, int L, const FwdWinArgs& a) {
+  if (pk.nt == kWideThreads) return pk.tgs == kWideTgs ? launch_fwd_win<kWideTgs, kWideThreads>(pk.rows, L, a) : hipErrorInvalidValue;
+  PSF_TGS_SWITCH(launch_fwd_win, (pk.rows, L, a))
 }
 
-hipError_t launch_dw_win(int tgs, int rows, int L, const BwdWinArgs& a) {
-  switch (tgs) {
-    case 0: return launch_dw_win_tgs<0>(rows, L, a);
-    case 1: return launch_dw_win_tgs<1>(rows, L, a);
-    case 2: return launch_dw_win_tgs<2>(rows, L, a);
-    case 3: return launch_dw_win_tgs<3>(rows, L, a);
-    case 4: return launch_dw_win_tgs<4>(rows, L, a);
-    case 5: return launch_dw_win_tgs<5>(rows, L, a);
-    case 6: return launch_dw_win_tgs<6>(rows, L, a);
-    default: return hipErrorInvalidValue;
-  }
+hipError_t launch_dv(const WinPick& pk, int L, const BwdWinArgs& a) {
+  if (pk.nt == kWideThreads) return pk.tgs == kWideTgs ? launch_dv_win<kWideTgs, kWideThreads>(pk.rows, L, a) : hipErrorInvalidValue;
+  PSF_TGS_SWITCH(launch_dv_win, (pk.rows, L, a))
 }
+#undef PSF_TGS_SWITCH
 
-hipError_t launch_dv_win(int tgs, int rows, int L, const BwdWinArgs& a) {
-  switch (tgs) {
-    case 0: return launch_dv_win_tgs<0>(rows, L, a);
-    case 1: return launch_dv_win_tgs<1>(rows, L, a);
-    case 2: return launch_dv_win_tgs<2>(rows, L, a);
-    case 3: return launch_dv_win_tgs<3>(rows, L, a);
-    case 4: return launch_dv_win_tgs<4>(rows, L, a);
-    case 5: return launch_dv_win_tgs<5>(rows, L, a);
-    case 6: return launch_dv_win_tgs<6>(rows, L, a);
+hipError_t launch_dw(const WinPick& pk, int L, const BwdWinArgs& a) {
+  switch (pk.tgs) {
+    case 0: return launch_dw_win<0>(pk.rows, L, a);
+    case 1: return launch_dw_win<1>(pk.rows, L, a);
+    case 2: return launch_dw_win<2>(pk.rows, L, a);
+    case 3: return launch_dw_win<3>(pk.rows, L, a);
+    case 4: return launch_dw_win<4>(pk.rows, L, a);
+    case 5: return launch_dw_win<5>(pk.rows, L, a);
+    case 6: return launch_dw_win<6>(pk.rows, L, a);
     default: return hipErrorInvalidValue;
   }
 }
 
 // Decide whether a window kernel applies (f32, vectorisable, chord-like near links); fills pick on success.
 // `W` is the flat [B,N,L] array the kernel copies in 16-byte chunks (W itself, or dW for the dW kernel).
+// `chunk_channels`: the kernel may split a row's channels over several workgroups (forward, dV) — then wide rows
+// (C >= 64) use the wide-row configuration: 32-channel chunks, 1024 threads, 256-row tiles.
 bool pick_window(const void* W, int64_t B, int64_t N, int32_t L, int64_t C, const Offsets& offs, bool vec_ok,
-                 WinPick* pick, int rows_pref = -1) {
+                 WinPick* pick, int rows_pref, bool chunk_channels) {
   if (!vec_ok || L < kWinLmin || L > kWinLmax) return false;
   const int64_t CG = C / 4;
-  const int tgs = ceil_log2(CG) > kWinTgsMax ? kWinTgsMax : ceil_log2(CG);
-  int rows = rows_pref >= 0 ? rows_pref : g_fwd_rows.load();
-  if (rows == 0 || !win_rows_compiled(rows)) rows = win_default_rows(tgs);
-  const int TR = win_tile_rows(tgs, rows);
+  int tgs = ceil_log2(CG) > kWinTgsMax ? kWinTgsMax : ceil_log2(CG);
+  int nt = 256;
+  int rows = rows_pref;
+  if (rows <= 0 || !win_rows_compiled(rows)) rows = win_default_rows(tgs);
+  const int wide = g_fwd_wide.load();
+  if (chunk_channels && wide == 1 && CG >= 16 && N >= 2 * (int64_t)win_tile_rows(kWideTgs, rows, kWideThreads)) {
+    tgs = kWideTgs;  // 32-channel chunks on 1024-thread workgroups
+    nt = kWideThreads;
+  } else if (chunk_channels && wide == 2 && CG >= 16) {
+    tgs = kWideTgs;  // 32-channel chunks on 256-thread workgroups
+  }
+  const int TR = win_tile_rows(tgs, rows, nt);
   if (N < 2 * (int64_t)TR) return false;  // the window may wrap at most once
   int KN = 2;                             // offsets 0, 1, 2, ..., 2^(KN-2) <= TR
   for (int t = TR; t > 1; t >>= 1) ++KN;
@@ -195,6 +208,7 @@ bool pick_window(const void* W, int64_t B, int64_t N, int32_t L, int64_t C, cons
     if (offs.v[k] > TR) return false;  // near links must fall inside the window
   pick->tgs = tgs;
   pick->rows = rows;
+  pick->nt = nt;
   pick->TR = TR;
   pick->KN = KN;
   pick->tiles_full = (int)(N / TR);
@@ -247,7 +261,7 @@ int fwd_window_f32(const WinPick& pk, const float* W, const float* V, const floa
   a.w_total = B * N * (int64_t)L;
   a.stream = s;
   return window_launches(pk, pk.all_edge, B, N, L, C, v_batch_stride, true, &a.gm, &a.edge,
-                         [&] { return launch_win(pk.tgs, pk.rows, L, a); }, "chord_fwd_win launch");
+                         [&] { return launch_win(pk, L, a); }, "chord_fwd_win launch");
 }
 
 template <typename T>
@@ -271,7 +285,7 @@ int fwd_impl(const T* W, const T* V, const T* res, T* out, int64_t B, int64_t N,
   const int variant = g_fwd_variant.load();
   if constexpr (sizeof(T) == 4) {  // the window kernels are compiled for f32 only (f64 exists for gradcheck)
     WinPick pk;
-    if (variant != 1 && pick_window(W, B, N, L, C, offs, vec_ok, &pk))
+    if (variant != 1 && pick_window(W, B, N, L, C, offs, vec_ok, &pk, g_fwd_rows.load(), true))
       return fwd_window_f32(pk, W, V, res, out, B, N, L, C, v_batch_stride, offs, s);
   }
   if (variant == 2)
@@ -315,21 +329,21 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
       const int knob = g_bwd_rows.load();
       const int rows_dv = knob ? knob : 2, rows_dw = knob ? knob : 1;
       if (dV && pick_window(W, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(dV, 16), &pk,
-                            rows_dv)) {
+                            rows_dv, true)) {
         BwdWinArgs a{dZ, W, dV, Geom{}, offs, w_total, false, s};
         int rc = window_launches(pk, pk.all_edge, B, N, L, C, N * C, true, &a.gm, &a.edge,
-                                 [&] { return launch_dv_win(pk.tgs, pk.rows, L, a); }, "chord_dv_win");
+                                 [&] { return launch_dv(pk, L, a); }, "chord_dv_win");
         if (rc) return rc;
         dV = nullptr;
       }
       if (dW && C / 4 <= TGmax &&
           pick_window(dW, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(V, 16), &pk,
-                      rows_dw)) {
+                      rows_dw, false)) {
         // the dW tile store is chunk-clean only if every sequence starts on a 16-byte boundary
         const bool all_edge = pk.all_edge || ((N * (int64_t)L) % 4) != 0;
         BwdWinArgs a{dZ, V, dW, Geom{}, offs, w_total, false, s};
         int rc = window_launches(pk, all_edge, B, N, L, C, v_batch_stride, false, &a.gm, &a.edge,
-                                 [&] { return launch_dw_win(pk.tgs, pk.rows, L, a); }, "chord_dw_win");
+                                 [&] { return launch_dw(pk, L, a); }, "chord_dw_win");
         if (rc) return rc;
         dW = nullptr;
       }
@@ -489,9 +503,9 @@ int psf_describe_fwd(int64_t B, int64_t N, int32_t L, int64_t C, int32_t elem_by
   const bool vec_ok = C % vecw == 0;
   WinPick pk;
   const int variant = g_fwd_variant.load();
-  if (variant != 1 && elem_bytes == 4 && pick_window(nullptr, B, N, L, C, offs, vec_ok, &pk)) {
-    snprintf(buf, cap, "chord_fwd_win_k<f32,L=%d,TG=%d,R=%d> TR=%d near=%d far=%d tiles=%s", (int)L, 1 << pk.tgs,
-             pk.rows, pk.TR, pk.KN, (int)L - pk.KN,
+  if (variant != 1 && elem_bytes == 4 && pick_window(nullptr, B, N, L, C, offs, vec_ok, &pk, g_fwd_rows.load(), true)) {
+    snprintf(buf, cap, "chord_fwd_win_k<f32,L=%d,TG=%d,R=%d,NT=%d> TR=%d near=%d far=%d tiles=%s", (int)L,
+             1 << pk.tgs, pk.rows, pk.nt, pk.TR, pk.KN, (int)L - pk.KN,
              pk.all_edge ? "edge" : (pk.ragged ? "full+ragged" : "full"));
   } else {
     snprintf(buf, cap, "chord_fwd_generic_k<%s,VEC=%d>", elem_bytes == 4 ? "f32" : "f64", vec_ok ? vecw : 1);

@@ -102,6 +102,26 @@ def test_forward_split_and_edge_kernels_agree_on_all_shapes(gpu, split):
         sfa.set_tuning("fwd_split", 1)
 
 
+@pytest.mark.parametrize("wide", [0, 1, 2])
+@pytest.mark.parametrize("B,N,L,C", [(2, 2000, 12, 128), (1, 1024, 12, 1024), (3, 600, 10, 64), (2, 4097, 13, 260),
+                                     (2, 512, 9, 64), (2, 511, 9, 64), (1, 1536, 20, 96)])
+def test_forward_wide_rows(gpu, B, N, L, C, wide):
+    """Rows of >= 64 channels: channel-chunked 1024-thread tiles (fwd_wide=1) vs one workgroup per whole row."""
+    import sparsefactorization_amd as sfa
+    W, V, R = _mk((B, N, L), 51), _mk((B, N, C), 52), _mk((B, N, C), 53)
+    sfa.set_tuning("fwd_wide", wide)
+    try:
+        desc = sfa.describe_fwd(B, N, L, C)
+        got = sfa.chord_spmm(_t(W, gpu), _t(V, gpu), _t(R, gpu)).cpu().numpy()
+        got_nores = sfa.chord_spmm(_t(W, gpu), _t(V, gpu)).cpu().numpy()
+    finally:
+        sfa.set_tuning("fwd_wide", 0)
+    if wide == 1 and N >= 512:
+        assert "NT=1024" in desc, desc
+    assert np.array_equal(got, _oracle_fwd(W, V, R)), desc
+    assert np.array_equal(got_nores, _oracle_fwd(W, V)), desc
+
+
 def test_forward_xcd_remap_off(gpu):
     import sparsefactorization_amd as sfa
     W, V = _mk((5, 1000, 11), 7), _mk((5, 1000, 8), 8)
@@ -201,6 +221,21 @@ def test_backward_window_kernels(gpu, B, N, L, C, rows):
     for variant, (gW, gV) in got.items():
         assert np.array_equal(gV, dV), f"dV variant={variant}"
         assert rel_inf(gW, dF) <= TOL, f"dW variant={variant}"
+
+
+@pytest.mark.parametrize("wide", [1, 2])
+@pytest.mark.parametrize("B,N,L,C", [(2, 2000, 12, 128), (2, 640, 10, 260), (2, 2048, 12, 64)])
+def test_backward_dv_wide_row_configs(gpu, B, N, L, C, wide):
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.chord import _launch_bwd
+    W, V, dZ = _mk((B, N, L), 47), _mk((B, N, C), 48), _mk((B, N, C), 49)
+    sfa.set_tuning("fwd_wide", wide)
+    try:
+        gV = torch.full((B, N, C), float("nan"), device=gpu)
+        _launch_bwd(_t(dZ, gpu), _t(W, gpu), _t(V, gpu), None, gV, B, N, L, C, N * C, None)
+    finally:
+        sfa.set_tuning("fwd_wide", 0)
+    assert np.array_equal(gV.cpu().numpy(), oc.spmul_bwd(dZ, W, V)[1])
 
 
 def test_backward_window_misaligned_buffers(gpu):
