@@ -103,6 +103,96 @@ lab_k(const float* __restrict__ W, const float* __restrict__ V, const float* __r
   }
 }
 
+// Persistent variant: gridDim.x workgroups (a multiple of 8) walk the tiles of their XCD's contiguous share.
+// PF = 0: same schedule as the product kernel inside the loop. PF = 1: the NEXT tile's W tile and window are
+// DMA'd into the other LDS buffer right after the barrier, so they fly during this tile's accumulate.
+template <int L, int TGS, int R, int NT, int PF>
+__global__ void __launch_bounds__(NT)
+persist_k(const float* __restrict__ W, const float* __restrict__ V, const float* __restrict__ res,
+          float* __restrict__ out, const Geom gm, const Offsets offs, const int64_t w_total) {
+  using T = float;
+  using Cfg = FwdWinCfg<T, L, TGS, R, NT>;
+  constexpr int VEC = 4, TG = Cfg::TG, RS = Cfg::RS, TR = Cfg::TR, KN = Cfg::KN, NF = Cfg::NF;
+  using V4 = Vec<T, VEC>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BUF = Cfg::lds_bytes;
+  const int tid = threadIdx.x, lane = tid & 63, wave64 = tid & ~63;
+  const int g = tid & (TG - 1), rs = tid >> TGS, N = gm.N, C = gm.C;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, gx = gridDim.x >> 3;
+  const int per_xcd = (int)(gm.nblocks >> 3);  // lab: nblocks % 8 == 0
+
+  auto stage = [&](int lb, char* buf, int& mis_out) {
+    const int b = lb / gm.per_b, tile = lb - b * gm.per_b;
+    const int p0 = tile * TR;
+    V4* sWin = reinterpret_cast<V4*>(buf);
+    V4* sWv = reinterpret_cast<V4*>(buf + Cfg::win_bytes);
+    const T* Vb = V + (int64_t)b * gm.v_bstride;
+    const int64_t e_lo = ((int64_t)b * N + p0) * L;
+    const int mis = (int)(((reinterpret_cast<uintptr_t>(W) / sizeof(T)) + (uint64_t)e_lo) & (VEC - 1));
+    const T* Wal = W + (e_lo - mis);
+    const int nvec = (mis + TR * L + VEC - 1) / VEC;
+#pragma unroll
+    for (int n = 0; n < Cfg::w_passes; ++n) {
+      const int i = n * NT + tid;
+      if (i < nvec) stage16<T, VEC, true, 2>(Wal + (int64_t)i * VEC, sWv + n * NT + wave64, lane);
+    }
+#pragma unroll
+    for (int n = 0; n < Cfg::win_vecs / NT; ++n) {
+      const int i = n * NT + tid;
+      const int wr = i >> TGS, gg = i & (TG - 1);
+      int src = p0 + wr;
+      if (src >= N) src -= N;
+      stage16<T, VEC, true>(Vb + (int64_t)src * C + (int64_t)gg * VEC, sWin + n * NT + wave64, lane);
+    }
+    mis_out = mis;
+  };
+
+  int it = 0;
+  int mis_cur = 0, mis_next = 0;
+  if (PF && local < per_xcd) stage(xcd * per_xcd + local, smem, mis_cur);
+  for (int i = local; i < per_xcd; i += gx, ++it) {
+    const int lb = xcd * per_xcd + i;
+    char* buf = smem + (PF ? (it & 1) * BUF : 0);
+    if (!PF) stage(lb, buf, mis_cur);
+    const int b = lb / gm.per_b, tile = lb - b * gm.per_b;
+    const int p0 = tile * TR;
+    const T* Vb = V + (int64_t)b * gm.v_bstride;
+    V4 far[R][NF > 0 ? NF : 1];
+    V4 rres[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int p = p0 + j * RS + rs;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        int src = p + offs.v[KN + f];
+        if (src >= N) src -= N;
+        far[j][f] = ld<T, VEC>(Vb + (int64_t)src * C + (int64_t)g * VEC);
+      }
+      rres[j] = ld<T, VEC>(res + ((int64_t)b * N + p) * C + (int64_t)g * VEC);
+    }
+    __syncthreads();
+    if (PF && i + gx < per_xcd) stage(lb + gx, smem + ((it + 1) & 1) * BUF, mis_next);
+    const V4* sWin = reinterpret_cast<const V4*>(buf);
+    const T* sWf = reinterpret_cast<const T*>(buf + Cfg::win_bytes);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int pl = j * RS + rs;
+      V4 acc = V4{{0.f, 0.f, 0.f, 0.f}};
+      const T* wrow = sWf + mis_cur + pl * L;
+#pragma unroll
+      for (int k = 0; k < KN; ++k) axpy_rn<T, VEC>(acc, wrow[k], sWin[((pl + offs.v[k]) << TGS) + g]);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) axpy_rn<T, VEC>(acc, wrow[KN + f], far[j][f]);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc.e[e] = add_rn(acc.e[e], rres[j].e[e]);
+      st<T, VEC>(out + ((int64_t)b * N + p0 + pl) * C + (int64_t)g * VEC, acc);
+    }
+    if (PF) mis_cur = mis_next;
+    else __syncthreads();
+  }
+  (void)w_total;
+}
+
 struct Case {
   const char* name;
   int R, NT;
@@ -125,6 +215,16 @@ void launch_prod(const float* W, const float* V, const float* res, float* out, c
   static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::lds_bytes), true);
   (void)once;
   hipLaunchKernelGGL(k, dim3(gm.nblocks), dim3(NT), Cfg::lds_bytes, 0, W, V, res, out, gm, offs, wt);
+}
+
+template <int R, int NT, int PF, int GRID>
+void launch_persist(const float* W, const float* V, const float* res, float* out, const Geom& gm, const Offsets& offs, int64_t wt) {
+  using Cfg = FwdWinCfg<float, 15, 1, R, NT>;
+  auto k = persist_k<15, 1, R, NT, PF>;
+  const int lds = Cfg::lds_bytes * (PF ? 2 : 1);
+  static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+  (void)once;
+  hipLaunchKernelGGL(k, dim3(GRID), dim3(NT), lds, 0, W, V, res, out, gm, offs, wt);
 }
 
 Geom geom(int B, int N, int L, int C, int tgs, int R, int NT) {
@@ -155,19 +255,15 @@ int main() {
   std::vector<Case> cases = {
       {"prod NT=256  R=1 dma", 1, 256, launch_prod<1, 256, true>, {}},
       {"prod NT=256  R=2 dma", 2, 256, launch_prod<2, 256, true>, {}},
-      {"prod NT=256  R=4 dma", 4, 256, launch_prod<4, 256, true>, {}},
-      {"prod NT=512  R=1 dma", 1, 512, launch_prod<1, 512, true>, {}},
-      {"prod NT=512  R=2 dma", 2, 512, launch_prod<2, 512, true>, {}},
-      {"prod NT=1024 R=1 dma", 1, 1024, launch_prod<1, 1024, true>, {}},
-      {"prod NT=1024 R=2 dma", 2, 1024, launch_prod<2, 1024, true>, {}},
-      {"prod NT=256  R=1 reg", 1, 256, launch_prod<1, 256, false>, {}},
-      {"prod NT=512  R=1 reg", 1, 512, launch_prod<1, 512, false>, {}},
-      {"lab  NT=256  R=1 full", 1, 256, launch_lab<1, 256, 0>, {}},
       {"lab  NT=256  R=2 full", 2, 256, launch_lab<2, 256, 0>, {}},
-      {"lab  NT=512  R=1 full", 1, 512, launch_lab<1, 512, 0>, {}},
-      {"lab  NT=512  R=1 -far", 1, 512, launch_lab<1, 512, 2>, {}},
-      {"lab  NT=1024 R=1 full", 1, 1024, launch_lab<1, 1024, 0>, {}},
-      {"lab  NT=1024 R=1 -far", 1, 1024, launch_lab<1, 1024, 2>, {}},
+      {"persist R=2 PF=0 grid=1280", 2, 256, launch_persist<2, 256, 0, 1280>, {}},
+      {"persist R=2 PF=0 grid=1024", 2, 256, launch_persist<2, 256, 0, 1024>, {}},
+      {"persist R=2 PF=0 grid=2048", 2, 256, launch_persist<2, 256, 0, 2048>, {}},
+      {"persist R=1 PF=0 grid=2048", 1, 256, launch_persist<1, 256, 0, 2048>, {}},
+      {"persist R=2 PF=1 grid=512", 2, 256, launch_persist<2, 256, 1, 512>, {}},
+      {"persist R=1 PF=1 grid=1280", 1, 256, launch_persist<1, 256, 1, 1280>, {}},
+      {"persist R=1 PF=1 grid=1024", 1, 256, launch_persist<1, 256, 1, 1024>, {}},
+      {"persist R=1 PF=1 grid=768", 1, 256, launch_persist<1, 256, 1, 768>, {}},
   };
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));

@@ -16,6 +16,7 @@ hand-written kernels. There is deliberately no CPU or eager-PyTorch fallback.
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -167,10 +168,12 @@ _index_cache: dict = {}
 def offsets_from_index(index: torch.Tensor, m: int) -> Tuple[int, ...]:
     """Recover the link offsets from a COO index list and verify it is the affine (circulant) pattern the
     kernels assume: rows[i*L+k] == i and cols[i*L+k] == (i + off_k) mod m for every i (psf.py:7-32)."""
-    key = (index.data_ptr(), index._version, tuple(index.shape), str(index.device), m)
+    # cache per tensor OBJECT (weak reference) and in-place version: a freed tensor's address can be reused by a
+    # different index list, so data_ptr() is not an identity
+    key = id(index)
     hit = _index_cache.get(key)
-    if hit is not None:
-        return hit
+    if hit is not None and hit[0]() is index and hit[1] == (index._version, m):
+        return hit[2]
     if index.dim() != 2 or index.shape[0] != 2:
         raise ValueError(f"index must be [2, nnz], got {tuple(index.shape)}")
     nnz = index.shape[1]
@@ -190,7 +193,7 @@ def offsets_from_index(index: torch.Tensor, m: int) -> Tuple[int, ...]:
     out = tuple(int(o) for o in off)
     if len(_index_cache) > 64:
         _index_cache.clear()
-    _index_cache[key] = out
+    _index_cache[key] = (weakref.ref(index), (index._version, m), out)
     return out
 
 

@@ -22,6 +22,8 @@
 
 #include "../../include/psf_chord.h"
 
+extern "C" int psf_internal_fail(int code, const char* message);  // psf_chord.hip: sets psf_last_error()
+
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -251,10 +253,11 @@ int64_t psf_linear_wgrad_workspace(int64_t T, int32_t m, int32_t n) {
 
 int psf_linear_wgrad_f32(const float* X, const float* dY, int64_t T, int32_t m, int32_t n, float* dWt, float* db,
                          void* workspace, int64_t workspace_bytes, void* stream) {
-  if (!X || !dY || !dWt || !workspace) return PSF_E_NULL;
+  if (!X || !dY || !dWt || !workspace) return psf_internal_fail(PSF_E_NULL, "psf_linear_wgrad: X, dY, dWt and workspace must be non-NULL");
   Plan p;
-  if (!make_plan(T, m, n, &p)) return PSF_E_SHAPE;
-  if (workspace_bytes < (p.part_floats + p.bpart_floats) * (int64_t)sizeof(float)) return PSF_E_SHAPE;
+  if (!make_plan(T, m, n, &p)) return psf_internal_fail(PSF_E_SHAPE, "psf_linear_wgrad: need T >= 1 and 1 <= m, n <= 128");
+  if (workspace_bytes < (p.part_floats + p.bpart_floats) * (int64_t)sizeof(float))
+    return psf_internal_fail(PSF_E_SHAPE, "psf_linear_wgrad: workspace smaller than psf_linear_wgrad_workspace(T, m, n)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   float* part = reinterpret_cast<float*>(workspace);
   float* bpart = part + p.part_floats;
@@ -264,14 +267,14 @@ int psf_linear_wgrad_f32(const float* X, const float* dY, int64_t T, int32_t m, 
     case 2: e = launch_ti<2>(p, X, dY, T, m, n, part, bpart, s); break;
     case 3: e = launch_ti<3>(p, X, dY, T, m, n, part, bpart, s); break;
     case 4: e = launch_ti<4>(p, X, dY, T, m, n, part, bpart, s); break;
-    default: return PSF_E_SHAPE;
+    default: return psf_internal_fail(PSF_E_SHAPE, "psf_linear_wgrad: unsupported tile count");
   }
-  if (e != hipSuccess) return (int)e;
+  if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
   const int outs = n * m + n;
   hipLaunchKernelGGL(linear_wgrad_reduce_k, dim3((outs + kRedOuts - 1) / kRedOuts), dim3(256), 0, s, part, bpart, p.nparts,
                      p.tj * 32, p.ti * 32, (int)m, (int)n, dWt, db);
   e = hipGetLastError();
-  return e == hipSuccess ? PSF_OK : (int)e;
+  return e == hipSuccess ? PSF_OK : psf_internal_fail((int)e, hipGetErrorString(e));
 }
 
 }  // extern "C"

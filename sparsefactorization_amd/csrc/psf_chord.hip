@@ -403,6 +403,9 @@ int chain_impl(const T* const* W_steps, const T* V0, T* const* out_steps, int32_
 // ------------------------------------------------------------------------------------------------------
 // extern "C"
 // ------------------------------------------------------------------------------------------------------
+// Other translation units of the library report through the same thread-local string (not part of the ABI).
+extern "C" int psf_internal_fail(int code, const char* message) { return fail(code, "%s", message); }
+
 extern "C" {
 
 int psf_version(void) { return PSF_ABI_VERSION; }

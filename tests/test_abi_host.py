@@ -76,7 +76,14 @@ def test_argument_validation_returns_codes_not_crashes(lib):
     assert f(one, two, None, two, 1, 8, 4, 4, 32, None, None) == -3           # PSF_E_ALIAS
     assert f(ctypes.c_void_p(18), one, None, two, 1, 8, 4, 4, 32, None, None) == -4  # PSF_E_ALIGN
     assert f(one, one, None, two, 0, 8, 4, 4, 32, None, None) == 0            # empty batch: nothing to do
-    assert b"alias" in lib.psf_last_error()  or lib.psf_last_error() is not None
+    assert f(one, two, None, two, 1, 8, 4, 4, 32, None, None) == -3 and b"alias" in lib.psf_last_error()
+    # producer-side entry point: validation happens before any HIP call too
+    assert lib.psf_linear_wgrad_workspace(1 << 20, 32, 15) > 0
+    assert lib.psf_linear_wgrad_workspace(1 << 20, 129, 15) == -1
+    assert lib.psf_linear_wgrad_f32(None, one, 64, 8, 8, two, None, two, 1 << 20, None) == -1
+    assert b"non-NULL" in lib.psf_last_error()
+    assert lib.psf_linear_wgrad_f32(one, one, 64, 8, 300, two, None, two, 1 << 20, None) == -2
+    assert lib.psf_linear_wgrad_f32(one, one, 1 << 20, 32, 32, two, None, two, 16, None) == -2
     b = lib.psf_chord_spmm_bwd_f32
     assert b(None, one, one, two, two, 1, 8, 4, 4, 32, None, None) == -1
     assert b(one, None, one, None, two, 1, 8, 4, 4, 32, None, None) == -1     # dV needs W
