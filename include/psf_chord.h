@@ -124,7 +124,9 @@ int psf_chord_spmm_bwd_f64(const double* dZ, const double* W, const double* V, d
  *             alternate two buffers. out_steps[m] must differ from the step's input
  *             (V0 for m = 0, out_steps[m-1] after) and, with use_residual, from V0.
  *   V0 [B,N,C] or [N,C] with v0_batch_stride == 0 (then use_residual must be 0)
- * Launches M dependent kernels on `stream`; the result is out_steps[M-1].
+ * Launches M dependent kernels on `stream` — or, for short sequences, a single kernel that keeps each
+ * sequence's X in LDS across all M steps (a step buffer that a later step overwrites, as in two-buffer
+ * inference, is then not written at all). The result is out_steps[M-1].
  */
 int psf_chord_chain_fwd_f32(const float* const* W_steps, const float* V0, float* const* out_steps,
                             int32_t M, int32_t use_residual,
@@ -159,6 +161,8 @@ int psf_linear_wgrad_f32(const float* X, const float* dY, int64_t T, int32_t m, 
  *   key "fwd_wide"   : rows of >= 64 channels: 0 = one workgroup spans the whole row (default, fastest measured);
  *                      1 = 32-channel chunks on 1024-thread workgroups (256-row tiles); 2 = 32-channel chunks
  *                      on 256-thread workgroups
+ *   key "chain_fused": 1 = psf_chord_chain_fwd_f32 runs short sequences (N <= 2048, L <= 20, C % 4 == 0) as ONE
+ *                      launch with the sequence resident in LDS (default); 0 = always M per-step launches
  *   key "xcd_remap"  : 1 = keep a batch element's tiles on one XCD group (default), 0 = linear
  * psf_get_tuning returns the value (>= 0) or PSF_E_TUNING.
  */

@@ -33,21 +33,20 @@ SHAPES = {
     "genome": (16, 16384, 14, 32, True),
 }
 
+PS = {"chain_fused": 0}  # per-step launches (the shipped default fuses short sequences into one launch)
 VARIANTS = [
     ("auto", {}),
-    ("generic", {"fwd_variant": 1}),
-    ("win_r1", {"fwd_variant": 2, "fwd_rows": 1}),
-    ("win_r2", {"fwd_variant": 2, "fwd_rows": 2}),
-    ("win_r4", {"fwd_variant": 2, "fwd_rows": 4}),
-    ("win_r8", {"fwd_variant": 2, "fwd_rows": 8}),
-    ("auto_noremap", {"xcd_remap": 0}),
-    ("auto_alledge", {"fwd_split": 0}),
-    ("wide0_wholerow", {"fwd_wide": 0}),
-    ("wide1_nt1024", {"fwd_wide": 1}),
-    ("wide2_chunk256", {"fwd_wide": 2}),
-    ("wide2_chunk_r1", {"fwd_wide": 2, "fwd_rows": 1}),
+    ("fused_cc1", {"chain_cc": 1}),
+    ("per_step", {**PS}),
+    ("generic", {**PS, "fwd_variant": 1}),
+    ("win_r1", {**PS, "fwd_variant": 2, "fwd_rows": 1}),
+    ("win_r2", {**PS, "fwd_variant": 2, "fwd_rows": 2}),
+    ("noremap", {**PS, "xcd_remap": 0}),
+    ("alledge", {**PS, "fwd_split": 0}),
+    ("wide1_nt1024", {**PS, "fwd_wide": 1}),
+    ("wide2_chunk256", {**PS, "fwd_wide": 2}),
 ]
-DEFAULTS = {"fwd_variant": 0, "fwd_rows": 0, "xcd_remap": 1, "fwd_split": 1, "fwd_wide": 0}
+DEFAULTS = {"fwd_variant": 0, "fwd_rows": 0, "xcd_remap": 1, "fwd_split": 1, "fwd_wide": 0, "chain_fused": 1, "chain_cc": 0}
 
 
 def set_knobs(kn):
@@ -107,7 +106,7 @@ def main():
         seen = {}
         uniq = []
         for vname, kn, desc in usable:  # drop knob settings that resolve to an identical kernel
-            key = (desc, kn.get("xcd_remap", 1))  # desc already names tile shape, NT and full/edge split
+            key = (desc, kn.get("xcd_remap", 1), kn.get("chain_fused", 1), kn.get("chain_cc", 0))  # desc names tile shape, NT, full/edge
             if key in seen:
                 continue
             seen[key] = vname

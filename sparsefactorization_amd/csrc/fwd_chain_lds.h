@@ -1,0 +1,129 @@
+// fwd_chain_lds.h — the WHOLE forward chain in one launch for short sequences, with V resident in LDS.
+//
+//     X_0 = V0;  X_{m+1}[p,:] = sum_k W_m[p,k] * X_m[(p+off_k) mod N,:]  (+ V0[p,:])     m = 0 .. M-1
+//                                                           (SyntheticExperiments/psf.py:167-188)
+//
+// The operator never mixes channels, so a workgroup that owns ONE sequence and ONE group of CC*4 channels can
+// run all M steps by itself: its slice of X_m lives in LDS (two buffers, N*CC*16 bytes each), every link — near
+// or far, any offset — is an LDS read, and the only HBM traffic is W_m (read once per step, 4-byte-aligned
+// dwordx4 row loads, prefetched one step ahead) plus whatever step results the caller wants stored. That removes
+// the per-step V / residual / output traffic (100 of 156 B per row-step at cfg2's mix) and the M-1 kernel
+// boundaries, which dominate for short sequences (per-step kernels at N <= 2048 run 6-19 us of mostly launch and
+// fill/drain). Fits N * CC <= 2048 (row, channel-group) slots, i.e. N <= 2048: the LRA ListOps / Pathfinder /
+// CIFAR-10 configurations and the synthetic tasks up to N = 2048; longer sequences use the per-step kernels.
+//
+// Thread (rs, g): channel group g < CC of rows rs + j*RSN, j < R (RSN = blockDim / CC row slots). The same thread
+// produces the same rows at every step, so the residual rows stay in registers. Summation order and arithmetic
+// are those of the per-step kernels: results are bit-identical.
+#pragma once
+
+#include "psf_common.h"
+
+namespace psf {
+
+constexpr int kChainMaxSteps = 64;
+
+struct ChainArgs {
+  const float* W[kChainMaxSteps];  // W_m [B, N, L]
+  float* out[kChainMaxSteps];      // X_{m+1} [B, N, C]; written when bit m of store_mask is set
+  const float* V0;                 // [B, N, C] or [N, C] (v0_bstride == 0)
+  uint64_t store_mask;
+  int64_t v0_bstride;
+  int32_t M, N, C, CG, chunks;     // CG = C / 4 channel groups, chunks = ceil(CG / CC) workgroups per sequence
+};
+
+template <int L>
+struct __attribute__((packed, aligned(4))) WRow {
+  float e[L];
+};
+
+// NTMAX (512 or 1024) is the launch bound: workgroups of <= 512 threads may use 256 VGPRs and run 2-4 per CU,
+// which is what overlaps one workgroup's barrier / load latency with another's arithmetic.
+template <int L, int CC, int R, bool RES, int NTMAX>
+__global__ void __launch_bounds__(NTMAX)
+chord_chain_lds_k(const ChainArgs a, const Offsets offs) {
+  using V4 = Vec<float, 4>;
+  // LDS is addressed as ONE array of 16-byte vectors with a buffer offset (0 / slots) per step: a true vector
+  // type and a single base keep the accesses ds_read_b128 / ds_write_b128 (two swapped pointers made hipcc fall
+  // back to ds_read2_b32 pairs, 4-way bank-conflicted at a 16-byte lane stride).
+  using F4 = float __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) F4 xlds[];
+  const int N = a.N, C = a.C;
+  const int slots = N * CC;
+  int cur = 0;  // buffer holding X_m; the other one receives X_{m+1}
+
+  const int tid = threadIdx.x;
+  const int g = tid & (CC - 1);
+  const int rs = tid / CC;
+  const int RSN = blockDim.x / CC;
+  const int b = blockIdx.x / a.chunks;
+  const int chunk = blockIdx.x - b * a.chunks;
+  const int cg = chunk * CC + g;
+  const bool cg_ok = cg < a.CG;
+  const int cgc = cg_ok ? cg : a.CG - 1;
+
+  int prow[R];
+  bool pok[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int p = rs + j * RSN;
+    pok[j] = p < N;
+    prow[j] = pok[j] ? p : N - 1;
+  }
+
+  // X_0 slice -> LDS (and the residual rows -> registers)
+  const float* __restrict__ V0b = a.V0 + (int64_t)b * a.v0_bstride + (int64_t)cgc * 4;
+  V4 resv[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const V4 v = ld<float, 4>(V0b + (int64_t)prow[j] * C);
+    if (pok[j]) xlds[prow[j] * CC + g] = F4{v.e[0], v.e[1], v.e[2], v.e[3]};
+    resv[j] = v;
+  }
+
+  // W rows of step 0; from then on the rows of step m+1 are requested at the START of step m (W does not depend
+  // on X), so they have a whole step — accumulate, LDS writes and the barrier — to land. 2*R*L registers, which
+  // is why R stops at 2 for 1024-thread workgroups.
+  WRow<L> w[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) w[j] = *reinterpret_cast<const WRow<L>*>(a.W[0] + ((int64_t)b * N + prow[j]) * L);
+  __syncthreads();
+
+  for (int m = 0; m < a.M; ++m) {
+    const float* __restrict__ Wn = a.W[m + 1 < a.M ? m + 1 : m];
+    WRow<L> wn[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) wn[j] = *reinterpret_cast<const WRow<L>*>(Wn + ((int64_t)b * N + prow[j]) * L);
+
+    const bool store = (a.store_mask >> m) & 1;
+    float* __restrict__ om = a.out[m];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int p = prow[j];
+      V4 acc;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc.e[i] = 0.f;
+#pragma unroll
+      for (int k = 0; k < L; ++k) {
+        int src = p + offs.v[k];
+        if (src >= N) src -= N;
+        const F4 x = xlds[cur + src * CC + g];
+        axpy_rn<float, 4>(acc, w[j].e[k], V4{{x.x, x.y, x.z, x.w}});
+      }
+      if constexpr (RES) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc.e[i] = add_rn(acc.e[i], resv[j].e[i]);
+      }
+      if (pok[j]) {
+        xlds[(slots - cur) + p * CC + g] = F4{acc.e[0], acc.e[1], acc.e[2], acc.e[3]};
+        if (store && cg_ok) st<float, 4>(om + ((int64_t)b * N + p) * C + (int64_t)cg * 4, acc);
+      }
+    }
+    __syncthreads();
+    cur = slots - cur;
+#pragma unroll
+    for (int j = 0; j < R; ++j) w[j] = wn[j];
+  }
+}
+
+}  // namespace psf

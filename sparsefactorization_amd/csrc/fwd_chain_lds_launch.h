@@ -1,0 +1,28 @@
+// fwd_chain_lds_launch.h — host-side interface of the LDS-resident fused chain kernel (fwd_chain_lds.h).
+#pragma once
+
+#include "fwd_chain_lds.h"
+
+namespace psf {
+
+constexpr int kChainLdsLmin = 2, kChainLdsLmax = 20;  // compiled link counts
+// N * CC: 2 rows per thread x 1024 threads (4 rows per thread would need > 128 VGPRs at 1024 threads and spill)
+constexpr int kChainLdsMaxSlots = 2048;
+constexpr int kChainLdsMaxBytes = 2 * kChainLdsMaxSlots * 16;  // two X buffers: 64 KiB, two workgroups per CU
+
+struct ChainLdsPlan {
+  int cc;       // channel groups (of 4 channels) per workgroup: 1 or 2
+  int rows;     // rows per thread: 1 or 2
+  int threads;  // workgroup size (multiple of 64, <= 1024)
+  int chunks;   // workgroups per sequence
+  int lds_bytes;
+};
+
+// false when the shape does not fit the kernel (N * cc > 4096, L outside 2..20, C not a multiple of 4, ...)
+// cc_pref: 0 = automatic (2 channel groups per workgroup when the row count allows), 1 = force one
+bool plan_chain_lds(int64_t N, int64_t C, int32_t L, int32_t M, ChainLdsPlan* plan, int cc_pref = 0);
+
+hipError_t launch_chain_lds(const ChainLdsPlan& plan, int L, bool res, const ChainArgs& args, const Offsets& offs,
+                            int B, hipStream_t stream);
+
+}  // namespace psf

@@ -11,6 +11,7 @@
 
 #include "bwd_kernels.h"
 #include "bwd_window_launch.h"
+#include "fwd_chain_lds_launch.h"
 #include "fwd_kernels.h"
 #include "fwd_window_launch.h"
 
@@ -42,6 +43,8 @@ std::atomic<int> g_xcd_remap{1};
 std::atomic<int> g_fwd_rows{0};     // 0 = default, else rows per thread (R) of the window kernel
 std::atomic<int> g_fwd_split{1};    // 1 = full tiles on the predicate-free kernel + ragged tiles separately
 std::atomic<int> g_bwd_rows{0};     // 0 = default, else rows per thread (R) of the backward window kernels
+std::atomic<int> g_chain_fused{1};  // 1 = short sequences run the whole chain in one LDS-resident launch
+std::atomic<int> g_chain_cc{0};     // fused chain: 0 = auto channel groups per workgroup, 1 = one
 // Rows of >= 64 channels: 0 = one workgroup spans the whole row (default); 1 = 32-channel chunks on 1024-thread
 // workgroups (256-row tiles, far links 6 -> 2 at L=12); 2 = 32-channel chunks on 256-thread workgroups.
 // r01 sweep (us/launch): cfg3 C=128: 18.9 / 23.2 / 21.8; attention map C=1024: 19.2 / 20.5 / 20.9; C=64: 10.2 / 9.4 /
@@ -57,6 +60,8 @@ Knob g_knobs[] = {
     {"fwd_variant", &g_fwd_variant, 0, 2}, {"bwd_variant", &g_bwd_variant, 0, 1}, {"xcd_remap", &g_xcd_remap, 0, 1},
     {"fwd_rows", &g_fwd_rows, 0, 8},       {"fwd_split", &g_fwd_split, 0, 1},     {"bwd_rows", &g_bwd_rows, 0, 8},
     {"fwd_wide", &g_fwd_wide, 0, 2},
+    {"chain_fused", &g_chain_fused, 0, 1},
+    {"chain_cc", &g_chain_cc, 0, 1},
 };
 
 int ceil_log2(int64_t x) {
@@ -387,7 +392,46 @@ int chain_impl(const T* const* W_steps, const T* V0, T* const* out_steps, int32_
   for (int m = 0; m < M; ++m) {
     if (!W_steps[m] || !out_steps[m]) return fail(PSF_E_NULL, "step %d: NULL pointer", m);
     if (use_residual && out_steps[m] == V0) return fail(PSF_E_ALIAS, "step %d: out aliases the residual V0", m);
+    if (out_steps[m] == (m == 0 ? V0 : out_steps[m - 1]))
+      return fail(PSF_E_ALIAS, "step %d: out aliases the step's input", m);
   }
+
+  if constexpr (sizeof(T) == 4) {
+    // Short sequences: the whole chain in ONE launch with the sequence's X slice resident in LDS.
+    ChainLdsPlan plan;
+    bool ok = g_chain_fused.load() && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, g_chain_cc.load()) &&
+              aligned_to(V0, 16) && B * (int64_t)plan.chunks <= 0x7fffffff;
+    for (int m = 0; ok && m < M; ++m) ok = aligned_to(W_steps[m], 4) && aligned_to(out_steps[m], 16);
+    if (ok) {
+      if (int rc = check_dims(B, N, L, C, v0_batch_stride)) return rc;
+      ChainArgs a;
+      a.store_mask = 0;
+      for (int m = 0; m < M; ++m) {
+        a.W[m] = W_steps[m];
+        a.out[m] = out_steps[m];
+        bool later = false;  // a buffer that a later step overwrites (inference ping-pong) need not be stored
+        for (int q = m + 1; q < M; ++q) later = later || out_steps[q] == out_steps[m];
+        if (!later) a.store_mask |= (uint64_t)1 << m;
+      }
+      for (int m = M; m < kChainMaxSteps; ++m) {
+        a.W[m] = nullptr;
+        a.out[m] = nullptr;
+      }
+      a.V0 = V0;
+      a.v0_bstride = v0_batch_stride;
+      a.M = M;
+      a.N = (int32_t)N;
+      a.C = (int32_t)C;
+      a.CG = (int32_t)(C / 4);
+      a.chunks = plan.chunks;
+      Offsets offs;
+      make_offsets(N, L, offsets, &offs);
+      hipError_t e = launch_chain_lds(plan, L, use_residual != 0, a, offs, (int)B, reinterpret_cast<hipStream_t>(stream));
+      if (e != hipSuccess) return fail_hip(e, "chord_chain_lds launch");
+      return PSF_OK;
+    }
+  }
+
   for (int m = 0; m < M; ++m) {
     const T* in = m == 0 ? V0 : out_steps[m - 1];
     const int64_t stride = m == 0 ? v0_batch_stride : N * C;

@@ -343,6 +343,55 @@ def test_chain_gradients_against_reference_autograd(gpu, fixture):
     assert rel_inf(V02.grad.cpu().numpy(), g["dV0"]) <= TOL
 
 
+CHAIN_SHAPES = [  # (B, N, M, L, C, residual)
+    (40, 128, 7, 8, 8, True), (3, 2000, 11, 12, 16, False), (2, 1024, 11, 12, 32, True), (2, 2048, 5, 12, 8, True),
+    (5, 777, 4, 9, 12, True), (1, 64, 3, 7, 4, False), (2, 1500, 6, 20, 8, True), (2, 300, 9, 3, 24, False),
+    (3, 1025, 2, 11, 8, True), (2, 2049, 3, 12, 8, True), (1, 100, 12, 9, 260, True),
+]
+
+
+@pytest.mark.parametrize("B,N,M,L,C,residual", CHAIN_SHAPES)
+def test_fused_lds_chain_matches_oracle_and_per_step(gpu, B, N, M, L, C, residual):
+    """The one-launch LDS-resident chain (N*CC <= 2048) against the oracle, bit for bit, in both storage modes:
+    every step kept (training) and two ping-pong buffers (inference); also equal to the per-step kernels."""
+    import sparsefactorization_amd as sfa
+    W = _mk((M, B, N, L), 61, 0.4)
+    V0 = _mk((B, N, C), 62)
+    rows, cols = oc.chord_indices(N, L)
+    want = oc.chain(np.stack([rows, cols]), W, V0, residual)  # [M, B, N, C]
+    Ws = [_t(W[m], gpu) for m in range(M)]
+    got = {}
+    for fused in (1, 0):
+        sfa.set_tuning("chain_fused", fused)
+        try:
+            with torch.no_grad():
+                got[fused] = sfa.chord_chain(Ws, _t(V0, gpu), residual).cpu().numpy()       # ping-pong storage
+            Wg = [w.clone().requires_grad_(True) for w in Ws]
+            out = sfa.chord_chain(Wg, _t(V0, gpu), residual)                                # every step stored
+            steps = [t for t in out.grad_fn.saved_tensors][1 + M:]
+            for m, t in enumerate(steps):
+                assert np.array_equal(t.cpu().numpy(), want[m]), f"fused={fused} stored step {m}"
+            assert np.array_equal(out.detach().cpu().numpy(), want[-1])
+        finally:
+            sfa.set_tuning("chain_fused", 1)
+    assert np.array_equal(got[1], want[-1])
+    assert np.array_equal(got[0], want[-1])
+
+
+def test_fused_lds_chain_custom_offsets_and_broadcast(gpu):
+    import sparsefactorization_amd as sfa
+    B, N, M, L = 3, 256, 4, 6
+    W = _mk((M, B, N, L), 63, 0.5)
+    off = [0, 5, 255, 300, -1, 128]
+    eye = np.eye(N, dtype=np.float32)
+    Ws = [_t(W[m], gpu) for m in range(M)]
+    got = sfa.chord_chain(Ws, _t(eye, gpu), False, offsets=off).cpu().numpy()
+    X = np.broadcast_to(eye, (B, N, N)).copy()
+    for m in range(M):
+        X = oc.spmul_fwd(W[m], X, off)
+    assert np.array_equal(got, X)
+
+
 def test_attention_map_against_fixture(gpu):
     """W_M ... W_1 on eye(N): C = N = 1024, unbatched first operand (cfg4)."""
     import sparsefactorization_amd as sfa
