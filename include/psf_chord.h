@@ -151,6 +151,23 @@ int psf_linear_wgrad_f32(const float* X, const float* dY, int64_t T, int32_t m, 
                          void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * Producer side, forward (inference): K two-layer token-wise MLPs sharing one input, fused in one launch —
+ * g and fs[0..M) of PSFNet (MLPBlock = Linear, GELU, Linear; SyntheticExperiments/psf.py:35-60,110-126,165,175):
+ *     Y[k][t,:] = GELU(X[t,:] * A[k]^T + a[k]) * B[k]^T + b[k]          (erf GELU as torch.nn.GELU(); erf is
+ *                                                                          evaluated to 1.5e-7 absolute)
+ *   X [T,E]; A[k] [h[k],E], a[k] [h[k]], B[k] [O[k],h[k]], b[k] [O[k]] (nn.Linear layouts); Y[k] [T,O[k]].
+ *   A, a, B, b, Y, h, O are HOST tables of K entries (device pointers / sizes).
+ *   Limits: E a multiple of 4, 4 <= E <= 64; 1 <= h[k] <= 128; 1 <= O[k] <= 32; 1 <= K <= 32; X 16-byte aligned.
+ *   `workspace`: caller-owned, 16-byte-aligned device scratch of at least psf_mlp_fwd_workspace(E, K, h, O)
+ *   bytes (the packed weight images; that function returns -1 for unsupported sizes).
+ * X is read once, the hidden activations never reach memory; f32 throughout (f32 matrix core).
+ */
+int64_t psf_mlp_fwd_workspace(int32_t E, int32_t K, const int32_t* h, const int32_t* O);
+int psf_mlp_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float* const* A, const float* const* a,
+                    const float* const* B, const float* const* b, const int32_t* h, const int32_t* O,
+                    float* const* Y, void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * Process-wide tuning knobs (benchmark / test use; defaults are the shipped configuration).
  *   key "fwd_variant": 0 = auto, 1 = generic direct-gather kernel, 2 = LDS-window kernel
  *   key "bwd_variant": 0 = auto (LDS-window dV / dW kernels where they apply), 1 = generic kernels

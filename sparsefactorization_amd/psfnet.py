@@ -30,6 +30,7 @@ from typing import List, Sequence, Union
 import torch
 from torch import nn
 
+from . import fused_mlp
 from .chord import chord_chain, chord_spmm, get_chord_indices_assym
 from .token_linear import TokenEmbedding, TokenLinear
 
@@ -65,6 +66,15 @@ class MLPBlock(nn.Module):
         return self.network(data)
 
 
+def _flat_head(final: nn.Module, flat: torch.Tensor) -> torch.Tensor:
+    """``final(flat)`` for the FLATTEN head. With one output (Adding: Linear(N*C -> 1), psf.py:129-134) the GEMM
+    degenerates to [B, N*C] x [N*C, 1], for which the library picks a 0.57 ms kernel at N*C = 131072, B = 64
+    (profiles/r01_e2e_forward_split.log); the same product as a matrix-vector op reads the 34 MB once."""
+    if isinstance(final, nn.Linear) and final.out_features == 1 and final.bias is not None and flat.is_cuda:
+        return torch.addmv(final.bias, flat, final.weight[0]).unsqueeze(1)
+    return final(flat)
+
+
 class _ChordMixer(nn.Module):
     """Shared machinery: the f/g networks and the chain V <- W_m V (+ V_0)."""
 
@@ -95,7 +105,21 @@ class _ChordMixer(nn.Module):
 
     def link_weights(self, data: torch.Tensor) -> List[torch.Tensor]:
         """W_m = fs[m](data), each [B, N, L] (psf.py:175)."""
+        if fused_mlp.eligible(data, list(self.fs)):
+            return fused_mlp.fused_mlp_forward(data, list(self.fs))
         return [f(data) for f in self.fs]
+
+    def produce(self, data: torch.Tensor):
+        """(V, [W_m]) = (g(data), [fs[m](data)]) — psf.py:165,175. Without gradients (eval / no_grad) all M+1
+        MLPs run as ONE fused launch from one read of ``data`` (fused_mlp.py); otherwise the PyTorch layers.
+        Returns links = None when the chain is not fused (each W_m is then produced right before its step)."""
+        if not self.fused_chain:
+            return self.g(data), None
+        blocks = [self.g] + list(self.fs)
+        if fused_mlp.eligible(data, blocks):
+            outs = fused_mlp.fused_mlp_forward(data, blocks)
+            return outs[0], outs[1:]
+        return self.g(data), self.link_weights(data)
 
     def mix(self, data: torch.Tensor, V: torch.Tensor, use_residuals: bool, links=None) -> torch.Tensor:
         """The hot loop of PSFNet.forward (SyntheticExperiments/psf.py:167-188). ``links`` may carry
@@ -148,9 +172,9 @@ class SyntheticPSFNet(_ChordMixer):
             data = self.init_linear(data)
         if self.use_pos_embedding:
             data = data + self.pos_embedding.weight.unsqueeze(0)  # == pos_embedding(arange(n_vec)) per sample
-        V = self.g(data)
-        V = self.mix(data, V, self.use_residuals)
-        return self.final(V.reshape(V.size(0), -1))
+        V, links = self.produce(data)
+        V = self.mix(data, V, self.use_residuals, links)
+        return _flat_head(self.final, V.reshape(V.size(0), -1))
 
 
 class _TokenPSFNet(_ChordMixer):
@@ -211,10 +235,13 @@ class _TokenPSFNet(_ChordMixer):
         if self.use_pos_embedding:
             data = data + self.pos_embedding.weight.unsqueeze(0)
         data = self.dropout1(data)
-        V = self.dropout2(self.g(data))
-        if links is not None:
-            links.extend(self.link_weights(data))
-        V = self.mix(data, V, self.use_residuals, links)
+        V, produced = self.produce(data)
+        V = self.dropout2(V)
+        if links is not None:  # the caller wants the W_m (attention-map extraction)
+            if produced is None:
+                produced = self.link_weights(data)
+            links.extend(produced)
+        V = self.mix(data, V, self.use_residuals, produced)
         return self.dropout3(V)
 
     def pool_and_classify(self, V):
@@ -288,8 +315,8 @@ class AttentionBlockPSF(_ChordMixer):
     def forward(self, data):
         data = self.embedding(data) + self.apc_embedding.weight.unsqueeze(0)
         data = self.dropout1(data)
-        V = self.dropout2(self.g(data))
-        V = self.mix(data, V, self.use_residuals)
+        V, links = self.produce(data)
+        V = self.mix(data, self.dropout2(V), self.use_residuals, links)
         return self.dropout3(V)
 
 

@@ -67,6 +67,51 @@ def test_token_embedding_is_a_drop_in_for_nn_embedding(gpu, vocab, padding_idx):
         assert float(mine.weight.grad[padding_idx].abs().max()) == 0.0
 
 
+MLP_CASES = [  # (T, E, [(h, out), ...])
+    (64 * 1024, 32, [(32, 8)] + [(32, 15)] * 14),       # Adding/Order: g + 14 link MLPs
+    (4097 * 3, 32, [(128, 32)] + [(128, 13)] * 12),     # IMDb / Pathfinder widths
+    (1024 * 5 + 7, 16, [(16, 16)] + [(16, 11)] * 10),   # CIFAR-10 widths, ragged token count
+    (1000, 64, [(96, 32), (33, 1), (128, 20)]),         # mixed hidden widths, E = 64
+    (31, 4, [(5, 3)]),                                   # smaller than one tile
+    (2049, 8, [(7, 2), (40, 31)]),                       # E = 8, odd hidden width
+]
+
+
+@pytest.mark.parametrize("T,E,layers", MLP_CASES)
+def test_fused_mlp_forward_matches_pytorch(gpu, T, E, layers):
+    """psf_mlp_fwd_f32 vs the nn.Sequential(Linear, GELU, Linear) modules it replaces (float64 reference)."""
+    from sparsefactorization_amd import fused_mlp
+    from sparsefactorization_amd.psfnet import MLPBlock
+    torch.manual_seed(T + E)
+    blocks = [MLPBlock([h, 'GELU'], E, o).to(gpu) for h, o in layers]
+    x = torch.randn(T, E, device=gpu)
+    with torch.no_grad():
+        assert fused_mlp.eligible(x, blocks)
+        got = fused_mlp.fused_mlp_forward(x, blocks)
+        for blk, y in zip(blocks, got):
+            ref = blk.double()(x.double())
+            assert y.shape == ref.shape
+            assert rel_inf(y.cpu().numpy(), ref.cpu().numpy()) <= 1e-5
+    # with gradients enabled the PyTorch layers must be used (autograd needs their saved activations)
+    assert not fused_mlp.eligible(x, [b.float() for b in blocks])
+
+
+def test_fused_mlp_leading_dims_and_ineligible_forms(gpu):
+    from sparsefactorization_amd import fused_mlp
+    from sparsefactorization_amd.psfnet import MLPBlock
+    blk = MLPBlock([32, 'GELU'], 32, 15).to(gpu)
+    x = torch.randn(3, 500, 32, device=gpu)
+    with torch.no_grad():
+        (y,) = fused_mlp.fused_mlp_forward(x, [blk])
+        assert y.shape == (3, 500, 15)
+        assert rel_inf(y.cpu().numpy(), blk(x).cpu().numpy()) <= 1e-5
+        deep = MLPBlock([32, 'GELU', 32, 'GELU'], 32, 15).to(gpu)       # not the two-layer form
+        wide = MLPBlock([32, 'GELU'], 512, 15).to(gpu)                   # E = 512 (ListOps)
+        assert not fused_mlp.eligible(x, [deep])
+        assert not fused_mlp.eligible(torch.randn(4, 512, device=gpu), [wide])
+        assert not fused_mlp.eligible(x.cpu(), [blk])
+
+
 def test_token_linear_is_a_drop_in_for_nn_linear(gpu):
     from sparsefactorization_amd.token_linear import TokenLinear
     torch.manual_seed(0)
