@@ -54,13 +54,16 @@ def main():
             from sparsefactorization_amd import fused_mlp
             blocks = [net.g] + list(net.fs)
             t_mlp_fused = time_ms(lambda: fused_mlp.fused_mlp_forward(data, blocks)) if fused_mlp.eligible(data, blocks) else None
+            sfa.set_tuning("mlp_variant", 1)  # streaming weights (what the h = 128 networks use)
+            t_mlp_stream = time_ms(lambda: fused_mlp.fused_mlp_forward(data, blocks))
+            sfa.set_tuning("mlp_variant", 0)
             fused_mlp.enabled = False
             t_mlp_torch = time_ms(lambda: [blk(data) for blk in blocks])
             fused_mlp.enabled = True
             from sparsefactorization_amd.psfnet import _flat_head
             t_head = time_ms(lambda: _flat_head(net.final, V0.reshape(B, -1)))
         key = f"{problem}_N{n_vec}_B{B}"
-        out[key] = {"forward_ms": t_all, "producers_ms": t_prod, "embed_ms": t_embed, "mlps_fused_ms": t_mlp_fused,
+        out[key] = {"forward_ms": t_all, "producers_ms": t_prod, "embed_ms": t_embed, "mlps_fused_ms": t_mlp_fused, "mlps_fused_streaming_ms": t_mlp_stream,
                     "mlps_pytorch_ms": t_mlp_torch, "chain_ms": t_chain, "head_ms": t_head,
                     "tokens_per_s_end_to_end": B * n_vec / t_all * 1e3}
         print(key, json.dumps(out[key]), flush=True)

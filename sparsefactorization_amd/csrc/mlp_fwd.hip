@@ -30,7 +30,10 @@
 
 #include "../../include/psf_chord.h"
 
+#include <atomic>
+
 extern "C" int psf_internal_fail(int code, const char* message);
+extern std::atomic<int> psf_g_mlp_variant;  // psf_chord.hip: tuning knob "mlp_variant"
 
 namespace {
 
@@ -108,22 +111,104 @@ __global__ void __launch_bounds__(256) mlp_pack_k(const MlpArgs a, int ep) {
   }
 }
 
-// EP: E padded to 32 or 64 (columns >= E are zero on both operands). TPW: token tiles per wave.
+// One MLP on one 32-token tile: H^T = A·X^T (+a), GELU, Y^T = B·H^T (+b), transposed through the wave's scratch and
+// written as one contiguous burst. `img` is the MLP's LDS image, xr the wave's register operand of the tile.
+template <int EP>
+__device__ __forceinline__ void mlp_tile(const float* img, int hp, const float (&xr)[EP / 2], float* sw, float* __restrict__ yt,
+                                         int n_el, int O, int lane) {
+  constexpr int EH = EP / 2;  // k-steps of GEMM1
+  constexpr int SA = EP + 1;  // padded row stride of the A_k image (floats)
+  const int SB = hp + 1;      // padded row stride of the B_k image
+  const int c = lane & 31, half = lane >> 5;
+  const float* sA = img;
+  const float* sa = img + img_off_sa(EP, hp);
+  const float* sB = img + img_off_sB(EP, hp);
+  const float* sb = img + img_off_sb(EP, hp);
+  f32x16 acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc2[r] = sb[cd_row(r, half)];
+  for (int ht = 0; ht < hp; ht += 32) {
+    f32x16 acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = sa[ht + cd_row(r, half)];
+    const float* arow = sA + (ht + c) * SA + half;
+#pragma unroll
+    for (int kk = 0; kk < EH; ++kk) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * kk], xr[kk], acc1, 0, 0, 0);
+    const float* brow = sB + c * SB + ht;
+    // Order pinned with sched_barrier: GELU(r) [VALU, ~14 instructions] ; MFMA(r) ; GELU(r+1) ; ... so that the
+    // VALU work of register r+1 issues while the matrix core runs MFMA r (64 cycles, asynchronous). Left to
+    // itself hipcc evaluates all 16 GELUs and then the 16 MFMAs, and the two pipes never overlap in a wave.
+    float bw[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bw[r] = brow[cd_row(r, half)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float gv = gelu_erf(acc1[r]);
+      __builtin_amdgcn_sched_barrier(0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[r], gv, acc2, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // Y^T tile -> scratch[tok][o] (stride 33) -> one contiguous burst of n_el = rows*O floats. (Wave-private
+  // scratch: the wave's own LDS writes are ordered before its reads, no barrier needed.)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sw[c * 33 + cd_row(r, half)] = acc2[r];
+  // element e = lane + 64 i is (tok, o) = divmod(e, O): one division, then stepped by divmod(64, O)
+  const int q64 = 64 / O, r64 = 64 - q64 * O;
+  int tok = lane / O, o = lane - tok * O;
+  for (int e = lane; e < n_el; e += 64) {
+    yt[e] = sw[tok * 33 + o];
+    tok += q64;
+    o += r64;
+    if (o >= O) {
+      o -= O;
+      ++tok;
+    }
+  }
+}
+
+// X operand of one tile: lane holds X[t0 + c][2*kk + half]. A tile's 32 rows are one contiguous 32*E-float
+// burst: it is read with 16-byte loads into the wave's padded LDS scratch and the operand layout is read back from
+// there (strided 4-byte loads straight from global cost 16 instructions x 32 cache lines per tile and thrashed the
+// L1: 64 KB of rows per workgroup against a 32 KB cache).
+template <int EP>
+__device__ __forceinline__ void load_x_tile(const float* __restrict__ X, int64_t T, int E, int64_t t0, float* sw,
+                                            float (&xr)[EP / 2], int lane) {
+  constexpr int SA = EP + 1;
+  const int c = lane & 31, half = lane >> 5;
+  const int64_t rows_left = T - t0;
+  const int nflt = (int)(rows_left >= 32 ? 32 : (rows_left > 0 ? rows_left : 0)) * E;  // floats of this tile in X
+  const float* xt = X + t0 * E;
+  for (int f = 4 * lane; f < 32 * E; f += 256) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < nflt) v = *reinterpret_cast<const float4*>(xt + f);  // E % 4 == 0: a float4 never straddles rows
+    const int tok = f / E, col = f - tok * E;
+    float* s = sw + tok * SA + col;
+    s[0] = v.x;
+    s[1] = v.y;
+    s[2] = v.z;
+    s[3] = v.w;
+  }
+#pragma unroll
+  for (int kk = 0; kk < EP / 2; ++kk) {
+    const int col = 2 * kk + half;
+    xr[kk] = col < E ? sw[c * SA + col] : 0.f;
+  }
+}
+
+// Streaming variant. EP: E padded to 32 or 64 (columns >= E are zero on both operands). TPW: token tiles per wave.
+// Two image buffers: image k+1 streams in by LDS-DMA while MLP k computes; one barrier per MLP.
 template <int EP, int TPW>
 __global__ void __launch_bounds__(256)
 mlp_fwd_k(const MlpArgs a) {
-  constexpr int EH = EP / 2;  // k-steps of GEMM1
-  constexpr int SA = EP + 1;  // padded row stride of the A_k image (floats)
+  constexpr int SA = EP + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int hp = a.hp_max;
-  const int SB = hp + 1;      // padded row stride of the B_k image
   const int img = a.img_floats;
-  float* scratch = lds + 2 * img;  // [4 waves][32][33]
+  float* scratch = lds + 2 * img;  // [4 waves][32][EP+1]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int c = lane & 31, half = lane >> 5;
-  float* sw = scratch + wv * 32 * SA;  // per-wave scratch [32][EP+1] (X tile staging; Y^T transpose uses stride 33)
-  const int E = a.E;
+  float* sw = scratch + wv * 32 * SA;  // per-wave scratch (X tile staging; the Y^T transpose uses stride 33)
   const int64_t tiles = (a.T + 31) / 32;
   const int64_t tiles_per_block = 4 * TPW;
   const int img_vecs = img >> 2;
@@ -141,33 +226,12 @@ mlp_fwd_k(const MlpArgs a) {
   };
 
   for (int64_t blk = blockIdx.x; blk * tiles_per_block < tiles; blk += gridDim.x) {
-    // X operand of this wave's tiles: lane holds X[t0 + c][2*kk + half]. A tile's 32 rows are one contiguous
-    // 32*E-float burst: it is read with 16-byte loads into the wave's padded LDS scratch and the operand layout is
-    // read back from there (strided 4-byte loads straight from global cost 16 instructions x 32 cache lines per
-    // tile and thrashed the L1: 64 KB of rows per workgroup against a 32 KB cache).
-    float xr[TPW][EH];
+    float xr[TPW][EP / 2];
     int64_t t0[TPW];
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp) {
       t0[tp] = (blk * tiles_per_block + wv * TPW + tp) * 32;
-      const int64_t rows_left = a.T - t0[tp];
-      const int nflt = (int)(rows_left >= 32 ? 32 : (rows_left > 0 ? rows_left : 0)) * E;  // floats of this tile in X
-      const float* xt = a.X + t0[tp] * E;
-      for (int f = 4 * lane; f < 32 * E; f += 256) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f < nflt) v = *reinterpret_cast<const float4*>(xt + f);  // E % 4 == 0: a float4 never straddles rows
-        const int tok = f / E, col = f - tok * E;
-        float* s = sw + tok * SA + col;
-        s[0] = v.x;
-        s[1] = v.y;
-        s[2] = v.z;
-        s[3] = v.w;
-      }
-#pragma unroll
-      for (int kk = 0; kk < EH; ++kk) {
-        const int col = 2 * kk + half;
-        xr[tp][kk] = col < E ? sw[c * SA + col] : 0.f;
-      }
+      load_x_tile<EP>(a.X, a.T, a.E, t0[tp], sw, xr[tp], lane);
     }
     __syncthreads();  // the previous block's last MLP is done with both image buffers
     stage(0);
@@ -175,61 +239,73 @@ mlp_fwd_k(const MlpArgs a) {
     for (int k = 0; k < a.K; ++k) {
       __syncthreads();  // image k has landed (hipcc drains vmcnt before the barrier); MLP k-1 is finished
       if (k + 1 < a.K) stage(k + 1);  // flies during this MLP's arithmetic
-      const float* sA = lds + (k & 1) * img;
-      const float* sa = sA + img_off_sa(EP, hp);
-      const float* sB = sA + img_off_sB(EP, hp);
-      const float* sb = sA + img_off_sb(EP, hp);
+      const float* image = lds + (k & 1) * img;
       const int O = a.d[k].O;
       float* __restrict__ Yk = a.d[k].Y;
-
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp) {
         if (t0[tp] >= a.T) continue;  // wave-uniform
-        f32x16 acc2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[r] = sb[cd_row(r, half)];
-        for (int ht = 0; ht < hp; ht += 32) {
-          f32x16 acc1;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc1[r] = sa[ht + cd_row(r, half)];
-          const float* arow = sA + (ht + c) * SA + half;
-#pragma unroll
-          for (int kk = 0; kk < EH; ++kk)
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * kk], xr[tp][kk], acc1, 0, 0, 0);
-          const float* brow = sB + c * SB + ht;
-          // Order pinned with sched_barrier: GELU(r) [VALU, ~14 instructions] ; MFMA(r) ; GELU(r+1) ; ... so that the
-          // VALU work of register r+1 issues while the matrix core runs MFMA r (64 cycles, asynchronous). Left to
-          // itself hipcc evaluates all 16 GELUs and then the 16 MFMAs, and the two pipes never overlap in a wave.
-          float bw[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) bw[r] = brow[cd_row(r, half)];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float gv = gelu_erf(acc1[r]);
-            __builtin_amdgcn_sched_barrier(0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[r], gv, acc2, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        // Y^T tile -> scratch[tok][o] -> one contiguous burst of 32*O floats
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sw[c * 33 + cd_row(r, half)] = acc2[r];
-        // (wave-private scratch: the wave's own LDS writes are ordered before its reads, no barrier needed)
         const int64_t rem = a.T - t0[tp];
-        const int n_el = (int)(rem < 32 ? rem : 32) * O;
-        float* yt = Yk + t0[tp] * O;
-        for (int e = lane; e < n_el; e += 64) {
-          const int tok = e / O, o = e - tok * O;
-          yt[e] = sw[tok * 33 + o];
-        }
+        mlp_tile<EP>(image, hp, xr[tp], sw, Yk + t0[tp] * O, (int)(rem < 32 ? rem : 32) * O, O, lane);
       }
     }
   }
 }
 
+// Resident variant, for calls whose K images all fit in LDS next to the scratch (the h <= 32 networks: Adding /
+// Order / CIFAR widths): every image is staged ONCE per workgroup, then the 8 waves run free — no barrier in the
+// main loop, so waves drift apart and one wave's GELU / store phases overlap another's MFMA phases. (In the
+// streaming variant each per-MLP barrier re-synchronises the waves, and the vmcnt(0) hipcc puts before it — needed
+// for the LDS-DMA — also drains that MLP's Y stores.)
+template <int EP, int TPW>
+__global__ void __launch_bounds__(512)
+mlp_fwd_resident_k(const MlpArgs a) {
+  constexpr int SA = EP + 1;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int hp = a.hp_max;
+  const int img = a.img_floats;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float* sw = lds + a.K * img + wv * 32 * SA;
+
+  const int tot_vecs = (a.K * img) >> 2;
+  for (int v0 = 0; v0 < tot_vecs; v0 += 512) {
+    const int v = v0 + tid;
+    if (v < tot_vecs)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.images + 4 * v),
+                                       (__attribute__((address_space(3))) void*)(lds + 4 * (v0 + (tid & ~63))), 16, 0, 0);
+  }
+  __syncthreads();  // the only barrier: all images have landed
+
+  const int64_t groups = ((a.T + 31) / 32 + TPW - 1) / TPW;  // a group = TPW consecutive tiles, owned by one wave
+  const int64_t nwaves = (int64_t)gridDim.x * 8;
+  for (int64_t g = (int64_t)blockIdx.x * 8 + wv; g < groups; g += nwaves) {
+    float xr[TPW][EP / 2];
+    int64_t t0[TPW];
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+      t0[tp] = (g * TPW + tp) * 32;
+      load_x_tile<EP>(a.X, a.T, a.E, t0[tp], sw, xr[tp], lane);
+    }
+    for (int k = 0; k < a.K; ++k) {
+      const float* image = lds + k * img;
+      const int O = a.d[k].O;
+      float* __restrict__ Yk = a.d[k].Y;
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) {
+        if (t0[tp] >= a.T) continue;  // wave-uniform
+        const int64_t rem = a.T - t0[tp];
+        mlp_tile<EP>(image, hp, xr[tp], sw, Yk + t0[tp] * O, (int)(rem < 32 ? rem : 32) * O, O, lane);
+      }
+    }
+  }
+}
+
+constexpr size_t kLdsMax = 160 * 1024;
+
 struct Plan {
   int ep, tpw, hp_max, img_floats;
-  size_t lds_bytes;
+  size_t lds_bytes;           // streaming variant: two image buffers + 4 wave scratches
+  size_t lds_resident_bytes;  // resident variant: K images + 8 wave scratches (0: does not fit)
 };
 
 bool make_plan(int32_t E, int32_t K, const int32_t* h, const int32_t* O, Plan* p) {
@@ -244,6 +320,8 @@ bool make_plan(int32_t E, int32_t K, const int32_t* h, const int32_t* O, Plan* p
   p->tpw = p->ep == 32 ? 4 : 2;
   p->img_floats = img_size(p->ep, p->hp_max);
   p->lds_bytes = sizeof(float) * (2 * (size_t)p->img_floats + 4 * 32 * (size_t)(p->ep + 1));
+  p->lds_resident_bytes = sizeof(float) * ((size_t)K * p->img_floats + 8 * 32 * (size_t)(p->ep + 1));
+  if (p->lds_resident_bytes > kLdsMax) p->lds_resident_bytes = 0;
   return true;
 }
 
@@ -288,16 +366,33 @@ int psf_mlp_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
 
   const int64_t tiles = (T + 31) / 32;
-  const int64_t blocks_needed = (tiles + 4 * p.tpw - 1) / (4 * p.tpw);
-  const int grid = (int)(blocks_needed < 2048 ? blocks_needed : 2048);
-  if (p.ep == 32) {
-    if (p.lds_bytes > 48 * 1024)
-      e = hipFuncSetAttribute((const void*)mlp_fwd_k<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-    if (e == hipSuccess) hipLaunchKernelGGL((mlp_fwd_k<32, 4>), dim3(grid), dim3(256), p.lds_bytes, s, args);
+  const int variant = psf_g_mlp_variant.load();
+  if (variant == 2 && !p.lds_resident_bytes)
+    return psf_internal_fail(PSF_E_TUNING, "psf_mlp_fwd: mlp_variant=2 but the K weight images do not fit in LDS");
+  if (p.lds_resident_bytes && variant != 1) {
+    // persistent: one 8-wave workgroup per CU (LDS-bound), waves stride over groups of TPW tiles
+    const int64_t groups = (tiles + p.tpw - 1) / p.tpw;
+    const int grid = (int)((groups + 7) / 8 < 256 ? (groups + 7) / 8 : 256);
+    const int lds = (int)p.lds_resident_bytes;
+    if (p.ep == 32) {
+      e = hipFuncSetAttribute((const void*)mlp_fwd_resident_k<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess) hipLaunchKernelGGL((mlp_fwd_resident_k<32, 4>), dim3(grid), dim3(512), lds, s, args);
+    } else {
+      e = hipFuncSetAttribute((const void*)mlp_fwd_resident_k<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess) hipLaunchKernelGGL((mlp_fwd_resident_k<64, 2>), dim3(grid), dim3(512), lds, s, args);
+    }
   } else {
-    if (p.lds_bytes > 48 * 1024)
-      e = hipFuncSetAttribute((const void*)mlp_fwd_k<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-    if (e == hipSuccess) hipLaunchKernelGGL((mlp_fwd_k<64, 2>), dim3(grid), dim3(256), p.lds_bytes, s, args);
+    const int64_t blocks_needed = (tiles + 4 * p.tpw - 1) / (4 * p.tpw);
+    const int grid = (int)(blocks_needed < 2048 ? blocks_needed : 2048);
+    if (p.ep == 32) {
+      if (p.lds_bytes > 48 * 1024)
+        e = hipFuncSetAttribute((const void*)mlp_fwd_k<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+      if (e == hipSuccess) hipLaunchKernelGGL((mlp_fwd_k<32, 4>), dim3(grid), dim3(256), p.lds_bytes, s, args);
+    } else {
+      if (p.lds_bytes > 48 * 1024)
+        e = hipFuncSetAttribute((const void*)mlp_fwd_k<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+      if (e == hipSuccess) hipLaunchKernelGGL((mlp_fwd_k<64, 2>), dim3(grid), dim3(256), p.lds_bytes, s, args);
+    }
   }
   if (e == hipSuccess) e = hipGetLastError();
   return e == hipSuccess ? PSF_OK : psf_internal_fail((int)e, hipGetErrorString(e));

@@ -51,6 +51,11 @@ std::atomic<int> g_chain_cc{0};     // fused chain: 0 = auto channel groups per 
 // 10.0 — contiguous whole-row bursts beat fewer far links, so 0 stays the default.
 std::atomic<int> g_fwd_wide{0};
 
+}  // namespace
+// Fused producer MLPs (mlp_fwd.hip): 0 = auto (all images LDS-resident when they fit), 1 = streaming, 2 = resident
+std::atomic<int> psf_g_mlp_variant{0};
+namespace {
+
 struct Knob {
   const char* key;
   std::atomic<int>* var;
@@ -62,6 +67,7 @@ Knob g_knobs[] = {
     {"fwd_wide", &g_fwd_wide, 0, 2},
     {"chain_fused", &g_chain_fused, 0, 1},
     {"chain_cc", &g_chain_cc, 0, 1},
+    {"mlp_variant", &psf_g_mlp_variant, 0, 2},
 };
 
 int ceil_log2(int64_t x) {
