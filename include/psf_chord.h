@@ -168,6 +168,26 @@ int psf_mlp_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
                     float* const* Y, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * Producer side, backward (training) of the same K MLPs, fused in one pass over the tokens. What autograd does
+ * for MLPBlock (SyntheticExperiments/psf.py:35-60) with 4K GEMMs, K GELU-backward kernels and K-1 accumulations
+ * of the input gradient:
+ *     Hpre  = X * A[k]^T + a[k]            (recomputed; nothing of size [T, h] is saved by the forward)
+ *     dHpre = (dY[k] * B[k]) .* GELU'(Hpre)
+ *     dA[k] = dHpre^T * X,  da[k] = sum_t dHpre,  dB[k] = dY[k]^T * GELU(Hpre),  db[k] = sum_t dY[k]
+ *     dX    = sum_k dHpre_k * A[k]                                               (dX may be NULL: not computed)
+ *   Layouts as psf_mlp_fwd_f32; dY[k] [T,O[k]]; dA/da/dB/db[k] have the nn.Linear parameter shapes and are fully
+ *   overwritten. Limits: E a multiple of 4, 4 <= E <= 32; 1 <= h[k] <= 128; 1 <= O[k] <= 32; 1 <= K <= 32; X
+ *   16-byte aligned. `workspace`: at least psf_mlp_bwd_workspace(T, E, K, h, O) bytes, 16-byte aligned (packed
+ *   weights + per-wave partial sums; -1 for unsupported sizes).
+ * Weight gradients are reduced in a fixed order (no float atomics): results are bit-reproducible run to run.
+ */
+int64_t psf_mlp_bwd_workspace(int64_t T, int32_t E, int32_t K, const int32_t* h, const int32_t* O);
+int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float* const* A, const float* const* a,
+                    const float* const* B, const int32_t* h, const int32_t* O, const float* const* dY, float* dX,
+                    float* const* dA, float* const* da, float* const* dB, float* const* db, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+
+/*
  * Process-wide tuning knobs (benchmark / test use; defaults are the shipped configuration).
  *   key "fwd_variant": 0 = auto, 1 = generic direct-gather kernel, 2 = LDS-window kernel
  *   key "bwd_variant": 0 = auto (LDS-window dV / dW kernels where they apply), 1 = generic kernels

@@ -1,0 +1,439 @@
+// mlp_bwd.hip — fused backward of the producer MLPs (training path of mlp_fwd.hip).
+//
+//   Y_k = GELU(X · A_k^T + a_k) · B_k^T + b_k,  k < K      (MLPBlock, SyntheticExperiments/psf.py:35-60; PSFNet
+//   applies g and fs[0..M) to the same `data`, psf.py:165,175)
+//
+// Given dY_k, one launch produces dX = sum_k dHpre_k · A_k and per-wave partial sums of dA_k, da_k, dB_k, db_k; a
+// two-stage fixed-order reduction (no float atomics: bit-reproducible) finishes the weight gradients. Nothing of
+// size [T, h] ever exists in memory: the hidden layer is RECOMPUTED from X (16 MFMAs per 32-token tile), which
+// is cheaper than the 2 x [T, K*h] floats autograd would save and re-read (2.35 GB at Order N=16384, B=40).
+// Through PyTorch this backward is 4K GEMMs + K GELU-backward kernels + K-1 accumulations of dX: 4.9 ms of the
+// 8.3 ms training step (profiles/r01_train_step_profile_after.log).
+//
+// A hidden layer wider than 32 is processed as independent 32-row "units" (u = (k, ht)): Hpre, dHpost, dHpre, dA
+// and dB rows of a unit depend on no other unit; only dX (summed over all units) and db (taken from the ht = 0
+// unit) cross units.
+//
+// Per wave: TPW tiles of 32 tokens; X is held in registers in both MFMA orientations (xr: contraction over e;
+// xT: contraction over tokens), the dX^T accumulators persist over all units. Per unit and tile, on
+// v_mfma_f32_32x32x2_f32 (D[i][j] += A[i][k] B[k][j]; A-operand lane l = (i = l&31, k = l>>5), B-operand lane
+// l = (k = l>>5, j = l&31), result register r of lane l = D[(r&3) + 8(r>>2) + 4(l>>5)][l&31]):
+//   1. Hpre^T  [j x tok] = A_u · X^T + a_u                              16 MFMAs   (A from the LDS image, xr)
+//   2. dHpost^T[j x tok] = B_u^T · dY^T                                 O/2 MFMAs  (B^T from the image, dY tile via LDS)
+//   3. VALU: Phi, phi from one rcp + one exp;  Hpost = x Phi;  G = dHpost (Phi + x phi)   (G = dHpre^T)
+//   4. dB_u^T  [j x o]  += Hpost^T · dY    (contraction over tokens)    16 MFMAs   (Hpost^T re-laid through LDS)
+//   5. dA_u    [j x e]  += G · X           (contraction over tokens)    16 MFMAs   (G re-laid through LDS, xT)
+//   6. dX^T    [e x tok]+= A_u^T · G       (contraction over j)         16 MFMAs   (G's accumulator registers ARE
+//        the B operand: register r pairs rows {row(r,0), row(r,1)}; the A operand takes A_u[that row][e] from LDS)
+//   da_u, db_u: sums of the step-5 / step-4 operand registers (their k index is the token).
+// After the wave's TPW tiles the unit's 34 accumulator registers are flushed to the partial buffer.
+//
+// Limits: E <= 32 (multiple of 4), h <= 128, O <= 32, K <= 32; anything else stays on autograd.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/psf_chord.h"
+
+extern "C" int psf_internal_fail(int code, const char* message);
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kMaxMlps = 32;
+constexpr int kMaxUnits = 128;
+constexpr int kImg = 32 * 33 + 32 + 32 * 33;  // sA [32][33] | sa [32] | sB [32 o][33]  = 2144 floats
+constexpr int kOffSa = 32 * 33;
+constexpr int kOffSb = kOffSa + 32;
+constexpr int kPart = 1024 + 1024 + 64 + 64;  // per (group, unit): dA [j][e] | dB^T [j][o] | da [half][j] | db [half][o]
+constexpr int kSlices = 64;                   // stage-1 reduction slices
+constexpr int kTPW = 2;
+
+struct BwdMlp {
+  const float* A;   // [h, E]
+  const float* a;   // [h]
+  const float* B;   // [O, h]
+  const float* dY;  // [T, O]
+  float* dA;
+  float* da;
+  float* dB;
+  float* db;
+  int32_t h, O;
+};
+
+struct BwdArgs {
+  BwdMlp m[kMaxMlps];
+  uint8_t unit_k[kMaxUnits], unit_hb[kMaxUnits];  // unit -> (MLP, hidden block)
+  const float* X;
+  float* dX;        // [T, E] or nullptr
+  float* images;    // U images of kImg floats
+  float* partials;  // [G][U][kPart]
+  float* stage1;    // [kSlices][U * kPart]
+  int64_t T;
+  int64_t G;        // wave groups = partial slots
+  int32_t E, K, U;
+};
+
+__device__ __forceinline__ int cd_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// y = GELU(x) (erf form) and dy/dx = Phi(x) + x phi(x); erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7),
+// whose exp(-x^2/2) is also phi(x) sqrt(2 pi).
+__device__ __forceinline__ void gelu_and_grad(float x, float& y, float& dydx) {
+  const float s = x * 0.70710678118654752440f;
+  const float ax = fabsf(s);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-ax * ax);
+  const float erf = copysignf(fmaf(-p * t, e, 1.0f), s);
+  const float Phi = fmaf(0.5f, erf, 0.5f);
+  y = x * Phi;
+  dydx = fmaf(x * 0.39894228040143267794f, e, Phi);
+}
+
+__global__ void __launch_bounds__(256) mlp_bwd_pack_k(const BwdArgs a) {
+  const int u = blockIdx.x;
+  const BwdMlp d = a.m[a.unit_k[u]];
+  const int ht = 32 * a.unit_hb[u], E = a.E;
+  float* img = a.images + (int64_t)u * kImg;
+  for (int i = threadIdx.x; i < kImg; i += 256) {
+    float v = 0.f;
+    if (i < kOffSa) {
+      const int j = i / 33, e = i - j * 33;
+      if (ht + j < d.h && e < E) v = d.A[(ht + j) * E + e];
+    } else if (i < kOffSb) {
+      const int j = i - kOffSa;
+      if (ht + j < d.h) v = d.a[ht + j];
+    } else {
+      const int q = i - kOffSb, o = q / 33, j = q - o * 33;
+      if (o < d.O && j < 32 && ht + j < d.h) v = d.B[o * d.h + ht + j];
+    }
+    img[i] = v;
+  }
+}
+
+// Rows [t0, t0+32) of a row-major [T, W] array (W <= 32) into the wave's scratch S[tok][33]; rows >= T read as 0.
+// The tile is one contiguous burst of 32*W floats. VEC4 needs W % 4 == 0 and a 16-byte-aligned base.
+template <bool VEC4>
+__device__ __forceinline__ void tile_to_scratch(const float* __restrict__ base, int64_t T, int W, int64_t t0, float* S, int lane) {
+  const int64_t rows_left = T - t0;
+  const int n = (int)(rows_left >= 32 ? 32 : (rows_left > 0 ? rows_left : 0)) * W;
+  const float* src = base + t0 * W;
+  if (VEC4) {
+    for (int f = 4 * lane; f < 32 * W; f += 256) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < n) v = *reinterpret_cast<const float4*>(src + f);
+      const int tok = f / W, col = f - tok * W;
+      float* s = S + tok * 33 + col;
+      s[0] = v.x;
+      s[1] = v.y;
+      s[2] = v.z;
+      s[3] = v.w;
+    }
+  } else {
+    const int q64 = 64 / W, r64 = 64 - q64 * W;
+    int tok = lane / W, col = lane - tok * W;
+    for (int f = lane; f < 32 * W; f += 64) {
+      S[tok * 33 + col] = f < n ? src[f] : 0.f;
+      tok += q64;
+      col += r64;
+      if (col >= W) {
+        col -= W;
+        ++tok;
+      }
+    }
+  }
+}
+
+template <int TPW>
+__global__ void __launch_bounds__(256)
+mlp_bwd_k(const BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int c = lane & 31, half = lane >> 5;
+  float* S1 = lds + 2 * kImg + wv * (2 * 32 * 33);  // tile staging: X at group start, then the dY tile
+  float* S2 = S1 + 32 * 33;                         // re-layout of Hpost^T / G
+  const int E = a.E, U = a.U;
+  const int64_t tiles = (a.T + 31) / 32;
+  const int64_t tiles_per_block = 4 * TPW;
+  constexpr int img_vecs = kImg / 4;
+
+  auto stage = [&](int u) {
+    const float* src = a.images + (int64_t)u * kImg;
+    float* dst = lds + (u & 1) * kImg;
+    for (int v0 = 0; v0 < img_vecs; v0 += 256) {
+      const int v = v0 + tid;
+      if (v < img_vecs)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * v),
+                                         (__attribute__((address_space(3))) void*)(dst + 4 * (v0 + (tid & ~63))), 16, 0, 0);
+    }
+  };
+
+  for (int64_t blk = blockIdx.x; blk * tiles_per_block < tiles; blk += gridDim.x) {
+    float xr[TPW][16], xT[TPW][16];
+    f32x16 dxa[TPW];
+    int64_t t0[TPW];
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+      t0[tp] = (blk * tiles_per_block + wv * TPW + tp) * 32;
+      tile_to_scratch<true>(a.X, a.T, E, t0[tp], S1, lane);
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int q = 2 * kk + half;
+        xr[tp][kk] = q < E ? S1[c * 33 + q] : 0.f;   // X[tok = c][e = q]
+        xT[tp][kk] = c < E ? S1[q * 33 + c] : 0.f;   // X[tok = q][e = c]
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dxa[tp][r] = 0.f;
+    }
+    float* part = a.partials + ((blk * 4 + wv) * (int64_t)U) * kPart;
+    __syncthreads();  // the previous block's last unit is done with both image buffers
+    stage(0);
+
+    for (int u = 0; u < U; ++u) {
+      __syncthreads();  // image u has landed (hipcc drains vmcnt before the barrier); unit u-1 is finished
+      if (u + 1 < U) stage(u + 1);
+      const float* sA = lds + (u & 1) * kImg;
+      const float* sa = sA + kOffSa;
+      const float* sB = sA + kOffSb;
+      const BwdMlp& d = a.m[a.unit_k[u]];
+      const int O = d.O;
+      const float* __restrict__ dY = d.dY;
+
+      f32x16 dA, dBT;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dA[r] = dBT[r] = 0.f;
+      float da = 0.f, db = 0.f;
+
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) {
+        if (t0[tp] >= a.T) continue;  // wave-uniform
+        tile_to_scratch<false>(dY, a.T, O, t0[tp], S1, lane);
+        // 1. Hpre^T
+        f32x16 acc1, acc3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc1[r] = sa[cd_row(r, half)];
+          acc3[r] = 0.f;
+        }
+        const float* arow = sA + c * 33 + half;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * kk], xr[tp][kk], acc1, 0, 0, 0);
+        // 2. dHpost^T: A operand B[o = 2kk+half][j = c], B operand dY[tok = c][o = 2kk+half]
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          if (2 * kk >= O) break;  // wave-uniform
+          const int o = 2 * kk + half;
+          const float dyv = o < O ? S1[c * 33 + o] : 0.f;
+          acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(sB[o * 33 + c], dyv, acc3, 0, 0, 0);
+        }
+        // 3. GELU and its derivative; Hpost^T -> S2[j][tok]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float y, dy;
+          gelu_and_grad(acc1[r], y, dy);
+          S2[cd_row(r, half) * 33 + c] = y;
+          acc3[r] *= dy;  // G = dHpre^T
+        }
+        // 4. dB^T += Hpost^T[j = c][tok = 2kk+half] · dY[tok = 2kk+half][o = c]
+        {
+          float dbs = 0.f;
+#pragma unroll
+          for (int kk = 0; kk < 16; ++kk) {
+            const int q = 2 * kk + half;
+            const float dyt = c < O ? S1[q * 33 + c] : 0.f;
+            dbs += dyt;
+            dBT = __builtin_amdgcn_mfma_f32_32x32x2f32(S2[c * 33 + q], dyt, dBT, 0, 0, 0);
+          }
+          db += dbs;
+        }
+        // 5. dA += G[j = c][tok = 2kk+half] · X[tok = 2kk+half][e = c]   (G re-laid through S2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 33 + c] = acc3[r];
+        {
+          float das = 0.f;
+#pragma unroll
+          for (int kk = 0; kk < 16; ++kk) {
+            const float gt = S2[c * 33 + 2 * kk + half];
+            das += gt;
+            dA = __builtin_amdgcn_mfma_f32_32x32x2f32(gt, xT[tp][kk], dA, 0, 0, 0);
+          }
+          da += das;
+        }
+        // 6. dX^T += A_u^T · G: k-step r pairs hidden rows {row(r,0), row(r,1)}
+        if (a.dX) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            dxa[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[cd_row(r, half) * 33 + c], acc3[r], dxa[tp], 0, 0, 0);
+        }
+      }
+      // flush the unit's partial sums (coalesced: for fixed r the 64 lanes write two 128-byte rows)
+      float* pu = part + (int64_t)u * kPart;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pu[cd_row(r, half) * 32 + c] = dA[r];
+        pu[1024 + cd_row(r, half) * 32 + c] = dBT[r];
+      }
+      pu[2048 + lane] = da;
+      pu[2112 + lane] = db;
+    }
+
+    if (a.dX) {
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) {
+        if (t0[tp] >= a.T) continue;
+        // dX^T tile -> S2[tok][e] -> one contiguous burst
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S2[c * 33 + cd_row(r, half)] = dxa[tp][r];
+        const int64_t rem = a.T - t0[tp];
+        const int n_el = (int)(rem < 32 ? rem : 32) * E;
+        float* xt = a.dX + t0[tp] * E;
+        const int q64 = 64 / E, r64 = 64 - q64 * E;
+        int tok = lane / E, e = lane - tok * E;
+        for (int f = lane; f < n_el; f += 64) {
+          xt[f] = S2[tok * 33 + e];
+          tok += q64;
+          e += r64;
+          if (e >= E) {
+            e -= E;
+            ++tok;
+          }
+        }
+      }
+    }
+  }
+}
+
+// stage 1: R1[s][i] = sum over the groups of slice s of P[g][i]   (i < U*kPart; fixed order)
+__global__ void __launch_bounds__(256) mlp_bwd_reduce1_k(const BwdArgs a) {
+  const int64_t n = (int64_t)a.U * kPart;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int s = blockIdx.y;
+  const int64_t per = (a.G + kSlices - 1) / kSlices;
+  const int64_t g0 = s * per, g1 = g0 + per < a.G ? g0 + per : a.G;
+  float acc = 0.f;
+  for (int64_t g = g0; g < g1; ++g) acc += a.partials[g * n + i];
+  a.stage1[s * n + i] = acc;
+}
+
+// stage 2: sum the slices and scatter into the unpadded gradient tensors
+__global__ void __launch_bounds__(256) mlp_bwd_reduce2_k(const BwdArgs a) {
+  const int64_t n = (int64_t)a.U * kPart;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const int u = (int)(idx / kPart), i = (int)(idx - (int64_t)u * kPart);
+  const BwdMlp& d = a.m[a.unit_k[u]];
+  const int ht = 32 * a.unit_hb[u], E = a.E;
+  auto total = [&](int64_t at) {
+    float acc = 0.f;
+    for (int s = 0; s < kSlices; ++s) acc += a.stage1[s * n + at];
+    return acc;
+  };
+  if (i < 1024) {
+    const int j = i >> 5, e = i & 31;
+    if (ht + j < d.h && e < E) d.dA[(ht + j) * E + e] = total(idx);
+  } else if (i < 2048) {
+    const int j = (i - 1024) >> 5, o = i & 31;
+    if (ht + j < d.h && o < d.O) d.dB[o * d.h + ht + j] = total(idx);
+  } else if (i < 2048 + 32) {
+    const int j = i - 2048;
+    if (ht + j < d.h) d.da[ht + j] = total(idx) + total(idx + 32);
+  } else if (i >= 2112 && i < 2112 + 32) {
+    const int o = i - 2112;
+    if (ht == 0 && o < d.O) d.db[o] = total(idx) + total(idx + 32);
+  }
+}
+
+struct Plan {
+  int U;
+  int64_t G;
+  uint8_t unit_k[kMaxUnits], unit_hb[kMaxUnits];
+};
+
+bool make_plan(int64_t T, int32_t E, int32_t K, const int32_t* h, const int32_t* O, Plan* p) {
+  if (T < 1 || E < 4 || E > 32 || (E & 3) || K < 1 || K > kMaxMlps || !h || !O) return false;
+  p->U = 0;
+  for (int k = 0; k < K; ++k) {
+    if (h[k] < 1 || h[k] > 128 || O[k] < 1 || O[k] > 32) return false;
+    for (int hb = 0; hb * 32 < h[k]; ++hb) {
+      p->unit_k[p->U] = (uint8_t)k;
+      p->unit_hb[p->U] = (uint8_t)hb;
+      ++p->U;
+    }
+  }
+  const int64_t tiles = (T + 31) / 32;
+  p->G = 4 * ((tiles + 4 * kTPW - 1) / (4 * kTPW));
+  return true;
+}
+
+int64_t workspace_floats(const Plan& p) {
+  return (int64_t)p.U * kImg + p.G * p.U * kPart + (int64_t)kSlices * p.U * kPart;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t psf_mlp_bwd_workspace(int64_t T, int32_t E, int32_t K, const int32_t* h, const int32_t* O) {
+  Plan p;
+  if (!make_plan(T, E, K, h, O, &p)) return -1;
+  return workspace_floats(p) * (int64_t)sizeof(float);
+}
+
+int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float* const* A, const float* const* a,
+                    const float* const* B, const int32_t* h, const int32_t* O, const float* const* dY, float* dX,
+                    float* const* dA, float* const* da, float* const* dB, float* const* db, void* workspace,
+                    int64_t workspace_bytes, void* stream) {
+  if (!X || !A || !a || !B || !h || !O || !dY || !dA || !da || !dB || !db || !workspace)
+    return psf_internal_fail(PSF_E_NULL, "psf_mlp_bwd: NULL argument");
+  Plan p;
+  if (!make_plan(T, E, K, h, O, &p))
+    return psf_internal_fail(PSF_E_SHAPE, "psf_mlp_bwd: need T >= 1, E in {4,8,...,32}, 1 <= K <= 32, 1 <= h <= 128, 1 <= O <= 32");
+  if ((reinterpret_cast<uintptr_t>(X) & 15) != 0) return psf_internal_fail(PSF_E_ALIGN, "psf_mlp_bwd: X must be 16-byte aligned");
+  if (workspace_bytes < workspace_floats(p) * (int64_t)sizeof(float) || (reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
+    return psf_internal_fail(PSF_E_SHAPE, "psf_mlp_bwd: workspace too small (psf_mlp_bwd_workspace) or not 16-byte aligned");
+  BwdArgs args;
+  for (int k = 0; k < kMaxMlps; ++k) args.m[k] = BwdMlp{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+  for (int k = 0; k < K; ++k) {
+    if (!A[k] || !a[k] || !B[k] || !dY[k] || !dA[k] || !da[k] || !dB[k] || !db[k])
+      return psf_internal_fail(PSF_E_NULL, "psf_mlp_bwd: NULL layer pointer");
+    args.m[k] = BwdMlp{A[k], a[k], B[k], dY[k], dA[k], da[k], dB[k], db[k], h[k], O[k]};
+  }
+  for (int u = 0; u < kMaxUnits; ++u) {
+    args.unit_k[u] = u < p.U ? p.unit_k[u] : 0;
+    args.unit_hb[u] = u < p.U ? p.unit_hb[u] : 0;
+  }
+  float* ws = reinterpret_cast<float*>(workspace);
+  args.X = X;
+  args.dX = dX;
+  args.images = ws;
+  args.partials = ws + (int64_t)p.U * kImg;
+  args.stage1 = args.partials + p.G * p.U * kPart;
+  args.T = T;
+  args.G = p.G;
+  args.E = E;
+  args.K = K;
+  args.U = p.U;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(mlp_bwd_pack_k, dim3(p.U), dim3(256), 0, s, args);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
+
+  // every (block, wave) slot of the partial buffer is written exactly once: one block per 4*TPW tiles
+  const int64_t blocks = p.G / 4;
+  if (blocks > 0x7fffffff) return psf_internal_fail(PSF_E_SHAPE, "psf_mlp_bwd: T too large");
+  const size_t lds_bytes = sizeof(float) * (2 * (size_t)kImg + 4 * 2 * 32 * 33);
+  hipLaunchKernelGGL((mlp_bwd_k<kTPW>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, args);
+  e = hipGetLastError();
+  if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
+  const int64_t n = (int64_t)p.U * kPart;
+  hipLaunchKernelGGL(mlp_bwd_reduce1_k, dim3((unsigned)((n + 255) / 256), kSlices), dim3(256), 0, s, args);
+  hipLaunchKernelGGL(mlp_bwd_reduce2_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, args);
+  e = hipGetLastError();
+  return e == hipSuccess ? PSF_OK : psf_internal_fail((int)e, hipGetErrorString(e));
+}
+
+}  // extern "C"

@@ -1,12 +1,16 @@
-"""Fused forward of PSFNet's producer MLPs (``g`` and ``fs[0..M)``) — inference path.
+"""Fused PSFNet producer MLPs (``g`` and ``fs[0..M)``) — forward and backward in one launch each.
 
 ``MLPBlock`` is ``Linear(E, h) -> GELU -> Linear(h, out)`` (SyntheticExperiments/psf.py:35-60); PSFNet applies
-M+1 of them to the same ``data`` (psf.py:165,175). ``psf_mlp_fwd_f32`` (csrc/mlp_fwd.hip) evaluates all of them
-in one launch from one read of ``data`` on the f32 matrix core, the hidden layer staying in registers.
+M+1 of them to the same ``data`` (psf.py:165,175).
 
-Used only when nothing needs a gradient (eval / ``torch.no_grad()``): training keeps the PyTorch layers so that
-autograd has its saved activations (their weight gradients run on ``psf_linear_wgrad_f32``, token_linear.py).
-MLPs of another form, fp64, E > 64, h > 128, out > 32 or CPU tensors use the stock modules.
+* ``psf_mlp_fwd_f32`` (csrc/mlp_fwd.hip) evaluates all of them from one read of ``data`` on the f32 matrix
+  core, the hidden layer staying in registers.
+* ``psf_mlp_bwd_f32`` (csrc/mlp_bwd.hip) is their backward: the hidden layer is recomputed, dX is accumulated
+  over all MLPs in registers, weight gradients are reduced in a fixed order. The forward therefore saves only
+  ``data`` and the parameters (autograd through the PyTorch layers keeps 2 x [T, (M+1) h] activations).
+
+``eligible`` (no gradient needed) / ``trainable`` (gradient needed) say whether a call can take these kernels;
+MLPs of another form, fp64, E > 64 (E > 32 when training), h > 128, out > 32 or CPU tensors use the stock modules.
 """
 from __future__ import annotations
 
@@ -18,8 +22,11 @@ from torch import nn
 
 from . import _lib
 
-MAX_E, MAX_H, MAX_O, MAX_K = 64, 128, 32, 32
-enabled = True  # module-level switch (tests / A-B timing)
+MAX_E, MAX_E_TRAIN, MAX_H, MAX_O, MAX_K = 64, 32, 128, 32, 32
+enabled = True        # module-level switches (tests / A-B timing)
+train_enabled = True
+
+_vp = ctypes.c_void_p
 
 
 def _two_layer(block: nn.Module) -> Optional[tuple]:
@@ -35,13 +42,15 @@ def _two_layer(block: nn.Module) -> Optional[tuple]:
     return l1, l2
 
 
-def eligible(x: torch.Tensor, blocks: Sequence[nn.Module]) -> bool:
-    if not enabled or torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for b in blocks for p in b.parameters())):
-        return False
-    if not x.is_cuda or x.dtype != torch.float32 or x.dim() < 2:
+def _needs_grad(x: torch.Tensor, blocks: Sequence[nn.Module]) -> bool:
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for b in blocks for p in b.parameters()))
+
+
+def _shapes_ok(x: torch.Tensor, blocks: Sequence[nn.Module], max_e: int) -> bool:
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() < 2 or not len(blocks):
         return False
     E = x.shape[-1]
-    if E < 4 or E > MAX_E or E % 4:
+    if E < 4 or E > max_e or E % 4:
         return False
     for b in blocks:
         pair = _two_layer(b)
@@ -53,36 +62,107 @@ def eligible(x: torch.Tensor, blocks: Sequence[nn.Module]) -> bool:
     return True
 
 
-def fused_mlp_forward(x: torch.Tensor, blocks: Sequence[nn.Module]) -> List[torch.Tensor]:
-    """[block(x) for block in blocks], computed by the fused kernel. Caller checks ``eligible`` first."""
-    lead = x.shape[:-1]
-    E = x.shape[-1]
-    x2 = x.reshape(-1, E).contiguous()
-    T = x2.shape[0]
-    outs: List[torch.Tensor] = []
+def eligible(x: torch.Tensor, blocks: Sequence[nn.Module]) -> bool:
+    """Inference: the fused forward can replace ``[b(x) for b in blocks]`` and nothing needs a gradient."""
+    return enabled and not _needs_grad(x, blocks) and _shapes_ok(x, blocks, MAX_E)
+
+
+def trainable(x: torch.Tensor, blocks: Sequence[nn.Module]) -> bool:
+    """Training: fused forward + fused backward (``fused_mlp_apply``) can replace the PyTorch layers."""
+    return enabled and train_enabled and _needs_grad(x, blocks) and len(blocks) <= MAX_K and _shapes_ok(x, blocks, MAX_E_TRAIN)
+
+
+def _ptrs(tensors: Sequence[torch.Tensor]):
+    return (_vp * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _forward_raw(x2: torch.Tensor, params: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """x2 [T, E] contiguous; params = (A0, a0, B0, b0, A1, ...) contiguous fp32. One launch per <= MAX_K MLPs."""
+    T, E = x2.shape
+    dev = x2.device
     lib = _lib.load()
-    dev = x.device
-    for start in range(0, len(blocks), MAX_K):
-        group = blocks[start:start + MAX_K]
-        K = len(group)
-        pairs = [_two_layer(b) for b in group]
-        ys = [torch.empty((T, l2.out_features), dtype=torch.float32, device=dev) for _, l2 in pairs]
-        keep = [t.detach().contiguous() for l1, l2 in pairs for t in (l1.weight, l1.bias, l2.weight, l2.bias)]
-        vp = ctypes.c_void_p
-        A = (vp * K)(*[keep[4 * k].data_ptr() for k in range(K)])
-        a = (vp * K)(*[keep[4 * k + 1].data_ptr() for k in range(K)])
-        B = (vp * K)(*[keep[4 * k + 2].data_ptr() for k in range(K)])
-        b = (vp * K)(*[keep[4 * k + 3].data_ptr() for k in range(K)])
-        h = (ctypes.c_int32 * K)(*[l1.out_features for l1, _ in pairs])
-        O = (ctypes.c_int32 * K)(*[l2.out_features for _, l2 in pairs])
-        Y = (vp * K)(*[y.data_ptr() for y in ys])
+    outs: List[torch.Tensor] = []
+    n_mlp = len(params) // 4
+    for start in range(0, n_mlp, MAX_K):
+        grp = params[4 * start:4 * min(start + MAX_K, n_mlp)]
+        K = len(grp) // 4
+        As, as_, Bs, bs = grp[0::4], grp[1::4], grp[2::4], grp[3::4]
+        ys = [torch.empty((T, B.shape[0]), dtype=torch.float32, device=dev) for B in Bs]
+        h = (ctypes.c_int32 * K)(*[A.shape[0] for A in As])
+        O = (ctypes.c_int32 * K)(*[B.shape[0] for B in Bs])
         ws_bytes = lib.psf_mlp_fwd_workspace(E, K, h, O)
         if ws_bytes < 0:
             raise ValueError("psf_mlp_fwd does not support these layer sizes")
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)  # packed weight images
         with torch.cuda.device(dev):
-            rc = lib.psf_mlp_fwd_f32(x2.data_ptr(), T, E, K, A, a, B, b, h, O, Y, ws.data_ptr(), ws_bytes,
-                                     torch.cuda.current_stream(dev).cuda_stream)
+            rc = lib.psf_mlp_fwd_f32(x2.data_ptr(), T, E, K, _ptrs(As), _ptrs(as_), _ptrs(Bs), _ptrs(bs), h, O, _ptrs(ys),
+                                     ws.data_ptr(), ws_bytes, torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(rc, "psf_mlp_fwd_f32")
-        outs.extend(y.reshape(*lead, y.shape[1]) for y in ys)
+        outs.extend(ys)
     return outs
+
+
+def _backward_raw(x2: torch.Tensor, params: Sequence[torch.Tensor], gys: Sequence[torch.Tensor], need_dx: bool):
+    T, E = x2.shape
+    dev = x2.device
+    lib = _lib.load()
+    K = len(params) // 4
+    As, as_, Bs = params[0::4], params[1::4], params[2::4]
+    h = (ctypes.c_int32 * K)(*[A.shape[0] for A in As])
+    O = (ctypes.c_int32 * K)(*[B.shape[0] for B in Bs])
+    grads = [torch.empty_like(p) for p in params]
+    dX = torch.empty_like(x2) if need_dx else None
+    ws_bytes = lib.psf_mlp_bwd_workspace(T, E, K, h, O)
+    if ws_bytes < 0:
+        raise ValueError("psf_mlp_bwd does not support these layer sizes")
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)  # packed weights + per-wave partial sums
+    with torch.cuda.device(dev):
+        rc = lib.psf_mlp_bwd_f32(x2.data_ptr(), T, E, K, _ptrs(As), _ptrs(as_), _ptrs(Bs), h, O, _ptrs(gys),
+                                 dX.data_ptr() if need_dx else None, _ptrs(grads[0::4]), _ptrs(grads[1::4]),
+                                 _ptrs(grads[2::4]), _ptrs(grads[3::4]), ws.data_ptr(), ws_bytes,
+                                 torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "psf_mlp_bwd_f32")
+    return dX, grads
+
+
+class _FusedMLPFn(torch.autograd.Function):
+    """(Y_0, ..., Y_{K-1}) = MLPs(x2); saves x2 and the parameters only."""
+
+    @staticmethod
+    def forward(ctx, x2, *params):
+        params = tuple(p.detach().contiguous() for p in params)
+        ctx.save_for_backward(x2, *params)
+        return tuple(_forward_raw(x2, params))
+
+    @staticmethod
+    def backward(ctx, *gys):
+        x2, *params = ctx.saved_tensors
+        Bs = params[2::4]
+        gys = [torch.zeros((x2.shape[0], B.shape[0]), dtype=torch.float32, device=x2.device) if g is None else g.contiguous()
+               for g, B in zip(gys, Bs)]
+        dX, grads = _backward_raw(x2, params, gys, ctx.needs_input_grad[0])
+        return (dX, *grads)
+
+
+def _params_of(blocks: Sequence[nn.Module]) -> List[torch.Tensor]:
+    out: List[torch.Tensor] = []
+    for b in blocks:
+        l1, l2 = _two_layer(b)
+        out += [l1.weight, l1.bias, l2.weight, l2.bias]
+    return out
+
+
+def fused_mlp_forward(x: torch.Tensor, blocks: Sequence[nn.Module]) -> List[torch.Tensor]:
+    """[block(x) for block in blocks] without autograd, by the fused kernel. Caller checks ``eligible`` first."""
+    lead, E = x.shape[:-1], x.shape[-1]
+    x2 = x.detach().reshape(-1, E).contiguous()
+    params = [p.detach().contiguous() for p in _params_of(blocks)]
+    return [y.reshape(*lead, y.shape[1]) for y in _forward_raw(x2, params)]
+
+
+def fused_mlp_apply(x: torch.Tensor, blocks: Sequence[nn.Module]) -> List[torch.Tensor]:
+    """[block(x) for block in blocks] under autograd (fused forward and backward). Caller checks ``trainable``."""
+    lead, E = x.shape[:-1], x.shape[-1]
+    x2 = x.reshape(-1, E).contiguous()
+    ys = _FusedMLPFn.apply(x2, *_params_of(blocks))
+    return [y.reshape(*lead, y.shape[1]) for y in ys]

@@ -105,19 +105,26 @@ class _ChordMixer(nn.Module):
 
     def link_weights(self, data: torch.Tensor) -> List[torch.Tensor]:
         """W_m = fs[m](data), each [B, N, L] (psf.py:175)."""
-        if fused_mlp.eligible(data, list(self.fs)):
-            return fused_mlp.fused_mlp_forward(data, list(self.fs))
-        return [f(data) for f in self.fs]
+        fs = list(self.fs)
+        if fused_mlp.eligible(data, fs):
+            return fused_mlp.fused_mlp_forward(data, fs)
+        if fused_mlp.trainable(data, fs):
+            return fused_mlp.fused_mlp_apply(data, fs)
+        return [f(data) for f in fs]
 
     def produce(self, data: torch.Tensor):
-        """(V, [W_m]) = (g(data), [fs[m](data)]) — psf.py:165,175. Without gradients (eval / no_grad) all M+1
-        MLPs run as ONE fused launch from one read of ``data`` (fused_mlp.py); otherwise the PyTorch layers.
+        """(V, [W_m]) = (g(data), [fs[m](data)]) — psf.py:165,175. All M+1 MLPs run as ONE fused launch from one
+        read of ``data``, and under autograd their backward is one fused launch too (fused_mlp.py); shapes the
+        kernels do not cover use the PyTorch layers.
         Returns links = None when the chain is not fused (each W_m is then produced right before its step)."""
         if not self.fused_chain:
             return self.g(data), None
         blocks = [self.g] + list(self.fs)
         if fused_mlp.eligible(data, blocks):
             outs = fused_mlp.fused_mlp_forward(data, blocks)
+            return outs[0], outs[1:]
+        if fused_mlp.trainable(data, blocks):
+            outs = fused_mlp.fused_mlp_apply(data, blocks)
             return outs[0], outs[1:]
         return self.g(data), self.link_weights(data)
 

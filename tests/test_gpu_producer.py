@@ -96,6 +96,66 @@ def test_fused_mlp_forward_matches_pytorch(gpu, T, E, layers):
     assert not fused_mlp.eligible(x, [b.float() for b in blocks])
 
 
+MLP_TRAIN_CASES = [  # (T, E, [(h, out), ...])
+    (40 * 1024, 32, [(32, 8)] + [(32, 15)] * 14),       # Adding/Order
+    (4097 * 2, 32, [(128, 32)] + [(128, 13)] * 12),     # IMDb / Pathfinder widths: 4 hidden blocks per MLP
+    (1024 * 3 + 7, 16, [(16, 16)] + [(16, 11)] * 10),   # CIFAR-10 widths, ragged token count
+    (1000, 28, [(96, 32), (33, 1), (128, 20)]),         # mixed hidden widths, E = 28
+    (31, 4, [(5, 3)]),                                   # smaller than one tile
+    (2049, 8, [(7, 2), (40, 31)]),                       # E = 8, odd hidden width
+]
+
+
+@pytest.mark.parametrize("T,E,layers", MLP_TRAIN_CASES)
+def test_fused_mlp_backward_matches_float64_autograd(gpu, T, E, layers):
+    """psf_mlp_fwd_f32 + psf_mlp_bwd_f32 under autograd vs float64 autograd through the nn modules they replace.
+    Tolerance 2e-5 of max|ref| per tensor: f32 sums over up to T products plus a 1.5e-7 erf approximation."""
+    import copy
+    from sparsefactorization_amd import fused_mlp
+    from sparsefactorization_amd.psfnet import MLPBlock
+    torch.manual_seed(T + E)
+    blocks = [MLPBlock([h, 'GELU'], E, o).to(gpu) for h, o in layers]
+    ref_blocks = [copy.deepcopy(b).double() for b in blocks]
+    x = torch.randn(T, E, device=gpu, requires_grad=True)
+    xr = x.detach().double().requires_grad_(True)
+    gys = [torch.randn(T, o, device=gpu) for _, o in layers]
+    assert fused_mlp.trainable(x, blocks) and not fused_mlp.eligible(x, blocks)
+    ys = fused_mlp.fused_mlp_apply(x, blocks)
+    torch.autograd.backward(ys, gys)
+    torch.autograd.backward([b(xr) for b in ref_blocks], [g.double() for g in gys])
+    assert rel_inf(x.grad.cpu().numpy(), xr.grad.cpu().numpy()) <= 2e-5
+    for b, rb in zip(blocks, ref_blocks):
+        for (name, p), (_, rp) in zip(b.named_parameters(), rb.named_parameters()):
+            assert p.grad is not None and p.grad.shape == rp.grad.shape, name
+            assert rel_inf(p.grad.cpu().numpy(), rp.grad.cpu().numpy()) <= 2e-5, name
+    # fixed-order reductions: bit-reproducible
+    first = [p.grad.clone() for b in blocks for p in b.parameters()] + [x.grad.clone()]
+    for b in blocks:
+        b.zero_grad()
+    x.grad = None
+    torch.autograd.backward(fused_mlp.fused_mlp_apply(x, blocks), gys)
+    again = [p.grad for b in blocks for p in b.parameters()] + [x.grad]
+    assert all(torch.equal(u, v) for u, v in zip(first, again))
+
+
+def test_fused_mlp_backward_partial_outputs_and_frozen_input(gpu):
+    """Outputs that receive no gradient count as zero; an input that needs no gradient gets none."""
+    from sparsefactorization_amd import fused_mlp
+    from sparsefactorization_amd.psfnet import MLPBlock
+    torch.manual_seed(3)
+    blocks = [MLPBlock([32, 'GELU'], 32, o).to(gpu) for o in (8, 15, 15)]
+    x = torch.randn(5000, 32, device=gpu)  # no grad on the input
+    assert fused_mlp.trainable(x, blocks)
+    ys = fused_mlp.fused_mlp_apply(x, blocks)
+    ys[1].square().sum().backward()
+    ref = blocks[1](x)
+    g = torch.autograd.grad(ref.square().sum(), list(blocks[1].parameters()))
+    for p, r in zip(blocks[1].parameters(), g):
+        assert rel_inf(p.grad.cpu().numpy(), r.cpu().numpy()) <= 2e-5
+    for b in (blocks[0], blocks[2]):
+        assert all(float(p.grad.abs().max()) == 0.0 for p in b.parameters())
+
+
 def test_fused_mlp_leading_dims_and_ineligible_forms(gpu):
     from sparsefactorization_amd import fused_mlp
     from sparsefactorization_amd.psfnet import MLPBlock
