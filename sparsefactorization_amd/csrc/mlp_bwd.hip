@@ -147,14 +147,25 @@ __device__ __forceinline__ void tile_to_scratch(const float* __restrict__ base, 
   }
 }
 
-template <int TPW>
-__global__ void __launch_bounds__(256)
+// launch_bounds(256, 2): two workgroups (8 waves) per CU need <= 256 registers per lane; hipcc then spills ~30
+// registers, all but four scratch accesses of which sit in the per-block prologue / epilogue, not in the unit loop.
+// Unbounded it takes 352 registers (one wave per SIMD, every LDS round trip exposed): 2.46 ms vs the bounded build
+// at Order N=16384, B=40.
+// NDY: registers of the dY prefetch = ceil(32 * max O / 64): 8 for O <= 16, else 16.
+template <int TPW, int NDY>
+__global__ void __launch_bounds__(256, 2)
 mlp_bwd_k(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int c = lane & 31, half = lane >> 5;
-  float* S1 = lds + 2 * kImg + wv * (2 * 32 * 33);  // tile staging: X at group start, then the dY tile
-  float* S2 = S1 + 32 * 33;                         // re-layout of Hpost^T / G
+  // per wave: the TPW X tiles [tok][33] (B operand of step 5, read per use: keeping that orientation in registers
+  // too cost 32 of them and pushed the unit loop into scratch spills), the dY tile [tok][SD], the re-layout tile
+  constexpr int SD = NDY == 8 ? 17 : 33;  // odd strides: conflict-free by row and by column
+  constexpr int kImgBufs = NDY == 8 ? 2 : 1;  // O > 16: one image buffer so that two workgroups still fit a CU
+  constexpr int kWaveLds = TPW * 32 * 33 + 32 * SD + 32 * 33;
+  float* SX = lds + kImgBufs * kImg + wv * kWaveLds;
+  float* S1 = SX + TPW * 32 * 33;  // dY tile
+  float* S2 = S1 + 32 * SD;        // re-layout of Hpost^T / G; dX^T at the end
   const int E = a.E, U = a.U;
   const int64_t tiles = (a.T + 31) / 32;
   const int64_t tiles_per_block = 4 * TPW;
@@ -162,7 +173,7 @@ mlp_bwd_k(const BwdArgs a) {
 
   auto stage = [&](int u) {
     const float* src = a.images + (int64_t)u * kImg;
-    float* dst = lds + (u & 1) * kImg;
+    float* dst = lds + (kImgBufs == 2 ? (u & 1) : 0) * kImg;
     for (int v0 = 0; v0 < img_vecs; v0 += 256) {
       const int v = v0 + tid;
       if (v < img_vecs)
@@ -172,35 +183,71 @@ mlp_bwd_k(const BwdArgs a) {
   };
 
   for (int64_t blk = blockIdx.x; blk * tiles_per_block < tiles; blk += gridDim.x) {
-    float xr[TPW][16], xT[TPW][16];
+    float xr[TPW][16];
     f32x16 dxa[TPW];
     int64_t t0[TPW];
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp) {
       t0[tp] = (blk * tiles_per_block + wv * TPW + tp) * 32;
-      tile_to_scratch<true>(a.X, a.T, E, t0[tp], S1, lane);
+      float* sx = SX + tp * 32 * 33;
+      tile_to_scratch<true>(a.X, a.T, E, t0[tp], sx, lane);
+      if (E < 32)
+        for (int i = lane; i < 32 * 32; i += 64)
+          if ((i & 31) >= E) sx[(i >> 5) * 33 + (i & 31)] = 0.f;  // columns >= E read as zero
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int q = 2 * kk + half;
-        xr[tp][kk] = q < E ? S1[c * 33 + q] : 0.f;   // X[tok = c][e = q]
-        xT[tp][kk] = c < E ? S1[q * 33 + c] : 0.f;   // X[tok = q][e = c]
-      }
+      for (int kk = 0; kk < 16; ++kk) xr[tp][kk] = sx[c * 33 + 2 * kk + half];  // X[tok = c][e = 2kk+half]
 #pragma unroll
       for (int r = 0; r < 16; ++r) dxa[tp][r] = 0.f;
     }
     float* part = a.partials + ((blk * 4 + wv) * (int64_t)U) * kPart;
-    __syncthreads();  // the previous block's last unit is done with both image buffers
-    stage(0);
+    // dY tiles are fetched one tile-unit ahead into registers (element lane + 64 i of the 32*O-float burst): with two
+    // waves per SIMD a load consumed right after its issue exposes the whole memory latency once per tile-unit.
+    float dyn[NDY];
+    auto dy_fetch = [&](int u2, int64_t t02) {
+      const BwdMlp& d2 = a.m[a.unit_k[u2]];
+      const int W = d2.O;
+      const int64_t rows_left = a.T - t02;
+      const int n = (int)(rows_left >= 32 ? 32 : (rows_left > 0 ? rows_left : 0)) * W;
+      const float* src = d2.dY + t02 * W;
+#pragma unroll
+      for (int i = 0; i < NDY; ++i) {
+        const int f = lane + 64 * i;
+        dyn[i] = f < n ? src[f] : 0.f;
+      }
+    };
+    auto dy_commit = [&](int W) {  // registers -> S1[tok][33]
+      const int q64 = 64 / W, r64 = 64 - q64 * W;
+      int tok = lane / W, col = lane - tok * W;
+#pragma unroll
+      for (int i = 0; i < NDY; ++i) {
+        if (lane + 64 * i < 32 * W) S1[tok * SD + col] = dyn[i];
+        tok += q64;
+        col += r64;
+        if (col >= W) {
+          col -= W;
+          ++tok;
+        }
+      }
+    };
+    dy_fetch(0, t0[0]);
+    if (kImgBufs == 2) {
+      __syncthreads();  // the previous block's last unit is done with both image buffers
+      stage(0);
+    }
 
     for (int u = 0; u < U; ++u) {
       __syncthreads();  // image u has landed (hipcc drains vmcnt before the barrier); unit u-1 is finished
-      if (u + 1 < U) stage(u + 1);
-      const float* sA = lds + (u & 1) * kImg;
+      if (kImgBufs == 2) {
+        if (u + 1 < U) stage(u + 1);
+      } else {
+        stage(u);
+        __syncthreads();
+      }
+      const float* sA = lds + (kImgBufs == 2 ? (u & 1) : 0) * kImg;
       const float* sa = sA + kOffSa;
       const float* sB = sA + kOffSb;
       const BwdMlp& d = a.m[a.unit_k[u]];
       const int O = d.O;
-      const float* __restrict__ dY = d.dY;
 
       f32x16 dA, dBT;
 #pragma unroll
@@ -209,8 +256,12 @@ mlp_bwd_k(const BwdArgs a) {
 
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp) {
+        dy_commit(O);
+        if (tp + 1 < TPW)
+          dy_fetch(u, t0[tp + 1 < TPW ? tp + 1 : 0]);
+        else if (u + 1 < U)
+          dy_fetch(u + 1, t0[0]);
         if (t0[tp] >= a.T) continue;  // wave-uniform
-        tile_to_scratch<false>(dY, a.T, O, t0[tp], S1, lane);
         // 1. Hpre^T
         f32x16 acc1, acc3;
 #pragma unroll
@@ -222,20 +273,20 @@ mlp_bwd_k(const BwdArgs a) {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * kk], xr[tp][kk], acc1, 0, 0, 0);
         // 2. dHpost^T: A operand B[o = 2kk+half][j = c], B operand dY[tok = c][o = 2kk+half]
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-          if (2 * kk >= O) break;  // wave-uniform
+#pragma unroll 1
+        for (int kk = 0; 2 * kk < O; ++kk) {
           const int o = 2 * kk + half;
-          const float dyv = o < O ? S1[c * 33 + o] : 0.f;
+          const float dyv = o < O ? S1[c * SD + o] : 0.f;
           acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(sB[o * 33 + c], dyv, acc3, 0, 0, 0);
         }
         // 3. GELU and its derivative; Hpost^T -> S2[j][tok]
+        float g[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float y, dy;
           gelu_and_grad(acc1[r], y, dy);
           S2[cd_row(r, half) * 33 + c] = y;
-          acc3[r] *= dy;  // G = dHpre^T
+          g[r] = acc3[r] * dy;  // G = dHpre^T
         }
         // 4. dB^T += Hpost^T[j = c][tok = 2kk+half] · dY[tok = 2kk+half][o = c]
         {
@@ -243,7 +294,7 @@ mlp_bwd_k(const BwdArgs a) {
 #pragma unroll
           for (int kk = 0; kk < 16; ++kk) {
             const int q = 2 * kk + half;
-            const float dyt = c < O ? S1[q * 33 + c] : 0.f;
+            const float dyt = c < O ? S1[q * SD + c] : 0.f;
             dbs += dyt;
             dBT = __builtin_amdgcn_mfma_f32_32x32x2f32(S2[c * 33 + q], dyt, dBT, 0, 0, 0);
           }
@@ -251,14 +302,14 @@ mlp_bwd_k(const BwdArgs a) {
         }
         // 5. dA += G[j = c][tok = 2kk+half] · X[tok = 2kk+half][e = c]   (G re-laid through S2)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 33 + c] = acc3[r];
+        for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 33 + c] = g[r];
         {
           float das = 0.f;
 #pragma unroll
           for (int kk = 0; kk < 16; ++kk) {
             const float gt = S2[c * 33 + 2 * kk + half];
             das += gt;
-            dA = __builtin_amdgcn_mfma_f32_32x32x2f32(gt, xT[tp][kk], dA, 0, 0, 0);
+            dA = __builtin_amdgcn_mfma_f32_32x32x2f32(gt, SX[tp * 32 * 33 + (2 * kk + half) * 33 + c], dA, 0, 0, 0);
           }
           da += das;
         }
@@ -266,7 +317,7 @@ mlp_bwd_k(const BwdArgs a) {
         if (a.dX) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            dxa[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[cd_row(r, half) * 33 + c], acc3[r], dxa[tp], 0, 0, 0);
+            dxa[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[cd_row(r, half) * 33 + c], g[r], dxa[tp], 0, 0, 0);
         }
       }
       // flush the unit's partial sums (coalesced: for fixed r the 64 lanes write two 128-byte rows)
@@ -425,8 +476,18 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   // every (block, wave) slot of the partial buffer is written exactly once: one block per 4*TPW tiles
   const int64_t blocks = p.G / 4;
   if (blocks > 0x7fffffff) return psf_internal_fail(PSF_E_SHAPE, "psf_mlp_bwd: T too large");
-  const size_t lds_bytes = sizeof(float) * (2 * (size_t)kImg + 4 * 2 * 32 * 33);
-  hipLaunchKernelGGL((mlp_bwd_k<kTPW>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, args);
+  int max_o = 1;
+  for (int k = 0; k < K; ++k) max_o = O[k] > max_o ? O[k] : max_o;
+  if (max_o <= 16) {
+    const size_t lds_bytes = sizeof(float) * (2 * (size_t)kImg + 4 * (kTPW * 32 * 33 + 32 * 17 + 32 * 33));
+    e = hipFuncSetAttribute((const void*)mlp_bwd_k<kTPW, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) hipLaunchKernelGGL((mlp_bwd_k<kTPW, 8>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, args);
+  } else {
+    const size_t lds_bytes = sizeof(float) * ((size_t)kImg + 4 * (kTPW * 32 * 33 + 32 * 33 + 32 * 33));
+    e = hipFuncSetAttribute((const void*)mlp_bwd_k<kTPW, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) hipLaunchKernelGGL((mlp_bwd_k<kTPW, 16>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, args);
+  }
+  if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
   e = hipGetLastError();
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
   const int64_t n = (int64_t)p.U * kPart;
