@@ -14,8 +14,8 @@
 // and dB rows of a unit depend on no other unit; only dX (summed over all units) and db (taken from the ht = 0
 // unit) cross units.
 //
-// Per wave: TPW tiles of 32 tokens; X is held in registers in both MFMA orientations (xr: contraction over e;
-// xT: contraction over tokens), the dX^T accumulators persist over all units. Per unit and tile, on
+// Per wave: TPW tiles of 32 tokens; X's operand for the contraction over e (xr) is held in registers, the tiles
+// themselves stay in LDS for the contraction over tokens (xT); the dX^T accumulators persist over all units. Per unit and tile, on
 // v_mfma_f32_32x32x2_f32 (D[i][j] += A[i][k] B[k][j]; A-operand lane l = (i = l&31, k = l>>5), B-operand lane
 // l = (k = l>>5, j = l&31), result register r of lane l = D[(r&3) + 8(r>>2) + 4(l>>5)][l&31]):
 //   1. Hpre^T  [j x tok] = A_u · X^T + a_u                              16 MFMAs   (A from the LDS image, xr)
@@ -26,7 +26,8 @@
 //   6. dX^T    [e x tok]+= A_u^T · G       (contraction over j)         16 MFMAs   (G's accumulator registers ARE
 //        the B operand: register r pairs rows {row(r,0), row(r,1)}; the A operand takes A_u[that row][e] from LDS)
 //   da_u, db_u: sums of the step-5 / step-4 operand registers (their k index is the token).
-// After the wave's TPW tiles the unit's 34 accumulator registers are flushed to the partial buffer.
+// After the wave's TPW tiles the unit's 34 accumulator registers are summed over the workgroup's four waves
+// through LDS and flushed to the workgroup's slot of the partial buffer.
 //
 // Limits: E <= 32 (multiple of 4), h <= 128, O <= 32, K <= 32; anything else stays on autograd.
 #include <hip/hip_runtime.h>
@@ -67,10 +68,10 @@ struct BwdArgs {
   const float* X;
   float* dX;        // [T, E] or nullptr
   float* images;    // U images of kImg floats
-  float* partials;  // [G][U][kPart]
+  float* partials;  // [G][U][kPart], one slot per workgroup
   float* stage1;    // [kSlices][U * kPart]
   int64_t T;
-  int64_t G;        // wave groups = partial slots
+  int64_t G;        // workgroups = partial slots
   int32_t E, K, U;
 };
 
@@ -199,7 +200,7 @@ mlp_bwd_k(const BwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dxa[tp][r] = 0.f;
     }
-    float* part = a.partials + ((blk * 4 + wv) * (int64_t)U) * kPart;
+    float* part = a.partials + (blk * (int64_t)U) * kPart;  // one partial slot per workgroup
     // dY tiles are fetched one tile-unit ahead into registers (element lane + 64 i of the 32*O-float burst): with two
     // waves per SIMD a load consumed right after its issue exposes the whole memory latency once per tile-unit.
     float dyn[NDY];
@@ -320,16 +321,37 @@ mlp_bwd_k(const BwdArgs a) {
             dxa[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[cd_row(r, half) * 33 + c], g[r], dxa[tp], 0, 0, 0);
         }
       }
-      // flush the unit's partial sums (coalesced: for fixed r the 64 lanes write two 128-byte rows)
+      // Combine the four waves' partial sums through LDS (fixed order w = 0..3) and flush once per workgroup: a
+      // quarter of the partial-buffer traffic of per-wave flushes (1.3 GB at Order N=16384, B=40, whose fixed-order
+      // reduction alone took 0.38 ms).
       float* pu = part + (int64_t)u * kPart;
+      const float* wave0 = lds + kImgBufs * kImg + TPW * 32 * 33;  // wave 0's S1; wave w's is + w * kWaveLds
+      auto sum4 = [&](int off) {  // off: float offset from a wave's S1, 16-byte aligned
+        float4 acc = *reinterpret_cast<const float4*>(wave0 + off);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pu[cd_row(r, half) * 32 + c] = dA[r];
-        pu[1024 + cd_row(r, half) * 32 + c] = dBT[r];
-      }
-      pu[2048 + lane] = da;
-      pu[2112 + lane] = db;
+        for (int w = 1; w < 4; ++w) {
+          const float4 v = *reinterpret_cast<const float4*>(wave0 + w * kWaveLds + off);
+          acc.x += v.x;
+          acc.y += v.y;
+          acc.z += v.z;
+          acc.w += v.w;
+        }
+        return acc;
+      };
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 32 + c] = dA[r];
+      S1[lane] = da;
+      S1[64 + lane] = db;
+      __syncthreads();
+      *reinterpret_cast<float4*>(pu + wv * 256 + 4 * lane) = sum4(32 * SD + wv * 256 + 4 * lane);
+      if (wv == 0 && lane < 32) *reinterpret_cast<float4*>(pu + 2048 + 4 * lane) = sum4(4 * lane);  // da [2][32] | db [2][32]
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 32 + c] = dBT[r];
+      __syncthreads();
+      *reinterpret_cast<float4*>(pu + 1024 + wv * 256 + 4 * lane) = sum4(32 * SD + wv * 256 + 4 * lane);
     }
+    __syncthreads();  // all combine reads of S2 are done before the dX epilogue reuses it
 
     if (a.dX) {
 #pragma unroll
@@ -416,7 +438,7 @@ bool make_plan(int64_t T, int32_t E, int32_t K, const int32_t* h, const int32_t*
     }
   }
   const int64_t tiles = (T + 31) / 32;
-  p->G = 4 * ((tiles + 4 * kTPW - 1) / (4 * kTPW));
+  p->G = (tiles + 4 * kTPW - 1) / (4 * kTPW);  // one workgroup (= one partial slot) per 4*TPW tiles
   return true;
 }
 
@@ -473,8 +495,8 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
 
-  // every (block, wave) slot of the partial buffer is written exactly once: one block per 4*TPW tiles
-  const int64_t blocks = p.G / 4;
+  // every slot of the partial buffer is written exactly once: one workgroup per 4*TPW tiles
+  const int64_t blocks = p.G;
   if (blocks > 0x7fffffff) return psf_internal_fail(PSF_E_SHAPE, "psf_mlp_bwd: T too large");
   int max_o = 1;
   for (int k = 0; k < K; ++k) max_o = O[k] > max_o ? O[k] : max_o;
