@@ -48,7 +48,6 @@ constexpr int kOffSa = 32 * 33;
 constexpr int kOffSb = kOffSa + 32;
 constexpr int kPart = 1024 + 1024 + 64 + 64;  // per (group, unit): dA [j][e] | dB^T [j][o] | da [half][j] | db [half][o]
 constexpr int kSlices = 64;                   // stage-1 reduction slices
-constexpr int kTPW = 2;
 
 struct BwdMlp {
   const float* A;   // [h, E]
@@ -422,6 +421,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_reduce2_k(const BwdArgs a) {
 
 struct Plan {
   int U;
+  int tpw;  // tiles per wave: 2, or 1 for short inputs (keeps >= 2 workgroups per CU in flight)
   int64_t G;
   uint8_t unit_k[kMaxUnits], unit_hb[kMaxUnits];
 };
@@ -438,7 +438,8 @@ bool make_plan(int64_t T, int32_t E, int32_t K, const int32_t* h, const int32_t*
     }
   }
   const int64_t tiles = (T + 31) / 32;
-  p->G = (tiles + 4 * kTPW - 1) / (4 * kTPW);  // one workgroup (= one partial slot) per 4*TPW tiles
+  p->tpw = (tiles + 7) / 8 >= 512 ? 2 : 1;
+  p->G = (tiles + 4 * p->tpw - 1) / (4 * p->tpw);  // one workgroup (= one partial slot) per 4*TPW tiles
   return true;
 }
 
@@ -500,17 +501,18 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   if (blocks > 0x7fffffff) return psf_internal_fail(PSF_E_SHAPE, "psf_mlp_bwd: T too large");
   int max_o = 1;
   for (int k = 0; k < K; ++k) max_o = O[k] > max_o ? O[k] : max_o;
+  auto launch = [&](auto kernel, int tpw, int sd, int img_bufs) {
+    const size_t lds_bytes = sizeof(float) * ((size_t)img_bufs * kImg + 4 * (tpw * 32 * 33 + 32 * sd + 32 * 33));
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, s, args);
+  };
   if (max_o <= 16) {
-    const size_t lds_bytes = sizeof(float) * (2 * (size_t)kImg + 4 * (kTPW * 32 * 33 + 32 * 17 + 32 * 33));
-    e = hipFuncSetAttribute((const void*)mlp_bwd_k<kTPW, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e == hipSuccess) hipLaunchKernelGGL((mlp_bwd_k<kTPW, 8>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, args);
+    if (p.tpw == 2) launch(mlp_bwd_k<2, 8>, 2, 17, 2);
+    else launch(mlp_bwd_k<1, 8>, 1, 17, 2);
   } else {
-    const size_t lds_bytes = sizeof(float) * ((size_t)kImg + 4 * (kTPW * 32 * 33 + 32 * 33 + 32 * 33));
-    e = hipFuncSetAttribute((const void*)mlp_bwd_k<kTPW, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e == hipSuccess) hipLaunchKernelGGL((mlp_bwd_k<kTPW, 16>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, args);
+    if (p.tpw == 2) launch(mlp_bwd_k<2, 16>, 2, 33, 1);
+    else launch(mlp_bwd_k<1, 16>, 1, 33, 1);
   }
-  if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
-  e = hipGetLastError();
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
   const int64_t n = (int64_t)p.U * kPart;
   hipLaunchKernelGGL(mlp_bwd_reduce1_k, dim3((unsigned)((n + 255) / 256), kSlices), dim3(256), 0, s, args);

@@ -369,9 +369,14 @@ int psf_mlp_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   const int variant = psf_g_mlp_variant.load();
   if (variant == 2 && !p.lds_resident_bytes)
     return psf_internal_fail(PSF_E_TUNING, "psf_mlp_fwd: mlp_variant=2 but the K weight images do not fit in LDS");
-  if (p.lds_resident_bytes && variant != 1) {
+  // Tiles per wave: as many as the registers allow (4 at EP = 32, 2 at EP = 64) when T is large; fewer for short
+  // inputs so that the launch still has >= 2 workgroups per CU (Pathfinder B=64: 2048 tiles were 128 workgroups).
+  int tpw = p.tpw;
+  while (tpw > 1 && (tiles + 4 * tpw - 1) / (4 * tpw) < 512) tpw >>= 1;
+  const int64_t groups = (tiles + p.tpw - 1) / p.tpw;
+  const bool resident = p.lds_resident_bytes && variant != 1 && (variant == 2 || groups >= 2 * 8 * 256);
+  if (resident) {
     // persistent: one 8-wave workgroup per CU (LDS-bound), waves stride over groups of TPW tiles
-    const int64_t groups = (tiles + p.tpw - 1) / p.tpw;
     const int grid = (int)((groups + 7) / 8 < 256 ? (groups + 7) / 8 : 256);
     const int lds = (int)p.lds_resident_bytes;
     if (p.ep == 32) {
@@ -382,16 +387,20 @@ int psf_mlp_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
       if (e == hipSuccess) hipLaunchKernelGGL((mlp_fwd_resident_k<64, 2>), dim3(grid), dim3(512), lds, s, args);
     }
   } else {
-    const int64_t blocks_needed = (tiles + 4 * p.tpw - 1) / (4 * p.tpw);
+    const int64_t blocks_needed = (tiles + 4 * tpw - 1) / (4 * tpw);
     const int grid = (int)(blocks_needed < 2048 ? blocks_needed : 2048);
+    auto launch = [&](auto kernel) {
+      if (p.lds_bytes > 48 * 1024)
+        e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+      if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), p.lds_bytes, s, args);
+    };
     if (p.ep == 32) {
-      if (p.lds_bytes > 48 * 1024)
-        e = hipFuncSetAttribute((const void*)mlp_fwd_k<32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-      if (e == hipSuccess) hipLaunchKernelGGL((mlp_fwd_k<32, 4>), dim3(grid), dim3(256), p.lds_bytes, s, args);
+      if (tpw == 4) launch(mlp_fwd_k<32, 4>);
+      else if (tpw == 2) launch(mlp_fwd_k<32, 2>);
+      else launch(mlp_fwd_k<32, 1>);
     } else {
-      if (p.lds_bytes > 48 * 1024)
-        e = hipFuncSetAttribute((const void*)mlp_fwd_k<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-      if (e == hipSuccess) hipLaunchKernelGGL((mlp_fwd_k<64, 2>), dim3(grid), dim3(256), p.lds_bytes, s, args);
+      if (tpw == 2) launch(mlp_fwd_k<64, 2>);
+      else launch(mlp_fwd_k<64, 1>);
     }
   }
   if (e == hipSuccess) e = hipGetLastError();
