@@ -149,6 +149,10 @@ int psf_chord_chain_fwd_f64(const double* const* W_steps, const double* V0, doub
 int64_t psf_linear_wgrad_workspace(int64_t T, int32_t m, int32_t n);
 int psf_linear_wgrad_f32(const float* X, const float* dY, int64_t T, int32_t m, int32_t n, float* dWt, float* db,
                          void* workspace, int64_t workspace_bytes, void* stream);
+/* Same with row strides (in floats; ldx >= m, ldy >= n): X and dY may be column slices of wider row-major arrays,
+ * e.g. one MLP's hidden block inside the stacked hidden layer of all MLPs. */
+int psf_linear_wgrad_strided_f32(const float* X, int64_t ldx, const float* dY, int64_t ldy, int64_t T, int32_t m, int32_t n,
+                                 float* dWt, float* db, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * Producer side, forward (inference): K two-layer token-wise MLPs sharing one input, fused in one launch —

@@ -22,6 +22,9 @@ from sparsefactorization_amd import lra_training  # noqa: E402
 
 
 def main():
+    if os.environ.get("PSF_GRAPH_LAB_UNSAFE") != "1":
+        raise SystemExit("graph_step_lab: a replay faulted the GPU in round 1 (see the docstring); "
+                         "set PSF_GRAPH_LAB_UNSAFE=1 only after nn.Embedding's backward has been replaced")
     task = sys.argv[1] if len(sys.argv) > 1 else "pathfinder"
     cfg = lra_training.config[task]
     batch = cfg["training"]["batch_size"]

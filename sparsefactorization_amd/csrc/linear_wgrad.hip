@@ -37,7 +37,7 @@ __device__ __forceinline__ int cd_row(int reg, int lane) { return (reg & 3) + 8 
 
 template <int TJ, int TI>
 __global__ void __launch_bounds__(256)
-linear_wgrad_partial_k(const float* __restrict__ X, const float* __restrict__ dY, int64_t T, int m, int n,
+linear_wgrad_partial_k(const float* __restrict__ X, int64_t ldx, const float* __restrict__ dY, int64_t ldy, int64_t T, int m, int n,
                        float* __restrict__ part, float* __restrict__ bpart, int64_t rows_per_wave, int nwaves) {
   const int lane = threadIdx.x & 63;
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -84,9 +84,9 @@ linear_wgrad_partial_k(const float* __restrict__ X, const float* __restrict__ dY
     for (int u = 0; u < U; ++u) {
       const int64_t row = t + 2 * u + kk;
 #pragma unroll
-      for (int a = 0; a < TJ; ++a) av[u][a] = dY[row * n + jc[a]];
+      for (int a = 0; a < TJ; ++a) av[u][a] = dY[row * ldy + jc[a]];
 #pragma unroll
-      for (int b = 0; b < TI; ++b) bv[u][b] = X[row * m + ic[b]];
+      for (int b = 0; b < TI; ++b) bv[u][b] = X[row * ldx + ic[b]];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -107,11 +107,11 @@ linear_wgrad_partial_k(const float* __restrict__ X, const float* __restrict__ dY
     const int64_t rc = ok ? row : t_end - 1;
 #pragma unroll
     for (int a = 0; a < TJ; ++a) {
-      const float aa = ok ? dY[rc * n + jc[a]] * jm[a] : 0.f;
+      const float aa = ok ? dY[rc * ldy + jc[a]] * jm[a] : 0.f;
       bacc[a] += aa;
 #pragma unroll
       for (int b = 0; b < TI; ++b) {
-        const float bb = ok ? X[rc * m + ic[b]] * im[b] : 0.f;
+        const float bb = ok ? X[rc * ldx + ic[b]] * im[b] : 0.f;
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa, bb, acc[a][b], 0, 0, 0);
       }
     }
@@ -228,14 +228,14 @@ bool make_plan(int64_t T, int m, int n, Plan* p) {
 }
 
 template <int TJ>
-hipError_t launch_ti(const Plan& p, const float* X, const float* dY, int64_t T, int m, int n, float* part,
-                     float* bpart, hipStream_t s) {
+hipError_t launch_ti(const Plan& p, const float* X, int64_t ldx, const float* dY, int64_t ldy, int64_t T, int m, int n,
+                     float* part, float* bpart, hipStream_t s) {
   const dim3 grid((p.nwaves + 3) / 4), block(256);
   switch (p.ti) {
-    case 1: hipLaunchKernelGGL((linear_wgrad_partial_k<TJ, 1>), grid, block, 0, s, X, dY, T, m, n, part, bpart, p.rows_per_wave, p.nwaves); break;
-    case 2: hipLaunchKernelGGL((linear_wgrad_partial_k<TJ, 2>), grid, block, 0, s, X, dY, T, m, n, part, bpart, p.rows_per_wave, p.nwaves); break;
-    case 3: hipLaunchKernelGGL((linear_wgrad_partial_k<TJ, 3>), grid, block, 0, s, X, dY, T, m, n, part, bpart, p.rows_per_wave, p.nwaves); break;
-    case 4: hipLaunchKernelGGL((linear_wgrad_partial_k<TJ, 4>), grid, block, 0, s, X, dY, T, m, n, part, bpart, p.rows_per_wave, p.nwaves); break;
+    case 1: hipLaunchKernelGGL((linear_wgrad_partial_k<TJ, 1>), grid, block, 0, s, X, ldx, dY, ldy, T, m, n, part, bpart, p.rows_per_wave, p.nwaves); break;
+    case 2: hipLaunchKernelGGL((linear_wgrad_partial_k<TJ, 2>), grid, block, 0, s, X, ldx, dY, ldy, T, m, n, part, bpart, p.rows_per_wave, p.nwaves); break;
+    case 3: hipLaunchKernelGGL((linear_wgrad_partial_k<TJ, 3>), grid, block, 0, s, X, ldx, dY, ldy, T, m, n, part, bpart, p.rows_per_wave, p.nwaves); break;
+    case 4: hipLaunchKernelGGL((linear_wgrad_partial_k<TJ, 4>), grid, block, 0, s, X, ldx, dY, ldy, T, m, n, part, bpart, p.rows_per_wave, p.nwaves); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -253,9 +253,15 @@ int64_t psf_linear_wgrad_workspace(int64_t T, int32_t m, int32_t n) {
 
 int psf_linear_wgrad_f32(const float* X, const float* dY, int64_t T, int32_t m, int32_t n, float* dWt, float* db,
                          void* workspace, int64_t workspace_bytes, void* stream) {
+  return psf_linear_wgrad_strided_f32(X, m, dY, n, T, m, n, dWt, db, workspace, workspace_bytes, stream);
+}
+
+int psf_linear_wgrad_strided_f32(const float* X, int64_t ldx, const float* dY, int64_t ldy, int64_t T, int32_t m, int32_t n,
+                                 float* dWt, float* db, void* workspace, int64_t workspace_bytes, void* stream) {
   if (!X || !dY || !dWt || !workspace) return psf_internal_fail(PSF_E_NULL, "psf_linear_wgrad: X, dY, dWt and workspace must be non-NULL");
   Plan p;
   if (!make_plan(T, m, n, &p)) return psf_internal_fail(PSF_E_SHAPE, "psf_linear_wgrad: need T >= 1 and 1 <= m, n <= 128");
+  if (ldx < m || ldy < n) return psf_internal_fail(PSF_E_SHAPE, "psf_linear_wgrad: row strides must be >= the row lengths");
   if (workspace_bytes < (p.part_floats + p.bpart_floats) * (int64_t)sizeof(float))
     return psf_internal_fail(PSF_E_SHAPE, "psf_linear_wgrad: workspace smaller than psf_linear_wgrad_workspace(T, m, n)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -263,10 +269,10 @@ int psf_linear_wgrad_f32(const float* X, const float* dY, int64_t T, int32_t m, 
   float* bpart = part + p.part_floats;
   hipError_t e;
   switch (p.tj) {
-    case 1: e = launch_ti<1>(p, X, dY, T, m, n, part, bpart, s); break;
-    case 2: e = launch_ti<2>(p, X, dY, T, m, n, part, bpart, s); break;
-    case 3: e = launch_ti<3>(p, X, dY, T, m, n, part, bpart, s); break;
-    case 4: e = launch_ti<4>(p, X, dY, T, m, n, part, bpart, s); break;
+    case 1: e = launch_ti<1>(p, X, ldx, dY, ldy, T, m, n, part, bpart, s); break;
+    case 2: e = launch_ti<2>(p, X, ldx, dY, ldy, T, m, n, part, bpart, s); break;
+    case 3: e = launch_ti<3>(p, X, ldx, dY, ldy, T, m, n, part, bpart, s); break;
+    case 4: e = launch_ti<4>(p, X, ldx, dY, ldy, T, m, n, part, bpart, s); break;
     default: return psf_internal_fail(PSF_E_SHAPE, "psf_linear_wgrad: unsupported tile count");
   }
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));

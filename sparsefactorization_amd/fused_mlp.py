@@ -11,6 +11,11 @@ M+1 of them to the same ``data`` (psf.py:165,175).
 
 ``eligible`` (no gradient needed) / ``trainable`` (gradient needed) say whether a call can take these kernels;
 MLPs of another form, fp64, E > 64 (E > 32 when training), h > 128, out > 32 or CPU tensors use the stock modules.
+
+``stackable`` / ``stacked_apply`` cover the widths the kernels do not (ListOps: E = 512, out = 128) with library
+GEMMs laid out for them: the M+1 first layers share their input, so they run as ONE Linear(E, sum h) — one GEMM
+forward, one GEMM for the input gradient (K = sum h, instead of M+1 GEMMs plus M accumulations of a [T, E]
+tensor) and one for the weight gradient; GELU and its backward are one kernel each.
 """
 from __future__ import annotations
 
@@ -18,6 +23,7 @@ import ctypes
 from typing import List, Optional, Sequence
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
@@ -166,3 +172,32 @@ def fused_mlp_apply(x: torch.Tensor, blocks: Sequence[nn.Module]) -> List[torch.
     x2 = x.reshape(-1, E).contiguous()
     ys = _FusedMLPFn.apply(x2, *_params_of(blocks))
     return [y.reshape(*lead, y.shape[1]) for y in ys]
+
+
+def stackable(x: torch.Tensor, blocks: Sequence[nn.Module]) -> bool:
+    """GPU call of >= 2 two-layer MLPs that share their input and that the fused kernels do not take."""
+    if not enabled or not x.is_cuda or len(blocks) < 2 or x.dim() < 2:
+        return False
+    pairs = [_two_layer(b) for b in blocks]
+    return all(p is not None and p[0].in_features == x.shape[-1] and p[0].weight.dtype == x.dtype for p in pairs)
+
+
+def stacked_apply(x: torch.Tensor, blocks: Sequence[nn.Module]) -> List[torch.Tensor]:
+    """[block(x) for block in blocks] with the first layers stacked into one Linear (autograd-transparent: the
+    parameters stay the modules' own tensors; ``torch.cat`` routes their gradients back)."""
+    pairs = [_two_layer(b) for b in blocks]
+    lead, E = x.shape[:-1], x.shape[-1]
+    x2 = x.reshape(-1, E)
+    hidden = F.gelu(F.linear(x2, torch.cat([l1.weight for l1, _ in pairs], 0), torch.cat([l1.bias for l1, _ in pairs], 0)))
+    parts = hidden.split([l1.out_features for l1, _ in pairs], dim=-1)  # column slices: GEMM operands with lda = sum h
+    from .token_linear import _TokenLinearFn, wgrad_supported  # (token_linear imports nothing from here)
+    outs = []
+    for p, (_, l2) in zip(parts, pairs):
+        # second-layer weight gradients are [out x T] * [T x h] reductions into a tiny tile: on the tall-skinny MFMA
+        # kernel (reads the slice with its row stride) where it applies — 135 us each through hipBLASLt at ListOps sizes
+        if torch.is_grad_enabled() and l2.weight.requires_grad and wgrad_supported(p, l2.out_features):
+            y = _TokenLinearFn.apply(p, l2.weight, l2.bias)
+        else:
+            y = F.linear(p, l2.weight, l2.bias)
+        outs.append(y.reshape(*lead, l2.out_features))
+    return outs

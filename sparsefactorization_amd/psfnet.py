@@ -110,6 +110,8 @@ class _ChordMixer(nn.Module):
             return fused_mlp.fused_mlp_forward(data, fs)
         if fused_mlp.trainable(data, fs):
             return fused_mlp.fused_mlp_apply(data, fs)
+        if fused_mlp.stackable(data, fs):
+            return fused_mlp.stacked_apply(data, fs)
         return [f(data) for f in fs]
 
     def produce(self, data: torch.Tensor):
@@ -125,6 +127,9 @@ class _ChordMixer(nn.Module):
             return outs[0], outs[1:]
         if fused_mlp.trainable(data, blocks):
             outs = fused_mlp.fused_mlp_apply(data, blocks)
+            return outs[0], outs[1:]
+        if fused_mlp.stackable(data, blocks):
+            outs = fused_mlp.stacked_apply(data, blocks)
             return outs[0], outs[1:]
         return self.g(data), self.link_weights(data)
 

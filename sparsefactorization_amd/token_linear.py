@@ -32,15 +32,19 @@ def linear_wgrad(x2d: torch.Tensor, dy2d: torch.Tensor, need_bias: bool = True):
     ws_bytes = lib.psf_linear_wgrad_workspace(T, m, n)
     if ws_bytes < 0:
         raise ValueError(f"psf_linear_wgrad does not support T={T}, m={m}, n={n}")
-    x2d, dy2d = x2d.contiguous(), dy2d.contiguous()
+    # column slices of a wider row-major array (unit inner stride) are taken as they are, with their row stride
+    if x2d.stride(1) != 1 or x2d.stride(0) < m:
+        x2d = x2d.contiguous()
+    if dy2d.stride(1) != 1 or dy2d.stride(0) < n:
+        dy2d = dy2d.contiguous()
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x2d.device)
     dW = torch.empty((n, m), dtype=torch.float32, device=x2d.device)
     db = torch.empty(n, dtype=torch.float32, device=x2d.device) if need_bias else None
     with torch.cuda.device(x2d.device):
-        rc = lib.psf_linear_wgrad_f32(x2d.data_ptr(), dy2d.data_ptr(), T, m, n, dW.data_ptr(),
-                                      db.data_ptr() if db is not None else None, ws.data_ptr(), ws_bytes,
-                                      torch.cuda.current_stream(x2d.device).cuda_stream)
-    _lib.check(rc, "psf_linear_wgrad_f32")
+        rc = lib.psf_linear_wgrad_strided_f32(x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), T, m, n,
+                                              dW.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(),
+                                              ws_bytes, torch.cuda.current_stream(x2d.device).cuda_stream)
+    _lib.check(rc, "psf_linear_wgrad_strided_f32")
     return dW, db
 
 

@@ -156,6 +156,31 @@ def test_fused_mlp_backward_partial_outputs_and_frozen_input(gpu):
         assert all(float(p.grad.abs().max()) == 0.0 for p in b.parameters())
 
 
+def test_stacked_first_layer_matches_per_module_path(gpu):
+    """ListOps widths (E = 512, out = 128: outside the fused kernels): stacking the first layers into one Linear
+    is the same function and has the same gradients as calling the modules one by one."""
+    import copy
+    from sparsefactorization_amd import fused_mlp
+    from sparsefactorization_amd.psfnet import MLPBlock
+    torch.manual_seed(11)
+    blocks = [MLPBlock([128, 'GELU'], 512, o).to(gpu) for o in (128, 12, 12, 12)]
+    refs = [copy.deepcopy(b).double() for b in blocks]
+    x = torch.randn(2, 3001, 512, device=gpu, requires_grad=True)
+    xr = x.detach().double().requires_grad_(True)
+    assert fused_mlp.stackable(x, blocks) and not fused_mlp.trainable(x, blocks) and not fused_mlp.eligible(x, blocks)
+    ys = fused_mlp.stacked_apply(x, blocks)
+    yr = [b(xr) for b in refs]
+    gys = [torch.randn_like(y) for y in ys]
+    torch.autograd.backward(ys, gys)
+    torch.autograd.backward(yr, [g.double() for g in gys])
+    for y, r in zip(ys, yr):
+        assert y.shape == r.shape and rel_inf(y.detach().cpu().numpy(), r.detach().cpu().numpy()) <= 1e-5
+    assert rel_inf(x.grad.cpu().numpy(), xr.grad.cpu().numpy()) <= 2e-5
+    for b, rb in zip(blocks, refs):
+        for p, rp in zip(b.parameters(), rb.parameters()):
+            assert rel_inf(p.grad.cpu().numpy(), rp.grad.cpu().numpy()) <= 2e-5
+
+
 def test_fused_mlp_leading_dims_and_ineligible_forms(gpu):
     from sparsefactorization_amd import fused_mlp
     from sparsefactorization_amd.psfnet import MLPBlock
