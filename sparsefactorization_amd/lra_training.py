@@ -20,12 +20,11 @@ import os
 import time
 
 import torch
-from torch import nn, optim
-from torch.utils.data import DataLoader
+from torch import nn
 
 from . import dp
 from .lra_psf import PSFNet
-from .train import DatasetCreator, TrainPSF, count_params, seed_everything, train_epoch
+from .train import DeviceBatches, TrainPSF, count_params, make_adam, seed_everything, train_epoch
 
 config = {
     "listops": {
@@ -119,7 +118,7 @@ def main(argv=None):
     if rank == 0:
         print('Number of trainable parameters', count_params(net))
     loss = nn.CrossEntropyLoss()
-    optimizer = optim.Adam(net.parameters(), lr=cfg_training['learning_rate'])
+    optimizer = make_adam(net.parameters(), cfg_training['learning_rate'])
     reducer = dp.FlatGradAllReduce(net.parameters()) if world > 1 else None
 
     splits = {}
@@ -135,8 +134,7 @@ def main(argv=None):
         if cfg_model['pooling_type'] == 'CLS':
             X = add_cls_token(X, cfg_model['vocab_size'])
         splits[split] = (X, Y)
-    mk = lambda s, shuffle: DataLoader(DatasetCreator(*splits[s]), batch_size=batch, shuffle=shuffle,  # noqa: E731
-                                       drop_last=True, num_workers=0)
+    mk = lambda s, shuffle: DeviceBatches(*splits[s], batch, shuffle=shuffle, drop_last=True)  # noqa: E731
     trainloader, valloader, testloader = mk("train", True), mk("val", False), mk("test", False)
 
     if args.json:

@@ -7,7 +7,8 @@
 Same model construction as the reference driver (psf_training.py:29-45: ``n_W = int(log2(n_vec))``, config keys
 of synthetic_training_config.py), same optimiser / loss choice (50-58), ``seed_everything(42)`` (16),
 ``drop_last=True`` loaders (80-114). What changes: data come from the on-device generators
-(``synth_data``: there are no ``.pt`` files here), the loaders are ``torch.utils.data.DataLoader`` (the
+(``synth_data``: there are no ``.pt`` files here), the loaders are ``train.DeviceBatches`` — DataLoader semantics for
+tensors that already sit on the GPU, without the per-sample collate (the
 reference's ``torch_geometric.data.DataLoader`` is a subclass that adds nothing for tensor pairs), and under
 ``torch.distributed.run`` every rank trains on its shard of each global batch with ONE flat gradient
 all-reduce per step (``dp.FlatGradAllReduce``, RCCL over xGMI).
@@ -20,12 +21,11 @@ import time
 
 import numpy as np
 import torch
-from torch import nn, optim
-from torch.utils.data import DataLoader
+from torch import nn
 
 from . import dp, synth_data
 from .synthetic_psf import PSFNet
-from .train import DatasetCreator, TrainModel, count_params, seed_everything, train_epoch
+from .train import DeviceBatches, TrainModel, count_params, make_adam, seed_everything, train_epoch
 
 # PSF entries of SyntheticExperiments/synthetic_training_config.py (same keys and values)
 config = {
@@ -85,7 +85,7 @@ def main(argv=None):
     dp.broadcast_parameters(net)
     if rank == 0:
         print('Number of trainable parameters', count_params(net))
-    optimizer = optim.Adam(net.parameters(), lr=cfg_training["learning_rate"])
+    optimizer = make_adam(net.parameters(), cfg_training["learning_rate"])
     loss = nn.MSELoss() if args.problem == "adding" else nn.CrossEntropyLoss()
     reducer = dp.FlatGradAllReduce(net.parameters()) if world > 1 else None
 
@@ -94,8 +94,7 @@ def main(argv=None):
     Xtr, Ytr = make_split(args.problem, hi - lo, args.n_vec, device, 1000 + rank)
     Xva, Yva = make_split(args.problem, args.eval_seqs, args.n_vec, device, 2000)
     Xte, Yte = make_split(args.problem, args.eval_seqs, args.n_vec, device, 3000)
-    mk = lambda X, Y, shuffle: DataLoader(DatasetCreator(X, Y), batch_size=batch, shuffle=shuffle,  # noqa: E731
-                                          drop_last=True, num_workers=0)
+    mk = lambda X, Y, shuffle: DeviceBatches(X, Y, batch, shuffle=shuffle, drop_last=True)  # noqa: E731
     trainloader, valloader, testloader = mk(Xtr, Ytr, True), mk(Xva, Yva, False), mk(Xte, Yte, False)
 
     if args.json:

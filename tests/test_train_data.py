@@ -132,3 +132,29 @@ def test_training_driver_runs_on_gpu(gpu, capsys):
                        "--epochs", "1"])
     out = capsys.readouterr().out
     assert "Training loss" in out and "Test accuracy" in out
+
+
+def test_device_batches_has_dataloader_semantics():
+    """DeviceBatches vs DataLoader(DatasetCreator, batch_size, shuffle, drop_last): same number of batches, same
+    shapes, every sample at most once per epoch, sequential order when not shuffled, a new order every epoch."""
+    from sparsefactorization_amd.train import DeviceBatches
+    X, Y = torch.arange(23, dtype=torch.float32).reshape(23, 1), torch.arange(23)
+    for drop_last in (True, False):
+        ref = DataLoader(DatasetCreator(X, Y), batch_size=5, shuffle=False, drop_last=drop_last)
+        mine = DeviceBatches(X, Y, 5, shuffle=False, drop_last=drop_last)
+        assert len(mine) == len(ref)
+        for (xa, ya), (xb, yb) in zip(mine, ref):
+            assert torch.equal(xa, xb) and torch.equal(ya, yb)
+    sh = DeviceBatches(X, Y, 5, shuffle=True, drop_last=True)
+    e1 = torch.cat([y for _, y in sh])
+    e2 = torch.cat([y for _, y in sh])
+    assert e1.numel() == 20 and e1.unique().numel() == 20 and not torch.equal(e1, e2)
+    for x, y in sh:
+        assert torch.equal(x.squeeze(1).long(), y)  # samples and labels stay paired
+
+
+def test_make_adam_is_plain_adam_on_cpu():
+    from sparsefactorization_amd.train import make_adam
+    lin = torch.nn.Linear(3, 2)
+    opt = make_adam(lin.parameters(), 0.01)
+    assert isinstance(opt, torch.optim.Adam) and opt.defaults["lr"] == 0.01 and not opt.defaults.get("fused")
