@@ -29,6 +29,7 @@
 #include <stdint.h>
 
 #include "../../include/psf_chord.h"
+#include "mlp_fwd_x3.h"
 
 #include <atomic>
 
@@ -332,7 +333,9 @@ extern "C" {
 int64_t psf_mlp_fwd_workspace(int32_t E, int32_t K, const int32_t* h, const int32_t* O) {
   Plan p;
   if (!make_plan(E, K, h, O, &p)) return -1;
-  return (int64_t)K * p.img_floats * (int64_t)sizeof(float);
+  const int64_t f32_bytes = (int64_t)K * p.img_floats * (int64_t)sizeof(float);
+  const int64_t x3_bytes = psf_x3_mlp_fwd_workspace(E, K, h, O);  // -1: that variant does not cover these sizes
+  return x3_bytes > f32_bytes ? x3_bytes : f32_bytes;
 }
 
 int psf_mlp_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float* const* A, const float* const* a,
@@ -344,9 +347,19 @@ int psf_mlp_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   if (T < 1 || !make_plan(E, K, h, O, &p))
     return psf_internal_fail(PSF_E_SHAPE, "psf_mlp_fwd: need T >= 1, E in {4,8,...,64}, 1 <= K <= 32, 1 <= h <= 128, 1 <= O <= 32");
   if ((reinterpret_cast<uintptr_t>(X) & 15) != 0) return psf_internal_fail(PSF_E_ALIGN, "psf_mlp_fwd: X must be 16-byte aligned");
-  if (workspace_bytes < (int64_t)K * p.img_floats * (int64_t)sizeof(float) ||
-      (reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
+  if (workspace_bytes < psf_mlp_fwd_workspace(E, K, h, O) || (reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
     return psf_internal_fail(PSF_E_SHAPE, "psf_mlp_fwd: workspace too small (psf_mlp_fwd_workspace) or not 16-byte aligned");
+  for (int k = 0; k < K; ++k)
+    if (!A[k] || !a[k] || !B[k] || !b[k] || !Y[k]) return psf_internal_fail(PSF_E_NULL, "psf_mlp_fwd: NULL layer pointer");
+  const int variant = psf_g_mlp_variant.load();
+  // Split-bf16 variant (mlp_fwd_x3.hip): the same result to f32 accuracy on the bf16 matrix pipe, which overlaps
+  // with the VALU work; default wherever it applies (E <= 32).
+  const bool x3_ok = psf_x3_mlp_fwd_workspace(E, K, h, O) >= 0;
+  if (variant == 3 && !x3_ok) return psf_internal_fail(PSF_E_TUNING, "psf_mlp_fwd: mlp_variant=3 needs E <= 32");
+  if (x3_ok && (variant == 0 || variant == 3)) {
+    const hipError_t e3 = psf_x3_mlp_fwd_launch(X, T, E, K, A, a, B, b, h, O, Y, workspace, reinterpret_cast<hipStream_t>(stream));
+    return e3 == hipSuccess ? PSF_OK : psf_internal_fail((int)e3, hipGetErrorString(e3));
+  }
   MlpArgs args;
   args.X = X;
   args.images = reinterpret_cast<float*>(workspace);
@@ -355,10 +368,7 @@ int psf_mlp_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   args.K = K;
   args.hp_max = p.hp_max;
   args.img_floats = p.img_floats;
-  for (int k = 0; k < K; ++k) {
-    if (!A[k] || !a[k] || !B[k] || !b[k] || !Y[k]) return psf_internal_fail(PSF_E_NULL, "psf_mlp_fwd: NULL layer pointer");
-    args.d[k] = MlpDesc{A[k], a[k], B[k], b[k], Y[k], h[k], O[k]};
-  }
+  for (int k = 0; k < K; ++k) args.d[k] = MlpDesc{A[k], a[k], B[k], b[k], Y[k], h[k], O[k]};
   for (int k = K; k < kMaxMlps; ++k) args.d[k] = MlpDesc{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(mlp_pack_k, dim3(K), dim3(256), 0, s, args, p.ep);
@@ -366,7 +376,6 @@ int psf_mlp_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
 
   const int64_t tiles = (T + 31) / 32;
-  const int variant = psf_g_mlp_variant.load();
   if (variant == 2 && !p.lds_resident_bytes)
     return psf_internal_fail(PSF_E_TUNING, "psf_mlp_fwd: mlp_variant=2 but the K weight images do not fit in LDS");
   // Tiles per wave: as many as the registers allow (4 at EP = 32, 2 at EP = 64) when T is large; fewer for short

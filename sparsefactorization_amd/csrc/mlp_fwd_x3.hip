@@ -1,0 +1,441 @@
+// mlp_fwd_x3.hip — the fused producer-MLP forward of mlp_fwd.hip on the bf16 matrix pipe, at f32 accuracy.
+//
+// Why: v_mfma_f32_32x32x2_f32 shares the vector ALU's datapath — MFMA cycles and VALU cycles ADD (profiles/
+// r01_mfmalab.log: 64-cycle MFMA + 14 VALU = 130 cycles per SIMD at any occupancy), which pins mlp_fwd.hip at
+// 32 x 64 + ~1500 cycles per tile-MLP. v_mfma_f32_32x32x16_bf16 runs on the separate matrix pipe (32 cycles, of
+// which 8 hold the vector issue) and overlaps with VALU work (same log: 40-cycle MFMA + 16 VALU = 76 cycles).
+//
+// How f32 accuracy survives bf16 operands: every f32 operand v is split EXACTLY into three bf16 terms by
+// truncation, v = v1 + v2 + v3 (8 + 8 + 8 significant bits: v1 = v & 0xffff0000, v2 = (v - v1) & 0xffff0000,
+// v3 = v - v1 - v2; each subtraction is exact), and a product x*w is accumulated in f32 as the six terms of
+// magnitude >= 2^-16 |x w|:  x3 w1 + x2 w2 + x1 w3 + x2 w1 + x1 w2 + x1 w1  (small terms first). The three
+// dropped terms are <= 2^-23 |x w| together — the size of one f32 rounding of the product. Per GEMM of K = 32
+// that is 2 k-steps x 6 = 12 MFMAs of 32 cycles instead of 16 of 64, on a pipe that leaves the VALU free for the
+// GELU and the splitting (4 VALU + 1.5 v_perm per value).
+//
+// Structure (as mlp_fwd.hip): a wave owns TPW tiles of 32 tokens and keeps X's split B-operand fragments in
+// registers for all MLPs; a hidden layer wider than 32 is processed as 32-row units whose second-GEMM results
+// accumulate in the same registers; weights are packed once per call into LDS images (already split, already in
+// operand order) and stream through two LDS buffers by LDS-DMA, one barrier per unit.
+//   GEMM1  H^T[j][tok] = A_u X^T: A operand = 8 consecutive e of row j (one ds_read_b128 per term and k-step)
+//   GELU on the accumulator registers, then split + pack: register r of lane (tok, half) is hidden row
+//          rho(r, half) = (r&3) + 8(r>>2) + 4 half, so registers 8s..8s+7 ARE the lane's B-operand fragment of
+//          k-step s for the second GEMM if the weights are packed in the same order (accumulator-as-operand)
+//   GEMM2  Y^T[o][tok] += B_u[o][rho] H^T: A operand prepacked as [s][half][o][8]
+// Limits of this variant: E <= 32 (multiple of 4), h <= 128, O <= 32, K <= 32.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/psf_chord.h"
+#include "mlp_fwd_x3.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+// unit image (bytes): A terms 3 x [32 j][80 B: 32 bf16 + pad] | sa 32 f32 | B' terms 3 x [2 s][2 half][32 o][8 bf16]
+// | sb 32 f32
+constexpr int kARow = 80;                  // bytes; 20-dword stride: ds_read_b128 conflict-free over 16 lanes
+constexpr int kATerm = 32 * kARow;         // 2560
+constexpr int kOffSa = 3 * kATerm;         // 7680
+constexpr int kOffB = kOffSa + 128;        // 7808
+constexpr int kBTerm = 2 * 2 * 32 * 16;    // 2048
+constexpr int kOffSb = kOffB + 3 * kBTerm; // 13952
+constexpr int kImgBytes = kOffSb + 128;    // 14080
+constexpr int kImgVecs = kImgBytes / 16;   // 880
+constexpr int kScr = 32 * 36;              // per-wave scratch floats: X staging [tok][36], Y transpose [tok][33]
+
+struct X3Mlp {
+  const float* A;
+  const float* a;
+  const float* B;
+  const float* b;
+  float* Y;
+  int32_t h, O;
+};
+
+struct X3Args {
+  X3Mlp m[32];
+  uint8_t unit_k[128], unit_hb[128], unit_last[128];  // unit -> (MLP, hidden block, last unit of its MLP)
+  const float* X;
+  unsigned char* images;
+  int64_t T;
+  int32_t E, U;
+};
+
+__device__ __forceinline__ int cd_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// exact three-way truncation split; the results are f32 bit patterns whose low 16 bits are zero
+__device__ __forceinline__ void split3(float v, uint32_t& t1, uint32_t& t2, uint32_t& t3) {
+  t1 = __float_as_uint(v) & 0xffff0000u;
+  const float r1 = v - __uint_as_float(t1);
+  t2 = __float_as_uint(r1) & 0xffff0000u;
+  t3 = __float_as_uint(r1 - __uint_as_float(t2));
+}
+
+// eight f32 bit patterns (low halves zero) -> their bf16 high halves, element i in bits [16 (i&1), +16) of dword i/2
+__device__ __forceinline__ bf16x8 pack8(const uint32_t (&w)[8]) {
+  uint4 d;
+  d.x = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
+  d.y = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+  d.z = __builtin_amdgcn_perm(w[5], w[4], 0x07060302u);
+  d.w = __builtin_amdgcn_perm(w[7], w[6], 0x07060302u);
+  return __builtin_bit_cast(bf16x8, d);
+}
+
+struct Frag3 {  // the three terms of one 8-element operand fragment
+  bf16x8 t1, t2, t3;
+};
+
+__device__ __forceinline__ Frag3 split_pack8(const float (&v)[8]) {
+  uint32_t a[8], b[8], c[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) split3(v[i], a[i], b[i], c[i]);
+  Frag3 f;
+  f.t1 = pack8(a);
+  f.t2 = pack8(b);
+  f.t3 = pack8(c);
+  return f;
+}
+
+// acc += sum of the six kept terms of (weights w) x (activations x), smallest first
+__device__ __forceinline__ f32x16 mfma6(const Frag3& w, const Frag3& x, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.t1, x.t3, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.t2, x.t2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.t3, x.t1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.t1, x.t2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.t2, x.t1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.t1, x.t1, acc, 0, 0, 0);
+  return acc;
+}
+
+// GELU(x) = x Phi(x) for a PAIR of values, on packed f32 math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two
+// elements per instruction — the kernel is VALU-issue-bound, rocprofv3: ~70 % VALU-busy, 22 % matrix-pipe-busy).
+// Phi by Abramowitz & Stegun 26.2.17 (the normal-CDF form of 7.1.26, |error| <= 7.5e-8):
+//   t = 1 / (1 + 0.2316419 |x|),  q = exp(-x^2/2)/sqrt(2 pi) * (b1 t + ... + b5 t^5),  Phi = x >= 0 ? 1 - q : q
+// with 1/sqrt(2 pi) folded into the b's and exp as exp2(x^2 * -0.5 log2 e): 19 instructions per pair.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+  f32x2 t;
+  t.x = __builtin_amdgcn_rcpf(fmaf(fabsf(x.x), 0.2316419f, 1.0f));
+  t.y = __builtin_amdgcn_rcpf(fmaf(fabsf(x.y), 0.2316419f, 1.0f));
+  const f32x2 B5 = {0.53070271f, 0.53070271f}, B4 = {-0.72657602f, -0.72657602f}, B3 = {0.71070687f, 0.71070687f},
+              B2 = {-0.14224837f, -0.14224837f}, B1 = {0.12741479f, 0.12741479f};
+  f32x2 p = __builtin_elementwise_fma(B5, t, B4);
+  p = __builtin_elementwise_fma(p, t, B3);
+  p = __builtin_elementwise_fma(p, t, B2);
+  p = __builtin_elementwise_fma(p, t, B1);
+  p = p * t;
+  const f32x2 c2 = {-0.72134752044448170368f, -0.72134752044448170368f};
+  const f32x2 arg = (x * x) * c2;
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(arg.x);
+  e.y = __builtin_amdgcn_exp2f(arg.y);
+  const f32x2 half2 = {0.5f, 0.5f};
+  f32x2 dlt = half2 - p * e;  // 0.5 - q >= 0
+  dlt.x = copysignf(dlt.x, x.x);
+  dlt.y = copysignf(dlt.y, x.y);
+  return x * (half2 + dlt);  // Phi = 0.5 + sign(x) (0.5 - q)
+}
+
+__device__ __forceinline__ uint16_t bf16_bits(uint32_t f32_pattern) { return (uint16_t)(f32_pattern >> 16); }
+
+// One workgroup per unit: split the weights and write them in operand order.
+__global__ void __launch_bounds__(256) x3_pack_k(const X3Args a) {
+  const int u = blockIdx.x;
+  const X3Mlp d = a.m[a.unit_k[u]];
+  const int ht = 32 * a.unit_hb[u], E = a.E;
+  unsigned char* img = a.images + (size_t)u * kImgBytes;
+  uint16_t* img16 = reinterpret_cast<uint16_t*>(img);
+  float* img32 = reinterpret_cast<float*>(img);
+  // A terms: [j][e]
+  for (int i = threadIdx.x; i < 32 * 40; i += 256) {
+    const int j = i / 40, e = i - j * 40;
+    const float v = (e < E && ht + j < d.h) ? d.A[(ht + j) * E + e] : 0.f;
+    uint32_t t1, t2, t3;
+    split3(v, t1, t2, t3);
+    img16[(0 * kATerm + j * kARow) / 2 + e] = bf16_bits(t1);
+    img16[(1 * kATerm + j * kARow) / 2 + e] = bf16_bits(t2);
+    img16[(2 * kATerm + j * kARow) / 2 + e] = bf16_bits(t3);
+  }
+  for (int j = threadIdx.x; j < 32; j += 256) {
+    img32[kOffSa / 4 + j] = ht + j < d.h ? d.a[ht + j] : 0.f;
+    img32[kOffSb / 4 + j] = j < d.O ? d.b[j] : 0.f;
+  }
+  // B' terms: [s][half][o][i] = B[o][ht + rho], rho = (i&3) + 16 s + 8 (i>>2) + 4 half
+  for (int q = threadIdx.x; q < 2 * 2 * 32 * 8; q += 256) {
+    const int i = q & 7, o = (q >> 3) & 31, hf = (q >> 8) & 1, s = q >> 9;
+    const int rho = (i & 3) + 16 * s + 8 * (i >> 2) + 4 * hf;
+    const float v = (o < d.O && ht + rho < d.h) ? d.B[o * d.h + ht + rho] : 0.f;
+    uint32_t t1, t2, t3;
+    split3(v, t1, t2, t3);
+    img16[(kOffB + 0 * kBTerm) / 2 + q] = bf16_bits(t1);
+    img16[(kOffB + 1 * kBTerm) / 2 + q] = bf16_bits(t2);
+    img16[(kOffB + 2 * kBTerm) / 2 + q] = bf16_bits(t3);
+  }
+}
+
+template <int TPW>
+__global__ void __launch_bounds__(256, 2)  // <= 256 registers: two workgroups (two waves per SIMD) per CU
+x3_fwd_k(const X3Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int c = lane & 31, half = lane >> 5;
+  float* sw = reinterpret_cast<float*>(lds_raw + 2 * kImgBytes) + wv * (TPW * kScr);  // TPW tiles of [32][36]
+  const int E = a.E, U = a.U;
+  const int64_t tiles = (a.T + 31) / 32;
+  const int64_t tiles_per_block = 4 * TPW;
+
+  auto stage = [&](int u) {
+    const unsigned char* src = a.images + (size_t)u * kImgBytes;
+    unsigned char* dst = lds_raw + (u & 1) * kImgBytes;
+    for (int v0 = 0; v0 < kImgVecs; v0 += 256) {
+      const int v = v0 + tid;
+      if (v < kImgVecs)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * v),
+                                         (__attribute__((address_space(3))) void*)(dst + 16 * (v0 + (tid & ~63))), 16, 0, 0);
+    }
+  };
+
+  for (int64_t blk = blockIdx.x; blk * tiles_per_block < tiles; blk += gridDim.x) {
+    Frag3 xf[TPW][2];  // X fragments: k-step s covers e = 16 s + 8 half + (0..7) of the lane's token
+    f32x16 acc2[TPW];
+    int64_t t0[TPW];
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+      t0[tp] = (blk * tiles_per_block + wv * TPW + tp) * 32;
+      const int64_t rows_left = a.T - t0[tp];
+      const int nflt = (int)(rows_left >= 32 ? 32 : (rows_left > 0 ? rows_left : 0)) * E;
+      const float* xt = a.X + t0[tp] * E;
+      for (int f = 4 * lane; f < 32 * E; f += 256) {  // coalesced 16-byte loads of the contiguous tile
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < nflt) v = *reinterpret_cast<const float4*>(xt + f);
+        const int tok = f / E, col = f - tok * E;
+        *reinterpret_cast<float4*>(sw + tok * 36 + col) = v;  // E % 4 == 0: 16-byte aligned, never straddles a row
+      }
+      if (E < 32)
+        for (int i = lane; i < 32 * 8; i += 64) {  // zero the columns >= E (groups of 4)
+          const int tok = i >> 3, col = 4 * (i & 7);
+          if (col >= E) *reinterpret_cast<float4*>(sw + tok * 36 + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float4 lo = *reinterpret_cast<const float4*>(sw + c * 36 + 16 * s + 8 * half);
+        const float4 hi = *reinterpret_cast<const float4*>(sw + c * 36 + 16 * s + 8 * half + 4);
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        xf[tp][s] = split_pack8(v);
+      }
+    }
+    __syncthreads();  // the previous block's last unit is done with both image buffers
+    stage(0);
+
+    // Deferred Y stores. The vmcnt(0) that hipcc puts before every barrier (needed for the LDS-DMA) also waits for
+    // whatever global stores the wave has in flight: stores issued at the END of a unit made every barrier wait a
+    // full write latency (0.27 of 0.69 ms in an ablation). A finished Y^T tile is therefore parked in the wave's
+    // LDS tile buffer and its global stores are issued at the START of the next unit, a whole unit of arithmetic
+    // ahead of the next barrier.
+    int pend = -1;  // MLP whose Y tiles are parked in sw (wave-uniform)
+    // Element e = lane + 64 i of a tile's burst sits at sw[tok * 33 + o], (tok, o) = divmod(e, O). The offsets depend
+    // on O only (two values per block in PSFNet: g, then the link MLPs), so they are kept in registers: stepping
+    // them per element cost ~200 integer instructions per tile in a kernel that is VALU-issue-bound.
+    int yoff[8], yoff_O = -1;
+    auto flush = [&]() {
+      const X3Mlp& dp = a.m[pend];
+      const int O = dp.O;
+      if (O != yoff_O) {  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int e = lane + 64 * i, tok = e / O;
+          yoff[i] = (tok < 32 ? tok : 31) * 33 + (e - tok * O);  // clamped: lanes past the tile read a valid address
+        }
+        yoff_O = O;
+      }
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) {
+        if (t0[tp] >= a.T) continue;  // wave-uniform
+        const float* st = sw + tp * kScr;
+        const int64_t rem = a.T - t0[tp];
+        const int n_el = (int)(rem < 32 ? rem : 32) * O;  // one contiguous burst of rows*O floats
+        float* __restrict__ yt = dp.Y + t0[tp] * O;
+        // all LDS reads of a batch of 8 are issued before its first store (a rolled loop paid one LDS round trip per
+        // element)
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = st[yoff[i]];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (lane + 64 * i < n_el) yt[lane + 64 * i] = v[i];
+        for (int e = lane + 512; e < n_el; e += 64) {  // O > 16 only
+          const int tok = e / O;
+          yt[e] = st[tok * 33 + (e - tok * O)];
+        }
+      }
+      pend = -1;
+    };
+
+    for (int u = 0; u < U; ++u) {
+      __syncthreads();  // image u has landed (hipcc drains vmcnt before the barrier); unit u-1 is finished
+      if (u + 1 < U) stage(u + 1);
+      if (pend >= 0) flush();
+      const unsigned char* img = lds_raw + (u & 1) * kImgBytes;
+      const float* sa = reinterpret_cast<const float*>(img + kOffSa);
+      const float* sb = reinterpret_cast<const float*>(img + kOffSb);
+      const bool first = a.unit_hb[u] == 0, last = a.unit_last[u] != 0;
+
+      // weight fragments of this unit (shared by the wave's tiles)
+      Frag3 wa[2], wb[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const unsigned char* pa = img + c * kARow + 32 * s + 16 * half;
+        wa[s].t1 = *reinterpret_cast<const bf16x8*>(pa);
+        wa[s].t2 = *reinterpret_cast<const bf16x8*>(pa + kATerm);
+        wa[s].t3 = *reinterpret_cast<const bf16x8*>(pa + 2 * kATerm);
+        const unsigned char* pb = img + kOffB + ((s * 2 + half) * 32 + c) * 16;
+        wb[s].t1 = *reinterpret_cast<const bf16x8*>(pb);
+        wb[s].t2 = *reinterpret_cast<const bf16x8*>(pb + kBTerm);
+        wb[s].t3 = *reinterpret_cast<const bf16x8*>(pb + 2 * kBTerm);
+      }
+
+      if (first) {
+#pragma unroll
+        for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc2[tp][r] = sb[cd_row(r, half)];
+      }
+      auto half_gelu = [&](const f32x16& acc1, int s) {  // GELU + split of registers 8s..8s+7: one B fragment
+        float g[8];
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+          const f32x2 y = gelu2(f32x2{acc1[8 * s + i], acc1[8 * s + i + 1]});
+          g[i] = y.x;
+          g[i + 1] = y.y;
+        }
+        return split_pack8(g);
+      };
+
+      if constexpr (TPW == 2) {
+        // Software pipeline over the wave's two tiles, ONE basic block. A dependent MFMA blocks the wave's in-order
+        // issue until its predecessor retires, so matrix-pipe work only overlaps with VALU work when the two are
+        // interleaved in the instruction stream: the 12 MFMAs of tile 1's first GEMM are spread through the GELU +
+        // split of tile 0's first half, and each 6-MFMA k-step of the second GEMM through the GELU + split of the
+        // next half (sched_group_barrier: 1 MFMA, then a share of the VALU instructions). Tiles past the end of X
+        // hold zeros and are computed like the others (stores are predicated).
+        f32x16 h0, h1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h0[r] = h1[r] = sa[cd_row(r, half)];
+        h0 = mfma6(wa[0], xf[0][0], h0);
+        h0 = mfma6(wa[1], xf[0][1], h0);
+        h1 = mfma6(wa[0], xf[1][0], h1);
+        h1 = mfma6(wa[1], xf[1][1], h1);
+        const Frag3 f00 = half_gelu(h0, 0);
+        acc2[0] = mfma6(wb[0], f00, acc2[0]);
+        const Frag3 f01 = half_gelu(h0, 1);
+        acc2[0] = mfma6(wb[1], f01, acc2[0]);
+        const Frag3 f10 = half_gelu(h1, 0);
+        acc2[1] = mfma6(wb[0], f10, acc2[1]);
+        const Frag3 f11 = half_gelu(h1, 1);
+        acc2[1] = mfma6(wb[1], f11, acc2[1]);
+        // desired order: 12 MFMA (tile 0, GEMM 1) | 12 x {1 MFMA, 17 VALU} | 3 x 6 x {1 MFMA, 34 VALU} | 6 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 17, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 34, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      } else {
+#pragma unroll
+        for (int tp = 0; tp < TPW; ++tp) {
+          f32x16 acc1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc1[r] = sa[cd_row(r, half)];
+          acc1 = mfma6(wa[0], xf[tp][0], acc1);
+          acc1 = mfma6(wa[1], xf[tp][1], acc1);
+          acc2[tp] = mfma6(wb[0], half_gelu(acc1, 0), acc2[tp]);
+          acc2[tp] = mfma6(wb[1], half_gelu(acc1, 1), acc2[tp]);
+        }
+      }
+
+      if (last) {  // park the Y^T tiles as [tok][o] (stride 33); stored at the start of the next unit
+#pragma unroll
+        for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sw[tp * kScr + c * 33 + cd_row(r, half)] = acc2[tp][r];
+        pend = a.unit_k[u];
+      }
+    }
+    if (pend >= 0) flush();
+  }
+}
+
+struct Plan {
+  int U;
+  uint8_t unit_k[128], unit_hb[128], unit_last[128];
+};
+
+bool make_plan(int32_t E, int32_t K, const int32_t* h, const int32_t* O, Plan* p) {
+  if (E < 4 || E > 32 || (E & 3) || K < 1 || K > 32 || !h || !O) return false;
+  p->U = 0;
+  for (int k = 0; k < K; ++k) {
+    if (h[k] < 1 || h[k] > 128 || O[k] < 1 || O[k] > 32) return false;
+    const int nb = (h[k] + 31) / 32;
+    for (int hb = 0; hb < nb; ++hb) {
+      p->unit_k[p->U] = (uint8_t)k;
+      p->unit_hb[p->U] = (uint8_t)hb;
+      p->unit_last[p->U] = hb == nb - 1;
+      ++p->U;
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
+int64_t psf_x3_mlp_fwd_workspace(int32_t E, int32_t K, const int32_t* h, const int32_t* O) {
+  Plan p;
+  if (!make_plan(E, K, h, O, &p)) return -1;
+  return (int64_t)p.U * kImgBytes;
+}
+
+hipError_t psf_x3_mlp_fwd_launch(const float* X, int64_t T, int32_t E, int32_t K, const float* const* A,
+                                 const float* const* a, const float* const* B, const float* const* b, const int32_t* h,
+                                 const int32_t* O, float* const* Y, void* workspace, hipStream_t s) {
+  Plan p;
+  if (!make_plan(E, K, h, O, &p)) return hipErrorInvalidValue;
+  X3Args args;
+  for (int k = 0; k < 32; ++k) args.m[k] = X3Mlp{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+  for (int k = 0; k < K; ++k) args.m[k] = X3Mlp{A[k], a[k], B[k], b[k], Y[k], h[k], O[k]};
+  for (int u = 0; u < 128; ++u) {
+    args.unit_k[u] = u < p.U ? p.unit_k[u] : 0;
+    args.unit_hb[u] = u < p.U ? p.unit_hb[u] : 0;
+    args.unit_last[u] = u < p.U ? p.unit_last[u] : 0;
+  }
+  args.X = X;
+  args.images = reinterpret_cast<unsigned char*>(workspace);
+  args.T = T;
+  args.E = E;
+  args.U = p.U;
+  hipLaunchKernelGGL(x3_pack_k, dim3(p.U), dim3(256), 0, s, args);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const int64_t tiles = (T + 31) / 32;
+  int tpw = 2;
+  while (tpw > 1 && (tiles + 4 * tpw - 1) / (4 * tpw) < 512) tpw >>= 1;
+  const int64_t blocks_needed = (tiles + 4 * tpw - 1) / (4 * tpw);
+  const int grid = (int)(blocks_needed < 4096 ? blocks_needed : 4096);
+  const size_t lds = 2 * (size_t)kImgBytes + 4 * (size_t)tpw * kScr * sizeof(float);
+  if (tpw == 2) {
+    e = hipFuncSetAttribute((const void*)x3_fwd_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((x3_fwd_k<2>), dim3(grid), dim3(256), lds, s, args);
+  } else {
+    hipLaunchKernelGGL((x3_fwd_k<1>), dim3(grid), dim3(256), lds, s, args);
+  }
+  return hipGetLastError();
+}

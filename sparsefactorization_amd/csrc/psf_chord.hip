@@ -52,7 +52,8 @@ std::atomic<int> g_chain_cc{0};     // fused chain: 0 = auto channel groups per 
 std::atomic<int> g_fwd_wide{0};
 
 }  // namespace
-// Fused producer MLPs (mlp_fwd.hip): 0 = auto (all images LDS-resident when they fit), 1 = streaming, 2 = resident
+// Fused producer MLPs: 0 = auto (split-bf16 kernel of mlp_fwd_x3.hip where it applies, else the f32-MFMA kernel of
+// mlp_fwd.hip with all images LDS-resident when they fit), 1 = f32 MFMA streaming, 2 = f32 MFMA resident, 3 = split-bf16
 std::atomic<int> psf_g_mlp_variant{0};
 namespace {
 
@@ -67,7 +68,7 @@ Knob g_knobs[] = {
     {"fwd_wide", &g_fwd_wide, 0, 2},
     {"chain_fused", &g_chain_fused, 0, 1},
     {"chain_cc", &g_chain_cc, 0, 1},
-    {"mlp_variant", &psf_g_mlp_variant, 0, 2},
+    {"mlp_variant", &psf_g_mlp_variant, 0, 3},
 };
 
 int ceil_log2(int64_t x) {
