@@ -76,21 +76,34 @@ struct BwdArgs {
 
 __device__ __forceinline__ int cd_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
-// y = GELU(x) (erf form) and dy/dx = Phi(x) + x phi(x); erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7),
-// whose exp(-x^2/2) is also phi(x) sqrt(2 pi).
-__device__ __forceinline__ void gelu_and_grad(float x, float& y, float& dydx) {
-  const float s = x * 0.70710678118654752440f;
-  const float ax = fabsf(s);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __expf(-ax * ax);
-  const float erf = copysignf(fmaf(-p * t, e, 1.0f), s);
-  const float Phi = fmaf(0.5f, erf, 0.5f);
+// y = GELU(x) = x Phi(x) and dy/dx = Phi(x) + x phi(x) for a PAIR of values on packed f32 math (v_pk_fma_f32 /
+// v_pk_mul_f32: two elements per instruction; here VALU cycles add to the f32-MFMA cycles). Phi by Abramowitz &
+// Stegun 26.2.17 (|error| <= 7.5e-8): t = 1/(1 + 0.2316419 |x|), q = phi(x) (b1 t + ... + b5 t^5), Phi = x >= 0 ?
+// 1 - q : q, with 1/sqrt(2 pi) folded into the b's; E = exp(-x^2/2) = phi(x) sqrt(2 pi) serves both results.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ void gelu_and_grad2(f32x2 x, f32x2& y, f32x2& dydx) {
+  f32x2 t;
+  t.x = __builtin_amdgcn_rcpf(fmaf(fabsf(x.x), 0.2316419f, 1.0f));
+  t.y = __builtin_amdgcn_rcpf(fmaf(fabsf(x.y), 0.2316419f, 1.0f));
+  const f32x2 B5 = {0.53070271f, 0.53070271f}, B4 = {-0.72657602f, -0.72657602f}, B3 = {0.71070687f, 0.71070687f},
+              B2 = {-0.14224837f, -0.14224837f}, B1 = {0.12741479f, 0.12741479f};
+  f32x2 p = __builtin_elementwise_fma(B5, t, B4);
+  p = __builtin_elementwise_fma(p, t, B3);
+  p = __builtin_elementwise_fma(p, t, B2);
+  p = __builtin_elementwise_fma(p, t, B1);
+  p = p * t;
+  const f32x2 c2 = {-0.72134752044448170368f, -0.72134752044448170368f};
+  const f32x2 arg = (x * x) * c2;
+  f32x2 E;
+  E.x = __builtin_amdgcn_exp2f(arg.x);
+  E.y = __builtin_amdgcn_exp2f(arg.y);
+  const f32x2 half2 = {0.5f, 0.5f}, inv_sqrt_2pi = {0.39894228040143267794f, 0.39894228040143267794f};
+  f32x2 dlt = half2 - p * E;  // 0.5 - q >= 0
+  dlt.x = copysignf(dlt.x, x.x);
+  dlt.y = copysignf(dlt.y, x.y);
+  const f32x2 Phi = half2 + dlt;
   y = x * Phi;
-  dydx = fmaf(x * 0.39894228040143267794f, e, Phi);
+  dydx = __builtin_elementwise_fma(x * inv_sqrt_2pi, E, Phi);
 }
 
 __global__ void __launch_bounds__(256) mlp_bwd_pack_k(const BwdArgs a) {
@@ -282,11 +295,13 @@ mlp_bwd_k(const BwdArgs a) {
         // 3. GELU and its derivative; Hpost^T -> S2[j][tok]
         float g[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float y, dy;
-          gelu_and_grad(acc1[r], y, dy);
-          S2[cd_row(r, half) * 33 + c] = y;
-          g[r] = acc3[r] * dy;  // G = dHpre^T
+        for (int r = 0; r < 16; r += 2) {
+          f32x2 y, dy;
+          gelu_and_grad2(f32x2{acc1[r], acc1[r + 1]}, y, dy);
+          S2[cd_row(r, half) * 33 + c] = y.x;
+          S2[cd_row(r + 1, half) * 33 + c] = y.y;
+          g[r] = acc3[r] * dy.x;  // G = dHpre^T
+          g[r + 1] = acc3[r + 1] * dy.y;
         }
         // 4. dB^T += Hpost^T[j = c][tok = 2kk+half] · dY[tok = 2kk+half][o = c]
         {
