@@ -93,8 +93,64 @@ def test_argument_validation_returns_codes_not_crashes(lib):
     assert c(None, None, None, 0, 0, 1, 8, 4, 4, 32, None, None) == 0          # M == 0
 
 
+def test_producer_entry_points_validate_before_touching_the_gpu(lib):
+    """psf_mlp_fwd_f32 / psf_mlp_bwd_f32 / psf_linear_wgrad_strided_f32: sizes outside the kernels' limits, NULL
+    tables and short workspaces come back as PSF_E_* codes (no HIP call has been made at that point)."""
+    i32, vp = ctypes.c_int32, ctypes.c_void_p
+    one, two = vp(16), vp(32)
+
+    def arr(vals):
+        return (i32 * len(vals))(*vals)
+
+    def ptrs(n, v=16):
+        return (vp * n)(*([v] * n))
+
+    h, O = arr([32, 32, 128]), arr([8, 15, 32])
+    fwd_ws = lib.psf_mlp_fwd_workspace(32, 3, h, O)
+    assert fwd_ws > 0 and fwd_ws % 16 == 0
+    assert lib.psf_mlp_fwd_workspace(64, 3, h, O) > 0             # E = 64: f32-MFMA variant only
+    assert lib.psf_mlp_fwd_workspace(68, 3, h, O) == -1            # E > 64
+    assert lib.psf_mlp_fwd_workspace(30, 3, h, O) == -1            # E not a multiple of 4
+    assert lib.psf_mlp_fwd_workspace(32, 33, h, O) == -1           # K > 32
+    assert lib.psf_mlp_fwd_workspace(32, 3, arr([32, 129, 32]), O) == -1   # h > 128
+    assert lib.psf_mlp_fwd_workspace(32, 3, h, arr([8, 33, 8])) == -1      # out > 32
+    f = lib.psf_mlp_fwd_f32
+    tabs = [ptrs(3) for _ in range(5)]
+    assert f(None, 100, 32, 3, tabs[0], tabs[1], tabs[2], tabs[3], h, O, tabs[4], two, fwd_ws, None) == -1
+    assert f(one, 0, 32, 3, tabs[0], tabs[1], tabs[2], tabs[3], h, O, tabs[4], two, fwd_ws, None) == -2       # T < 1
+    assert f(vp(20), 100, 32, 3, tabs[0], tabs[1], tabs[2], tabs[3], h, O, tabs[4], two, fwd_ws, None) == -4  # X alignment
+    assert f(one, 100, 32, 3, tabs[0], tabs[1], tabs[2], tabs[3], h, O, tabs[4], two, fwd_ws - 16, None) == -2
+    assert b"workspace" in lib.psf_last_error()
+    assert f(one, 100, 32, 3, (vp * 3)(16, None, 16), tabs[1], tabs[2], tabs[3], h, O, tabs[4], two, fwd_ws, None) == -1
+
+    bwd_ws = lib.psf_mlp_bwd_workspace(100000, 32, 3, h, O)
+    assert bwd_ws > 0
+    assert lib.psf_mlp_bwd_workspace(100000, 64, 3, h, O) == -1    # the backward covers E <= 32
+    assert lib.psf_mlp_bwd_workspace(0, 32, 3, h, O) == -1
+    # the partial-sum buffer grows with T: one slot per workgroup of 4 waves x 1 or 2 tiles
+    assert lib.psf_mlp_bwd_workspace(10 ** 6, 32, 3, h, O) > bwd_ws
+    g = lib.psf_mlp_bwd_f32
+    t = [ptrs(3) for _ in range(8)]
+    assert g(one, 100000, 32, 3, t[0], t[1], t[2], h, O, t[3], two, t[4], t[5], t[6], t[7], two, bwd_ws - 16, None) == -2
+    assert g(one, 100000, 32, 3, t[0], t[1], t[2], h, O, None, two, t[4], t[5], t[6], t[7], two, bwd_ws, None) == -1
+    assert g(one, 100000, 32, 3, t[0], t[1], t[2], h, O, (vp * 3)(16, 16, None), two, t[4], t[5], t[6], t[7], two,
+             bwd_ws, None) == -1
+    assert b"NULL" in lib.psf_last_error()
+
+    s = lib.psf_linear_wgrad_strided_f32
+    assert s(one, 31, one, 15, 1 << 20, 32, 15, two, None, two, 1 << 30, None) == -2   # ldx < m
+    assert s(one, 480, one, 14, 1 << 20, 32, 15, two, None, two, 1 << 30, None) == -2  # ldy < n
+    assert b"strides" in lib.psf_last_error()
+
+
 def test_tuning_knobs(lib):
     import sparsefactorization_amd as sfa
+    assert sfa.get_tuning("mlp_variant") == 0
+    sfa.set_tuning("mlp_variant", 3)
+    assert sfa.get_tuning("mlp_variant") == 3
+    sfa.set_tuning("mlp_variant", 0)
+    with pytest.raises(sfa.PSFLibraryError):
+        sfa.set_tuning("mlp_variant", 4)
     assert sfa.get_tuning("fwd_variant") == 0
     sfa.set_tuning("fwd_variant", 1)
     assert "generic" in sfa.describe_fwd(64, 16384, 15, 8)
