@@ -155,6 +155,16 @@ int psf_linear_wgrad_strided_f32(const float* X, int64_t ldx, const float* dY, i
                                  float* dWt, float* db, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * Token embedding fused with the positional-embedding add — the first two lines of PSFNet.forward
+ * (SyntheticExperiments/psf.py:152-163, LRA/psf.py:203-214):
+ *     out[t,:] = table[idx[t],:] (+ pos[t mod N,:])        t < T = B*N
+ *   idx [T] int64 token ids (ids outside [0,V) are clamped: never an out-of-bounds read), table [V,E],
+ *   pos [N,E] or NULL, out [T,E]; E a multiple of 4; table, pos, out 16-byte aligned. One pass over the output.
+ */
+int psf_embed_tokens_f32(const int64_t* idx, const float* table, const float* pos, float* out, int64_t T, int64_t N,
+                         int32_t V, int32_t E, void* stream);
+
+/*
  * Producer side, forward (inference): K two-layer token-wise MLPs sharing one input, fused in one launch —
  * g and fs[0..M) of PSFNet (MLPBlock = Linear, GELU, Linear; SyntheticExperiments/psf.py:35-60,110-126,165,175):
  *     Y[k][t,:] = GELU(X[t,:] * A[k]^T + a[k]) * B[k]^T + b[k]          (erf GELU as torch.nn.GELU(); erf is

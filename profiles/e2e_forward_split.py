@@ -37,11 +37,14 @@ def main():
         with torch.no_grad():
             def embed():
                 d = X
-                if problem == "order":
-                    d = net.embedding(d).squeeze(-2)
+                pos_done = False
+                if problem == "order":  # as PSFNet.forward: lookup + positional add in one pass
+                    from sparsefactorization_amd.token_linear import embed_tokens
+                    pos_done = net.use_pos_embedding and not net.add_init_linear_layer
+                    d = embed_tokens(d.squeeze(-1), net.embedding, net.pos_embedding.weight if pos_done else None)
                 if net.add_init_linear_layer:
                     d = net.init_linear(d)
-                if net.use_pos_embedding:
+                if net.use_pos_embedding and not pos_done:
                     d = d + net.pos_embedding.weight.unsqueeze(0)
                 return d
             data = embed()

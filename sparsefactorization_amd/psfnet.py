@@ -32,7 +32,7 @@ from torch import nn
 
 from . import fused_mlp
 from .chord import chord_chain, chord_spmm, get_chord_indices_assym
-from .token_linear import TokenEmbedding, TokenLinear
+from .token_linear import TokenEmbedding, TokenLinear, embed_tokens
 
 LayerSpec = Sequence[Union[str, int]]
 
@@ -178,11 +178,17 @@ class SyntheticPSFNet(_ChordMixer):
         self._build_indices(n_vec, self.n_links, use_cuda)
 
     def forward(self, data):
+        pos_done = False
         if self.problem == 'order':
-            data = self.embedding(data).squeeze(-2)
+            if data.dim() == 3 and data.size(-1) == 1:
+                # lookup and positional add in one pass; pos_embedding(arange(n_vec)) per sample == its weight
+                pos_done = self.use_pos_embedding and not self.add_init_linear_layer
+                data = embed_tokens(data.squeeze(-1), self.embedding, self.pos_embedding.weight if pos_done else None)
+            else:
+                data = self.embedding(data).squeeze(-2)
         if self.add_init_linear_layer:
             data = self.init_linear(data)
-        if self.use_pos_embedding:
+        if self.use_pos_embedding and not pos_done:
             data = data + self.pos_embedding.weight.unsqueeze(0)  # == pos_embedding(arange(n_vec)) per sample
         V, links = self.produce(data)
         V = self.mix(data, V, self.use_residuals, links)
@@ -243,9 +249,7 @@ class _TokenPSFNet(_ChordMixer):
     def features(self, data, links=None):
         """Everything up to and including the chain and dropout3: returns V [B,N,C]. When ``links`` is a
         list it is filled with the W_m that were used."""
-        data = self.embedding(data)
-        if self.use_pos_embedding:
-            data = data + self.pos_embedding.weight.unsqueeze(0)
+        data = embed_tokens(data, self.embedding, self.pos_embedding.weight if self.use_pos_embedding else None)
         data = self.dropout1(data)
         V, produced = self.produce(data)
         V = self.dropout2(V)
@@ -325,7 +329,7 @@ class AttentionBlockPSF(_ChordMixer):
         self.apc_embedding = nn.Embedding(max_seq_len, embedding_size)
 
     def forward(self, data):
-        data = self.embedding(data) + self.apc_embedding.weight.unsqueeze(0)
+        data = embed_tokens(data, self.embedding, self.apc_embedding.weight)
         data = self.dropout1(data)
         V, links = self.produce(data)
         V = self.mix(data, self.dropout2(V), self.use_residuals, links)

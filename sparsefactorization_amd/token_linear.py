@@ -89,6 +89,63 @@ class _TokenEmbeddingFn(torch.autograd.Function):
         return None, dW, None
 
 
+class _EmbedTokensFn(torch.autograd.Function):
+    """out = weight[idx] (+ pos broadcast over the batch) in one pass (csrc/embed.hip). Gradients: the table's by
+    the one-hot tall-skinny kernel when it applies, else PyTorch's ``embedding_dense_backward``; pos's is the sum of
+    the output gradient over the batch."""
+
+    @staticmethod
+    def forward(ctx, idx, weight, pos, padding_idx):
+        lib = _lib.load()
+        V, E = weight.shape
+        idx_c = idx.contiguous()
+        T = idx_c.numel()
+        N = pos.shape[0] if pos is not None else 1
+        out = torch.empty(*idx.shape, E, dtype=torch.float32, device=idx.device)
+        w, p = weight.detach().contiguous(), (pos.detach().contiguous() if pos is not None else None)
+        with torch.cuda.device(idx.device):
+            rc = lib.psf_embed_tokens_f32(idx_c.data_ptr(), w.data_ptr(), p.data_ptr() if p is not None else None,
+                                          out.data_ptr(), T, N, V, E, torch.cuda.current_stream(idx.device).cuda_stream)
+        _lib.check(rc, "psf_embed_tokens_f32")
+        ctx.save_for_backward(idx_c)
+        ctx.vocab, ctx.padding_idx, ctx.has_pos, ctx.n_pos = V, padding_idx, pos is not None, N
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        E = dout.shape[-1]
+        dW = dpos = None
+        if ctx.needs_input_grad[1]:
+            d2 = dout.reshape(-1, E)
+            if ctx.vocab <= MAX_WIDTH and E <= MAX_WIDTH and d2.shape[0] >= MIN_TOKENS:
+                onehot = torch.nn.functional.one_hot(idx.reshape(-1), ctx.vocab).to(torch.float32)
+                dWt, _ = linear_wgrad(onehot, d2, need_bias=False)  # [E, vocab]
+                dW = dWt.t().contiguous()
+                if ctx.padding_idx is not None and ctx.padding_idx >= 0:
+                    dW[ctx.padding_idx].zero_()
+            else:
+                pad = -1 if ctx.padding_idx is None else ctx.padding_idx
+                dW = torch.ops.aten.embedding_dense_backward(dout.contiguous(), idx, ctx.vocab, pad, False)
+        if ctx.has_pos and ctx.needs_input_grad[2]:
+            dpos = dout.reshape(-1, ctx.n_pos, E).sum(0)
+        return None, dW, dpos, None
+
+
+def embed_tokens(idx: torch.Tensor, embedding: nn.Embedding, pos: torch.Tensor = None) -> torch.Tensor:
+    """``embedding(idx) + pos.unsqueeze(0)`` (``pos`` [N, E] with N = idx.shape[-1], or None) — the opening lines of
+    every PSFNet.forward. One fused pass on the GPU for plain fp32 embeddings; anything else (CPU, max_norm, sparse
+    gradients, E not a multiple of 4) takes the stock modules."""
+    w = embedding.weight
+    if (idx.is_cuda and idx.dtype == torch.int64 and w.dtype == torch.float32 and w.shape[1] % 4 == 0
+            and embedding.max_norm is None and not embedding.scale_grad_by_freq and not embedding.sparse
+            and (pos is None or (pos.dtype == torch.float32 and pos.dim() == 2 and pos.shape[0] == idx.shape[-1]
+                                 and pos.shape[1] == w.shape[1]))):
+        return _EmbedTokensFn.apply(idx, w, pos, embedding.padding_idx)
+    out = embedding(idx)
+    return out if pos is None else out + pos.unsqueeze(0)
+
+
 class TokenEmbedding(nn.Embedding):
     """Drop-in ``nn.Embedding`` (same parameters / state_dict / forward values) for small vocabularies looked up
     at ~1e6 positions; larger vocabularies, CPU tensors and exotic options use the stock path."""

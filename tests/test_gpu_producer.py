@@ -67,6 +67,35 @@ def test_token_embedding_is_a_drop_in_for_nn_embedding(gpu, vocab, padding_idx):
         assert float(mine.weight.grad[padding_idx].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("vocab,E,N,B,padding_idx,with_pos", [
+    (6, 32, 4096, 5, None, True),      # Temporal Order: 6 tokens, positional embedding
+    (225, 32, 1024, 8, 223, True),     # Pathfinder: vocabulary beyond the one-hot kernel -> dense backward
+    (17, 512, 2000, 3, 15, False),     # ListOps: wide rows, no positional term
+    (97, 32, 4097, 2, 95, True),       # IMDb: odd sequence length
+])
+def test_embed_tokens_matches_embedding_plus_positional_add(gpu, vocab, E, N, B, padding_idx, with_pos):
+    """psf_embed_tokens_f32 (lookup + positional add in one pass) vs nn.Embedding followed by the broadcast add:
+    the forward is the same single f32 addition, hence bit-identical; gradients to 1e-5."""
+    from sparsefactorization_amd.token_linear import embed_tokens
+    torch.manual_seed(vocab)
+    emb = torch.nn.Embedding(vocab, E, padding_idx=padding_idx).to(gpu)
+    pos = torch.nn.Embedding(N, E).to(gpu) if with_pos else None
+    idx = torch.randint(0, vocab, (B, N), device=gpu)
+    got = embed_tokens(idx, emb, pos.weight if with_pos else None)
+    ref = emb(idx) + (pos.weight.unsqueeze(0) if with_pos else 0)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    gy = torch.randn_like(ref)
+    g_ref = torch.autograd.grad(ref, [emb.weight] + ([pos.weight] if with_pos else []), gy)
+    g_got = torch.autograd.grad(got, [emb.weight] + ([pos.weight] if with_pos else []), gy)
+    for a, b in zip(g_got, g_ref):
+        assert rel_inf(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5
+    if padding_idx is not None:
+        assert float(g_got[0][padding_idx].abs().max()) == 0.0
+    # no-grad call and a [B, N, 1]-shaped Order input squeezed by the caller take the same path
+    with torch.no_grad():
+        assert torch.equal(embed_tokens(idx, emb, pos.weight if with_pos else None), ref)
+
+
 MLP_CASES = [  # (T, E, [(h, out), ...])
     (64 * 1024, 32, [(32, 8)] + [(32, 15)] * 14),       # Adding/Order: g + 14 link MLPs
     (4097 * 3, 32, [(128, 32)] + [(128, 13)] * 12),     # IMDb / Pathfinder widths
