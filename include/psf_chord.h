@@ -163,6 +163,16 @@ int psf_linear_wgrad_strided_f32(const float* X, int64_t ldx, const float* dY, i
  */
 int psf_embed_tokens_f32(const int64_t* idx, const float* table, const float* pos, float* out, int64_t T, int64_t N,
                          int32_t V, int32_t E, void* stream);
+/*
+ * Its gradient with respect to the table:  dTable[v,:] = sum over {t : idx[t] == v} of dOut[t,:]   (fully written;
+ * the caller zeroes a padding row). No sort, no atomics, no host read-back: deterministic (a fixed order of
+ * additions) and capturable in a HIP graph, unlike the sort-and-partition backward of nn.Embedding.
+ *   1 <= V <= 512, 1 <= E <= 4096; `workspace`: at least psf_embed_tokens_bwd_workspace(T, V, E) bytes (-1 for
+ *   unsupported sizes).
+ */
+int64_t psf_embed_tokens_bwd_workspace(int64_t T, int32_t V, int32_t E);
+int psf_embed_tokens_bwd_f32(const int64_t* idx, const float* dOut, int64_t T, int32_t V, int32_t E, float* dTable,
+                             void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * Producer side, forward (inference): K two-layer token-wise MLPs sharing one input, fused in one launch —

@@ -4,11 +4,15 @@ does replaying it buy on the launch-bound small models?
 
     python profiles/graph_step_lab.py pathfinder
 
-RESULT (round 1, profiles/r01_graph_step_lab.log): capture succeeds and the first replays reproduce the eager
-losses exactly, but a later replay faults (memory aperture violation) inside PyTorch's own
-aten::embedding_dense_backward (rocprim partition kernel whose sizes were read back to the host at capture
-time). DO NOT re-run on a shared box as is: nn.Embedding's backward must first be replaced by a capture-safe
-kernel. Kept as a record of the experiment; the training drivers do not use graphs.
+RESULTS (round 1):
+* first attempt (profiles/r01_graph_step_lab.log): capture succeeded and the first replays reproduced the eager
+  losses exactly, but a later replay faulted (memory aperture violation) inside PyTorch's own
+  aten::embedding_dense_backward (rocprim partition kernel whose sizes were read back to the host at capture time).
+* after the table gradient moved to psf_embed_tokens_bwd_f32 (no sort, no host read-back;
+  profiles/r01_graph_step_lab2.log): 48 replays with changing batches, no fault, loss after 8 steps 0.060913 vs
+  0.060912 eager; Pathfinder 2.11 ms/step eager (foreach Adam) -> 1.37 ms/step replayed.
+The guard below stays: the script replays a captured graph of a WHOLE step on whatever the installed PyTorch does for
+every op in it, and one non-capturable op is a GPU fault, not an exception. train.GraphedStep is the supported form.
 """
 import copy
 import os

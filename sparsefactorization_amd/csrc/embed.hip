@@ -56,3 +56,116 @@ extern "C" int psf_embed_tokens_f32(const int64_t* idx, const float* table, cons
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? PSF_OK : psf_internal_fail((int)e, hipGetErrorString(e));
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Gradient of the table:  dTable[v, :] = sum over the tokens t with idx[t] == v of dOut[t, :]
+// ------------------------------------------------------------------------------------------------------
+// PyTorch's embedding_dense_backward sorts the indices and partitions them (rocprim) with sizes read back to the
+// host: 0.1-0.26 ms per step on the LRA models, and not capturable in a HIP graph (a replay faulted in round 1,
+// profiles/r01_graph_step_lab.log). Here ONE WAVE per (token slice, 64-column chunk) walks its tokens in order and
+// accumulates into a private LDS table [V][64]: every table element has a single owner lane, so the sum over a
+// slice is a fixed sequence of additions — no atomics, no sort, deterministic — and the slices are summed in a fixed
+// order by a second kernel. Rows narrower than 64 floats put 64/E' tokens side by side in sub-tables (E' = E
+// rounded up to a power of two), combined at the end.
+namespace {
+
+constexpr int kEmbSlicesMax = 2048;
+constexpr int kEmbTokensPerSlice = 128;
+
+__global__ void __launch_bounds__(64)
+embed_bwd_partial_k(const int64_t* __restrict__ idx, const float* __restrict__ dOut, int64_t T, int32_t V, int32_t E,
+                    int32_t ep_log2, int64_t tokens_per_slice, float* __restrict__ part) {
+  extern __shared__ float tab[];  // [subs][V][ep], subs * ep == 64
+  const int lane = threadIdx.x;
+  const int ep = 1 << ep_log2, subs = 64 >> ep_log2;
+  const int sub = lane >> ep_log2, col = lane & (ep - 1);
+  const int c = blockIdx.y * 64 + col;
+  const bool active = c < E;
+  for (int i = lane; i < V * 64; i += 64) tab[i] = 0.f;
+  const int64_t t0 = (int64_t)blockIdx.x * tokens_per_slice;
+  const int64_t t1 = t0 + tokens_per_slice < T ? t0 + tokens_per_slice : T;
+  float* mine = tab + (size_t)sub * V * ep + col;
+  constexpr int U = 8;  // tokens in flight per sub-table (one wave per workgroup: loads in flight hide the latency)
+  for (int64_t t = t0 + sub; t < t1; t += (int64_t)U * subs) {
+    int v[U];
+    float g[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t tu = t + (int64_t)u * subs;
+      const bool ok = tu < t1;
+      int64_t vv = ok ? idx[tu] : 0;
+      vv = vv < 0 ? 0 : (vv >= V ? V - 1 : vv);
+      v[u] = (int)vv;
+      g[u] = (ok && active) ? dOut[tu * E + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) mine[v[u] * ep] += g[u];  // in token order; a single wave's LDS accesses stay ordered
+  }
+  // sub-tables -> one table, in sub order; this slice's partial result
+  float* out = part + (size_t)blockIdx.x * V * E;
+  for (int i = lane; i < V * ep; i += 64) {
+    const int vrow = i >> ep_log2, cc = i & (ep - 1);
+    float s = tab[vrow * ep + cc];
+    for (int q = 1; q < subs; ++q) s += tab[((size_t)q * V + vrow) * ep + cc];
+    const int cg = blockIdx.y * 64 + cc;
+    if (cg < E) out[(size_t)vrow * E + cg] = s;
+  }
+}
+
+// dTable[i] = sum over the slices of part[q][i]. A workgroup owns 32 consecutive elements; its 32 slice lanes each add
+// every 32nd slice in ascending order, then the 32 sub-sums are added in lane order: a fixed association. (With one
+// thread per element the 192 outputs of Temporal Order took 235 us for 1024 dependent loads each.)
+constexpr int kEmbRedLanes = 32;
+__global__ void __launch_bounds__(32 * kEmbRedLanes)
+embed_bwd_reduce_k(const float* __restrict__ part, int32_t slices, int64_t n, float* __restrict__ dTable) {
+  __shared__ float sub[kEmbRedLanes][32];
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + e;
+  float s = 0.f;
+  if (i < n)
+    for (int q = sl; q < slices; q += kEmbRedLanes) s += part[(size_t)q * n + i];
+  sub[sl][e] = s;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    float tot = sub[0][e];
+#pragma unroll
+    for (int q = 1; q < kEmbRedLanes; ++q) tot += sub[q][e];
+    dTable[i] = tot;
+  }
+}
+
+int emb_slices(int64_t T) {
+  const int64_t s = (T + kEmbTokensPerSlice - 1) / kEmbTokensPerSlice;
+  return (int)(s < 1 ? 1 : (s > kEmbSlicesMax ? kEmbSlicesMax : s));
+}
+
+}  // namespace
+
+extern "C" int64_t psf_embed_tokens_bwd_workspace(int64_t T, int32_t V, int32_t E) {
+  if (T < 1 || V < 1 || V > 512 || E < 1 || E > 4096) return -1;
+  return (int64_t)emb_slices(T) * V * E * (int64_t)sizeof(float);
+}
+
+extern "C" int psf_embed_tokens_bwd_f32(const int64_t* idx, const float* dOut, int64_t T, int32_t V, int32_t E,
+                                        float* dTable, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!idx || !dOut || !dTable || !workspace) return psf_internal_fail(PSF_E_NULL, "psf_embed_tokens_bwd: NULL argument");
+  const int64_t need = psf_embed_tokens_bwd_workspace(T, V, E);
+  if (need < 0) return psf_internal_fail(PSF_E_SHAPE, "psf_embed_tokens_bwd: need T >= 1, 1 <= V <= 512, 1 <= E <= 4096");
+  if (workspace_bytes < need) return psf_internal_fail(PSF_E_SHAPE, "psf_embed_tokens_bwd: workspace smaller than psf_embed_tokens_bwd_workspace(T, V, E)");
+  const int slices = emb_slices(T);
+  const int64_t tps = (T + slices - 1) / slices;
+  int ep_log2 = 6;  // columns per sub-table: E rounded up to a power of two, at most 64
+  while (ep_log2 > 0 && (1 << (ep_log2 - 1)) >= E) --ep_log2;
+  const int chunks = (E + 63) / 64;
+  const size_t lds = (size_t)V * 64 * sizeof(float);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipError_t e = hipSuccess;
+  if (lds > 48 * 1024) e = hipFuncSetAttribute((const void*)embed_bwd_partial_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
+  float* part = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(embed_bwd_partial_k, dim3(slices, chunks), dim3(64), lds, s, idx, dOut, T, V, E, ep_log2, tps, part);
+  const int64_t n = (int64_t)V * E;
+  hipLaunchKernelGGL(embed_bwd_reduce_k, dim3((unsigned)((n + 31) / 32)), dim3(32 * kEmbRedLanes), 0, s, part, slices, n, dTable);
+  e = hipGetLastError();
+  return e == hipSuccess ? PSF_OK : psf_internal_fail((int)e, hipGetErrorString(e));
+}

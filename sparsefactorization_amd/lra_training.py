@@ -24,7 +24,7 @@ from torch import nn
 
 from . import dp
 from .lra_psf import PSFNet
-from .train import DeviceBatches, TrainPSF, count_params, make_adam, seed_everything, train_epoch
+from .train import DeviceBatches, GraphedStep, TrainPSF, count_params, make_adam, seed_everything, train_epoch
 
 config = {
     "listops": {
@@ -103,6 +103,8 @@ def main(argv=None):
     ap.add_argument("--data-dir", default=None, help="directory with the reference's *_clean.pt tensors")
     ap.add_argument("--max-steps", type=int, default=None)
     ap.add_argument("--json", action="store_true", help="print one JSON line with training throughput")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the training step in a HIP graph and replay it (single process; train.GraphedStep)")
     args = ap.parse_args(argv)
 
     rank, world, device = dp.init_from_env()
@@ -118,7 +120,9 @@ def main(argv=None):
     if rank == 0:
         print('Number of trainable parameters', count_params(net))
     loss = nn.CrossEntropyLoss()
-    optimizer = make_adam(net.parameters(), cfg_training['learning_rate'])
+    if args.graph and world > 1:
+        raise SystemExit("--graph captures a single-process step (no gradient all-reduce inside the graph)")
+    optimizer = make_adam(net.parameters(), cfg_training['learning_rate'], capturable=args.graph)
     reducer = dp.FlatGradAllReduce(net.parameters()) if world > 1 else None
 
     splits = {}
@@ -137,11 +141,13 @@ def main(argv=None):
     mk = lambda s, shuffle: DeviceBatches(*splits[s], batch, shuffle=shuffle, drop_last=True)  # noqa: E731
     trainloader, valloader, testloader = mk("train", True), mk("val", False), mk("test", False)
 
+    graphed = GraphedStep(net, optimizer, loss, *next(iter(trainloader))) if args.graph else None
+
     if args.json:
-        train_epoch(net, trainloader, optimizer, loss, reducer, max_steps=3)
+        train_epoch(net, trainloader, optimizer, loss, reducer, max_steps=3, graphed=graphed)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        stats = train_epoch(net, trainloader, optimizer, loss, reducer, max_steps=args.max_steps)
+        stats = train_epoch(net, trainloader, optimizer, loss, reducer, max_steps=args.max_steps, graphed=graphed)
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         if rank == 0:
@@ -149,12 +155,13 @@ def main(argv=None):
                               "n_gpus": world, "batch_per_gpu": batch, "steps": stats["steps"],
                               "ms_per_step": dt * 1e3 / max(stats["steps"], 1),
                               "value": world * batch * cfg_model["n_vec"] * stats["steps"] / dt, "unit": "tokens/s",
-                              "loss": stats["loss"], "data": "files" if args.data_dir else "synthetic"}))
+                              "loss": stats["loss"], "data": "files" if args.data_dir else "synthetic",
+                              "hip_graph": bool(args.graph)}))
         return
 
     TrainPSF(net=net, trainloader=trainloader, valloader=valloader, testloader=testloader, n_epochs=epochs,
              test_freq=cfg_training['eval_frequency'], optimizer=optimizer, loss=loss, problem=cfg_model['problem'],
-             saving_criteria=config[args.task]["saving_criteria"], reducer=reducer, is_main=rank == 0)
+             saving_criteria=config[args.task]["saving_criteria"], reducer=reducer, is_main=rank == 0, graphed=graphed)
 
 
 if __name__ == "__main__":

@@ -25,7 +25,7 @@ from torch import nn
 
 from . import dp, synth_data
 from .synthetic_psf import PSFNet
-from .train import DeviceBatches, TrainModel, count_params, make_adam, seed_everything, train_epoch
+from .train import DeviceBatches, GraphedStep, TrainModel, count_params, make_adam, seed_everything, train_epoch
 
 # PSF entries of SyntheticExperiments/synthetic_training_config.py (same keys and values)
 config = {
@@ -71,6 +71,8 @@ def main(argv=None):
     ap.add_argument("--batch-size", type=int, default=None, help="per-rank batch (reference: 40)")
     ap.add_argument("--max-steps", type=int, default=None, help="stop an epoch early (benchmarking)")
     ap.add_argument("--json", action="store_true", help="print one JSON line with training throughput")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the training step in a HIP graph and replay it (single process; train.GraphedStep)")
     args = ap.parse_args(argv)
 
     rank, world, device = dp.init_from_env()
@@ -85,7 +87,9 @@ def main(argv=None):
     dp.broadcast_parameters(net)
     if rank == 0:
         print('Number of trainable parameters', count_params(net))
-    optimizer = make_adam(net.parameters(), cfg_training["learning_rate"])
+    if args.graph and world > 1:
+        raise SystemExit("--graph captures a single-process step (no gradient all-reduce inside the graph)")
+    optimizer = make_adam(net.parameters(), cfg_training["learning_rate"], capturable=args.graph)
     loss = nn.MSELoss() if args.problem == "adding" else nn.CrossEntropyLoss()
     reducer = dp.FlatGradAllReduce(net.parameters()) if world > 1 else None
 
@@ -97,11 +101,13 @@ def main(argv=None):
     mk = lambda X, Y, shuffle: DeviceBatches(X, Y, batch, shuffle=shuffle, drop_last=True)  # noqa: E731
     trainloader, valloader, testloader = mk(Xtr, Ytr, True), mk(Xva, Yva, False), mk(Xte, Yte, False)
 
+    graphed = GraphedStep(net, optimizer, loss, *next(iter(trainloader))) if args.graph else None
+
     if args.json:
-        train_epoch(net, trainloader, optimizer, loss, reducer, max_steps=3)  # warm-up
+        train_epoch(net, trainloader, optimizer, loss, reducer, max_steps=3, graphed=graphed)  # warm-up
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        stats = train_epoch(net, trainloader, optimizer, loss, reducer, max_steps=args.max_steps)
+        stats = train_epoch(net, trainloader, optimizer, loss, reducer, max_steps=args.max_steps, graphed=graphed)
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         if rank == 0:
@@ -109,12 +115,12 @@ def main(argv=None):
                               "n_gpus": world, "batch_per_gpu": batch, "steps": stats["steps"],
                               "ms_per_step": dt * 1e3 / max(stats["steps"], 1),
                               "value": world * batch * args.n_vec * stats["steps"] / dt, "unit": "tokens/s",
-                              "loss": stats["loss"]}))
+                              "loss": stats["loss"], "hip_graph": bool(args.graph)}))
         return
 
     TrainModel(net=net, trainloader=trainloader, valloader=valloader, testloader=testloader, n_epochs=epochs,
                test_freq=cfg_training["eval_frequency"], optimizer=optimizer, loss=loss, problem=args.problem,
-               saving_criteria=99.5, reducer=reducer, is_main=rank == 0)
+               saving_criteria=99.5, reducer=reducer, is_main=rank == 0, graphed=graphed)
 
 
 if __name__ == "__main__":

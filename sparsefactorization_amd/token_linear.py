@@ -68,9 +68,36 @@ class _TokenLinearFn(torch.autograd.Function):
         return dx, dW, db
 
 
+EMB_MAX_VOCAB, EMB_MAX_WIDTH = 512, 4096  # limits of psf_embed_tokens_bwd_f32
+
+
+def embedding_wgrad(idx: torch.Tensor, dout: torch.Tensor, vocab: int, padding_idx) -> torch.Tensor:
+    """d(table) [vocab, E] of ``table[idx]`` given d(out) [..., E]: ``psf_embed_tokens_bwd_f32`` (csrc/embed.hip —
+    per-slice LDS tables with single-owner accumulation, fixed-order reduction: deterministic, no host read-back, so
+    a training step stays capturable in a HIP graph). Vocabularies beyond its LDS table use PyTorch's kernel."""
+    E = dout.shape[-1]
+    d2 = dout.reshape(-1, E).contiguous()
+    T = d2.shape[0]
+    if vocab > EMB_MAX_VOCAB or E > EMB_MAX_WIDTH or dout.dtype != torch.float32 or T == 0:
+        pad = -1 if padding_idx is None else padding_idx
+        return torch.ops.aten.embedding_dense_backward(dout.contiguous(), idx, vocab, pad, False)
+    lib = _lib.load()
+    idx_c = idx.reshape(-1).contiguous()
+    ws_bytes = lib.psf_embed_tokens_bwd_workspace(T, vocab, E)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=d2.device)
+    dW = torch.empty((vocab, E), dtype=torch.float32, device=d2.device)
+    with torch.cuda.device(d2.device):
+        rc = lib.psf_embed_tokens_bwd_f32(idx_c.data_ptr(), d2.data_ptr(), T, vocab, E, dW.data_ptr(), ws.data_ptr(),
+                                          ws_bytes, torch.cuda.current_stream(d2.device).cuda_stream)
+    _lib.check(rc, "psf_embed_tokens_bwd_f32")
+    if padding_idx is not None and padding_idx >= 0:
+        dW[padding_idx].zero_()
+    return dW
+
+
 class _TokenEmbeddingFn(torch.autograd.Function):
-    """weight[idx] whose weight gradient is one_hot(idx)^T @ dOut on the tall-skinny kernel instead of PyTorch's
-    sort-and-scatter (4.5 ms per step for the 6-token vocabulary of Temporal Order at T = 655 360)."""
+    """weight[idx] whose weight gradient runs on ``embedding_wgrad`` instead of PyTorch's sort-and-scatter (4.5 ms
+    per step for the 6-token vocabulary of Temporal Order at T = 655 360)."""
 
     @staticmethod
     def forward(ctx, idx, weight, padding_idx):
@@ -81,18 +108,12 @@ class _TokenEmbeddingFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
-        onehot = torch.nn.functional.one_hot(idx.reshape(-1), ctx.vocab).to(torch.float32)
-        dWt, _ = linear_wgrad(onehot, dout.reshape(-1, dout.shape[-1]), need_bias=False)  # [E, vocab]
-        dW = dWt.t().contiguous()
-        if ctx.padding_idx is not None and ctx.padding_idx >= 0:
-            dW[ctx.padding_idx].zero_()
-        return None, dW, None
+        return None, embedding_wgrad(idx, dout, ctx.vocab, ctx.padding_idx), None
 
 
 class _EmbedTokensFn(torch.autograd.Function):
     """out = weight[idx] (+ pos broadcast over the batch) in one pass (csrc/embed.hip). Gradients: the table's by
-    the one-hot tall-skinny kernel when it applies, else PyTorch's ``embedding_dense_backward``; pos's is the sum of
-    the output gradient over the batch."""
+    ``embedding_wgrad``; pos's is the sum of the output gradient over the batch."""
 
     @staticmethod
     def forward(ctx, idx, weight, pos, padding_idx):
@@ -117,16 +138,7 @@ class _EmbedTokensFn(torch.autograd.Function):
         E = dout.shape[-1]
         dW = dpos = None
         if ctx.needs_input_grad[1]:
-            d2 = dout.reshape(-1, E)
-            if ctx.vocab <= MAX_WIDTH and E <= MAX_WIDTH and d2.shape[0] >= MIN_TOKENS:
-                onehot = torch.nn.functional.one_hot(idx.reshape(-1), ctx.vocab).to(torch.float32)
-                dWt, _ = linear_wgrad(onehot, d2, need_bias=False)  # [E, vocab]
-                dW = dWt.t().contiguous()
-                if ctx.padding_idx is not None and ctx.padding_idx >= 0:
-                    dW[ctx.padding_idx].zero_()
-            else:
-                pad = -1 if ctx.padding_idx is None else ctx.padding_idx
-                dW = torch.ops.aten.embedding_dense_backward(dout.contiguous(), idx, ctx.vocab, pad, False)
+            dW = embedding_wgrad(idx, dout, ctx.vocab, ctx.padding_idx)
         if ctx.has_pos and ctx.needs_input_grad[2]:
             dpos = dout.reshape(-1, ctx.n_pos, E).sum(0)
         return None, dW, dpos, None
@@ -152,7 +164,7 @@ class TokenEmbedding(nn.Embedding):
 
     def forward(self, idx: torch.Tensor) -> torch.Tensor:
         if (torch.is_grad_enabled() and self.weight.requires_grad and idx.is_cuda and self.weight.dtype == torch.float32
-                and self.num_embeddings <= MAX_WIDTH and self.embedding_dim <= MAX_WIDTH and idx.numel() >= MIN_TOKENS
+                and self.num_embeddings <= EMB_MAX_VOCAB and self.embedding_dim <= EMB_MAX_WIDTH
                 and self.max_norm is None and not self.scale_grad_by_freq and not self.sparse):
             return _TokenEmbeddingFn.apply(idx, self.weight, self.padding_idx)
         return super().forward(idx)

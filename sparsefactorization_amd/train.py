@@ -78,13 +78,16 @@ class DeviceBatches:
                 yield self.data[lo:hi], self.labels[lo:hi]
 
 
-def make_adam(params, lr: float) -> torch.optim.Adam:
+def make_adam(params, lr: float, capturable: bool = False) -> torch.optim.Adam:
     """``optim.Adam(net.parameters(), lr=...)`` of psf_training.py:50 / listops_training.py:84. On the GPU the
     single-kernel (``fused=True``) implementation of the same update: the per-tensor foreach version spends 0.6 ms of
-    host time per step on a PSFNet's ~60 small parameters."""
+    host time per step on a PSFNet's ~60 small parameters. ``capturable``: step counters live on the device, so the
+    step can be captured in a HIP graph (``GraphedStep``)."""
     params = list(params)
     fused = all(p.is_cuda and p.is_floating_point() for p in params)
-    return torch.optim.Adam(params, lr=lr, fused=True) if fused else torch.optim.Adam(params, lr=lr)
+    if fused:
+        return torch.optim.Adam(params, lr=lr, fused=True, capturable=capturable)
+    return torch.optim.Adam(params, lr=lr)
 
 
 def count_params(net: torch.nn.Module) -> int:
@@ -122,15 +125,63 @@ def evaluate(net, loader: Iterable, loss, problem: str) -> Dict[str, float]:
     return {"loss": float(loss_sum) / max(batches, 1), "accuracy": 100.0 * float(correct) / max(total, 1)}
 
 
+class GraphedStep:
+    """The training step of psf_utils.py:62-71 (zero_grad, forward, loss, backward, optimizer.step) captured ONCE in a
+    HIP graph and replayed per batch: for the small LRA models a step is ~150 kernel launches for ~1 ms of GPU work,
+    i.e. launch-bound from Python; a replay costs one launch. Single process only (no gradient all-reduce inside the
+    graph), fixed batch shape (``drop_last=True`` loaders), an optimizer built with ``make_adam(..., capturable=True)``.
+    Every kernel of this package takes its sizes from host arguments, never from device data (the token-embedding
+    gradient included — nn.Embedding's own backward is not capturable), so the captured step is shape-static."""
+
+    def __init__(self, net, optimizer, loss, X: torch.Tensor, Y: torch.Tensor, warmup_steps: int = 3):
+        if not X.is_cuda:
+            raise RuntimeError("GraphedStep needs GPU tensors")
+        self.net, self.optimizer, self.loss = net, optimizer, loss
+        self.X, self.Y = X.clone(), Y.clone()
+        side = torch.cuda.Stream(device=X.device)
+        side.wait_stream(torch.cuda.current_stream(X.device))
+        with torch.cuda.stream(side):  # eager warm-up on a side stream (allocator, lazy initialisations, autotuning)
+            for _ in range(warmup_steps):
+                self._step()
+        torch.cuda.current_stream(X.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.output = self._step(zero=False)
+        self.warmup_steps = warmup_steps
+
+    def _step(self, zero: bool = True):
+        if zero:
+            self.optimizer.zero_grad(set_to_none=True)
+        out = self.loss(self.net(self.X).squeeze(), self.Y)
+        out.backward()
+        self.optimizer.step()
+        return out.detach()
+
+    def __call__(self, X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+        """One optimisation step on (X, Y); returns the loss (a static tensor, overwritten by the next call)."""
+        self.X.copy_(X, non_blocking=True)
+        self.Y.copy_(Y, non_blocking=True)
+        self.graph.replay()
+        return self.output
+
+
 def train_epoch(net, loader: Iterable, optimizer, loss, reducer: Optional[Callable[[], None]] = None,
-                max_steps: Optional[int] = None) -> Dict[str, float]:
-    """One pass of the training loop (psf_utils.py:60-74). Returns mean loss, steps and seconds."""
+                max_steps: Optional[int] = None, graphed: Optional[GraphedStep] = None) -> Dict[str, float]:
+    """One pass of the training loop (psf_utils.py:60-74). Returns mean loss, steps and seconds. With ``graphed``
+    every step is a replay of that captured step (same net / optimizer / loss)."""
     dev = _device_of(net)
     running = torch.zeros((), device=dev)
     steps = 0
     t0 = time.perf_counter()
     for X, Y in loader:
         X, Y = X.to(dev, non_blocking=True), Y.to(dev, non_blocking=True)
+        if graphed is not None:
+            running += graphed(X, Y)
+            steps += 1
+            if max_steps is not None and steps >= max_steps:
+                break
+            continue
         optimizer.zero_grad(set_to_none=True)
         pred = net(X)
         output = loss(pred.squeeze(), Y)
@@ -148,12 +199,13 @@ def train_epoch(net, loader: Iterable, optimizer, loss, reducer: Optional[Callab
 
 def TrainModel(net, trainloader, valloader, testloader, n_epochs, test_freq, optimizer, loss, problem,
                saving_criteria, reducer: Optional[Callable[[], None]] = None, save_dir: str = ".",
-               log: Callable[[str], None] = print, is_main: bool = True):
+               log: Callable[[str], None] = print, is_main: bool = True, graphed: Optional[GraphedStep] = None):
     """Same arguments and behaviour as ``TrainModel`` (SyntheticExperiments/psf_utils.py:48-137); for LRA use
-    ``problem`` = the task name (arg-max accuracy, as ``TrainPSF``). Returns the per-epoch history."""
+    ``problem`` = the task name (arg-max accuracy, as ``TrainPSF``). Returns the per-epoch history. ``graphed``: a
+    ``GraphedStep`` over the same net / optimizer / loss replaces the eager step (evaluation stays eager)."""
     history = []
     for epoch in range(n_epochs):
-        stats = train_epoch(net, trainloader, optimizer, loss, reducer)
+        stats = train_epoch(net, trainloader, optimizer, loss, reducer, graphed=graphed)
         if is_main:
             log("Epoch {} - Training loss:  {} — Time:  {}sec".format(epoch, stats["loss"], stats["seconds"]))
         record = {"epoch": epoch, "train": stats}

@@ -137,6 +137,13 @@ def test_producer_entry_points_validate_before_touching_the_gpu(lib):
              bwd_ws, None) == -1
     assert b"NULL" in lib.psf_last_error()
 
+    assert lib.psf_embed_tokens_bwd_workspace(65536, 225, 32) > 0
+    assert lib.psf_embed_tokens_bwd_workspace(65536, 513, 32) == -1     # vocabulary beyond the LDS table
+    assert lib.psf_embed_tokens_bwd_f32(one, one, 65536, 225, 32, two, two, 16, None) == -2   # short workspace
+    assert lib.psf_embed_tokens_bwd_f32(None, one, 65536, 225, 32, two, two, 1 << 30, None) == -1
+    assert lib.psf_embed_tokens_f32(one, one, None, two, 100, 10, 6, 30, None) == -2           # E % 4 != 0
+    assert lib.psf_embed_tokens_f32(one, vp(20), None, two, 100, 10, 6, 32, None) == -4        # table alignment
+
     s = lib.psf_linear_wgrad_strided_f32
     assert s(one, 31, one, 15, 1 << 20, 32, 15, two, None, two, 1 << 30, None) == -2   # ldx < m
     assert s(one, 480, one, 14, 1 << 20, 32, 15, two, None, two, 1 << 30, None) == -2  # ldy < n

@@ -91,6 +91,9 @@ def test_embed_tokens_matches_embedding_plus_positional_add(gpu, vocab, E, N, B,
         assert rel_inf(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5
     if padding_idx is not None:
         assert float(g_got[0][padding_idx].abs().max()) == 0.0
+    # the table gradient is a fixed order of additions (per-slice LDS tables, fixed-order reduction): bit-reproducible
+    again = torch.autograd.grad(embed_tokens(idx, emb, pos.weight if with_pos else None), [emb.weight], gy)[0]
+    assert torch.equal(again, g_got[0])
     # no-grad call and a [B, N, 1]-shaped Order input squeezed by the caller take the same path
     with torch.no_grad():
         assert torch.equal(embed_tokens(idx, emb, pos.weight if with_pos else None), ref)
