@@ -175,6 +175,17 @@ int psf_embed_tokens_bwd_f32(const int64_t* idx, const float* dOut, int64_t T, i
                              void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * The FLATTEN head of PSFNet, `final = nn.Linear(n_vec * n_channels_V, n_class)` on V.view(B, -1)
+ * (SyntheticExperiments/psf.py:129-134,189-190):  out[b,j] = bias[j] + sum_i X[b,i] * W[j,i]
+ *   X [B,K] (K = N*C, a multiple of 4), W [J,K] (nn.Linear.weight), bias [J] or NULL, out [B,J]; 1 <= J <= 8;
+ *   X and W 16-byte aligned. `workspace`: at least psf_flat_head_workspace(B, K, J) bytes (-1 for unsupported
+ *   sizes). One read of X; per-chunk partial sums are added in a fixed order (bit-reproducible).
+ */
+int64_t psf_flat_head_workspace(int32_t B, int64_t K, int32_t J);
+int psf_flat_head_f32(const float* X, const float* W, const float* bias, float* out, int32_t B, int64_t K, int32_t J,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * Producer side, forward (inference): K two-layer token-wise MLPs sharing one input, fused in one launch —
  * g and fs[0..M) of PSFNet (MLPBlock = Linear, GELU, Linear; SyntheticExperiments/psf.py:35-60,110-126,165,175):
  *     Y[k][t,:] = GELU(X[t,:] * A[k]^T + a[k]) * B[k]^T + b[k]          (erf GELU as torch.nn.GELU(); erf is

@@ -30,7 +30,7 @@ from typing import List, Sequence, Union
 import torch
 from torch import nn
 
-from . import fused_mlp
+from . import _lib, fused_mlp
 from .chord import chord_chain, chord_spmm, get_chord_indices_assym
 from .token_linear import TokenEmbedding, TokenLinear, embed_tokens
 
@@ -66,12 +66,44 @@ class MLPBlock(nn.Module):
         return self.network(data)
 
 
+class _FlatHeadFn(torch.autograd.Function):
+    """out = flat @ weight.T + bias on ``psf_flat_head_f32`` (csrc/flat_head.hip); backward: the usual small GEMMs."""
+
+    @staticmethod
+    def forward(ctx, flat, weight, bias):
+        lib = _lib.load()
+        flat_c, w_c = flat.contiguous(), weight.contiguous()
+        B, K = flat_c.shape
+        J = w_c.shape[0]
+        ws_bytes = lib.psf_flat_head_workspace(B, K, J)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=flat.device)
+        out = torch.empty((B, J), dtype=torch.float32, device=flat.device)
+        with torch.cuda.device(flat.device):
+            rc = lib.psf_flat_head_f32(flat_c.data_ptr(), w_c.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                       out.data_ptr(), B, K, J, ws.data_ptr(), ws_bytes,
+                                       torch.cuda.current_stream(flat.device).cuda_stream)
+        _lib.check(rc, "psf_flat_head_f32")
+        ctx.save_for_backward(flat_c, w_c)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        flat, weight = ctx.saved_tensors
+        d_flat = dy.mm(weight) if ctx.needs_input_grad[0] else None
+        d_w = dy.t().mm(flat) if ctx.needs_input_grad[1] else None
+        d_b = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return d_flat, d_w, d_b
+
+
 def _flat_head(final: nn.Module, flat: torch.Tensor) -> torch.Tensor:
-    """``final(flat)`` for the FLATTEN head. With one output (Adding: Linear(N*C -> 1), psf.py:129-134) the GEMM
-    degenerates to [B, N*C] x [N*C, 1], for which the library picks a 0.57 ms kernel at N*C = 131072, B = 64
-    (profiles/r01_e2e_forward_split.log); the same product as a matrix-vector op reads the 34 MB once."""
-    if isinstance(final, nn.Linear) and final.out_features == 1 and final.bias is not None and flat.is_cuda:
-        return torch.addmv(final.bias, flat, final.weight[0]).unsqueeze(1)
+    """``final(flat)`` for the FLATTEN head, Linear(N*C -> n_class) on [B, N*C] (psf.py:129-134). As a GEMM the
+    library takes 0.57 ms (Adding, one output) or 117 us (Temporal Order, four) at N*C = 131072, B = 64
+    (profiles/r01_e2e_forward_split.log); ``psf_flat_head_f32`` reads the activations once."""
+    if (isinstance(final, nn.Linear) and final.out_features <= 8 and flat.is_cuda and flat.dim() == 2
+            and flat.dtype == torch.float32 and final.weight.dtype == torch.float32 and flat.shape[1] % 4 == 0
+            and flat.shape[1] >= 4096):
+        return _FlatHeadFn.apply(flat, final.weight, final.bias)
     return final(flat)
 
 

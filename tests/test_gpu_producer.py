@@ -99,6 +99,27 @@ def test_embed_tokens_matches_embedding_plus_positional_add(gpu, vocab, E, N, B,
         assert torch.equal(embed_tokens(idx, emb, pos.weight if with_pos else None), ref)
 
 
+@pytest.mark.parametrize("B,K,J", [(64, 131072, 1), (40, 131072, 4), (5, 20000, 3), (3, 16388, 8), (1, 4096, 2)])
+def test_flat_head_matches_linear(gpu, B, K, J):
+    """psf_flat_head_f32 (the FLATTEN head Linear(N*C -> n_class)) vs nn.Linear in float64; gradients through the
+    autograd wrapper; fixed-order partial sums: bit-reproducible."""
+    from sparsefactorization_amd.psfnet import _flat_head
+    torch.manual_seed(B + J)
+    lin = torch.nn.Linear(K, J).to(gpu)
+    x = torch.randn(B, K, device=gpu, requires_grad=True)
+    y = _flat_head(lin, x)
+    ref = torch.nn.functional.linear(x.detach().double(), lin.weight.detach().double(), lin.bias.detach().double())
+    assert y.shape == (B, J) and rel_inf(y.detach().cpu().numpy(), ref.cpu().numpy()) <= 1e-5
+    assert torch.equal(_flat_head(lin, x), y)
+    gy = torch.randn(B, J, device=gpu)
+    g = torch.autograd.grad(y, [x, lin.weight, lin.bias], gy)
+    g_ref = torch.autograd.grad(torch.nn.functional.linear(x, lin.weight, lin.bias), [x, lin.weight, lin.bias], gy)
+    for a, b in zip(g, g_ref):
+        assert rel_inf(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5
+    wide = torch.nn.Linear(K, 9).to(gpu)  # more than 8 classes: the stock layer
+    assert _flat_head(wide, x).shape == (B, 9)
+
+
 MLP_CASES = [  # (T, E, [(h, out), ...])
     (64 * 1024, 32, [(32, 8)] + [(32, 15)] * 14),       # Adding/Order: g + 14 link MLPs
     (4097 * 3, 32, [(128, 32)] + [(128, 13)] * 12),     # IMDb / Pathfinder widths
