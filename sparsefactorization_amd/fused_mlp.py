@@ -146,7 +146,24 @@ class _FusedMLPFn(torch.autograd.Function):
         Bs = params[2::4]
         gys = [torch.zeros((x2.shape[0], B.shape[0]), dtype=torch.float32, device=x2.device) if g is None else g.contiguous()
                for g, B in zip(gys, Bs)]
-        dX, grads = _backward_raw(x2, params, gys, ctx.needs_input_grad[0])
+        need_dx = ctx.needs_input_grad[0]
+        # The backward kernel sizes its dY prefetch and its weight buffering for the WIDEST output of a call: one MLP
+        # with more than 16 outputs (g of the LRA networks: 32 channels) would put all ~50 units of the 12 link MLPs
+        # on the slower configuration. Wide and narrow MLPs therefore go in two launches and their dX are added.
+        narrow = [k for k, B in enumerate(Bs) if B.shape[0] <= 16]
+        wide = [k for k, B in enumerate(Bs) if B.shape[0] > 16]
+        if not narrow or not wide:
+            dX, grads = _backward_raw(x2, params, gys, need_dx)
+            return (dX, *grads)
+        grads: List[Optional[torch.Tensor]] = [None] * len(params)
+        dX = None
+        for group in (narrow, wide):
+            sub_params = [params[4 * k + i] for k in group for i in range(4)]
+            d, g_sub = _backward_raw(x2, sub_params, [gys[k] for k in group], need_dx)
+            for n, k in enumerate(group):
+                grads[4 * k:4 * k + 4] = g_sub[4 * n:4 * n + 4]
+            if need_dx:
+                dX = d if dX is None else dX.add_(d)
         return (dX, *grads)
 
 
