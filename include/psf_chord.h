@@ -235,6 +235,8 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
  *                      on 256-thread workgroups
  *   key "chain_fused": 1 = psf_chord_chain_fwd_f32 runs short sequences (N <= 2048, L <= 20, C % 4 == 0) as ONE
  *                      launch with the sequence resident in LDS (default); 0 = always M per-step launches
+ *   key "fwd_wg_limit": LDS-window forward kernel, workgroups per CU: 0 = auto (3 for rows of <= 8 channels on
+ *                      launches of >= 4096 tiles, else unlimited), 1 = unlimited, 2..4 = that many
  *   key "chain_cc"   : fused chain: 0 = auto channel groups per workgroup (default), 1 = one
  *   key "mlp_variant": psf_mlp_fwd_f32: 0 = auto (default: the split-bf16 kernel for E <= 32, else the f32-MFMA
  *                      kernel), 1 = f32 MFMA with streamed weights, 2 = f32 MFMA with LDS-resident weights,

@@ -20,16 +20,24 @@ template <int L, int TGS, int R, int NT, bool RES, bool EDGE>
 hipError_t launch_one(const FwdWinArgs& a) {
   using Cfg = FwdWinCfg<float, L, TGS, R, NT>;
   auto kern = chord_fwd_win_k<float, L, TGS, R, NT, /*DMA=*/true, RES, EDGE>;
-  if (Cfg::lds_bytes > 48 * 1024) {
+  // Occupancy limiter: a CU takes floor(160 KB / LDS per workgroup) workgroups, so asking for just over
+  // 160 KB / (n + 1) caps it at n. (cfg2: 3 per CU is 2-3 % faster than the 4 the registers allow — fewer
+  // windows competing for the XCD's L2; 2 per CU is 10 % slower. DESIGN.md §4.1.)
+  int lds = Cfg::lds_bytes;
+  if (a.wg_per_cu > 0) {
+    const int floor_bytes = kLdsPerCu / (a.wg_per_cu + 1) + 256;
+    if (floor_bytes > lds && floor_bytes <= 64 * 1024) lds = floor_bytes;
+  }
+  if (lds > 48 * 1024) {
     static std::atomic<int> done{0};
-    if (!done.load()) {
+    if (done.load() < lds) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::lds_bytes);
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return e;
-      done.store(1);
+      done.store(lds);
     }
   }
-  hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(NT), Cfg::lds_bytes, a.stream, a.W, a.V, a.res, a.out, a.gm,
+  hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(NT), lds, a.stream, a.W, a.V, a.res, a.out, a.gm,
                      a.offs, a.w_total);
   return hipGetLastError();
 }

@@ -11,6 +11,7 @@
 namespace psf {
 
 constexpr int kWinLmin = 4, kWinLmax = 20;  // compiled link counts
+constexpr int kLdsPerCu = 160 * 1024;       // gfx950
 constexpr int kWinTgsMax = 6;               // TG = 1 << TGS <= 64 lanes share a row
 
 // Compiled (TGS, NT) pairs: every TGS at 256 threads, plus the "wide-row" configuration: 8 lanes per row
@@ -36,6 +37,7 @@ struct FwdWinArgs {
   Offsets offs;
   int64_t w_total;  // B*N*L
   bool edge;        // true: the launch contains tiles that are not full (EDGE = true kernels)
+  int wg_per_cu;    // 0: whatever fits; n > 0: at most n workgroups per CU (enforced by requesting more LDS)
   hipStream_t stream;
 };
 

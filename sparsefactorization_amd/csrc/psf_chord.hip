@@ -50,6 +50,8 @@ std::atomic<int> g_chain_cc{0};     // fused chain: 0 = auto channel groups per 
 // r01 sweep (us/launch): cfg3 C=128: 18.9 / 23.2 / 21.8; attention map C=1024: 19.2 / 20.5 / 20.9; C=64: 10.2 / 9.4 /
 // 10.0 — contiguous whole-row bursts beat fewer far links, so 0 stays the default.
 std::atomic<int> g_fwd_wide{0};
+// Forward window kernel, workgroups per CU: 0 = auto (3 for narrow rows on large launches), 1 = no limit, 2..4 = cap
+std::atomic<int> g_fwd_wg_limit{0};
 
 }  // namespace
 // Fused producer MLPs: 0 = auto (split-bf16 kernel of mlp_fwd_x3.hip where it applies, else the f32-MFMA kernel of
@@ -66,6 +68,7 @@ Knob g_knobs[] = {
     {"fwd_variant", &g_fwd_variant, 0, 2}, {"bwd_variant", &g_bwd_variant, 0, 1}, {"xcd_remap", &g_xcd_remap, 0, 1},
     {"fwd_rows", &g_fwd_rows, 0, 8},       {"fwd_split", &g_fwd_split, 0, 1},     {"bwd_rows", &g_bwd_rows, 0, 8},
     {"fwd_wide", &g_fwd_wide, 0, 2},
+    {"fwd_wg_limit", &g_fwd_wg_limit, 0, 4},
     {"chain_fused", &g_chain_fused, 0, 1},
     {"chain_cc", &g_chain_cc, 0, 1},
     {"mlp_variant", &psf_g_mlp_variant, 0, 3},
@@ -272,6 +275,12 @@ int fwd_window_f32(const WinPick& pk, const float* W, const float* V, const floa
   a.offs = offs;
   a.w_total = B * N * (int64_t)L;
   a.stream = s;
+  // Workgroups per CU. Measured (profiles/r01e_fwd_wg_per_cu.log, us per launch, 4 / 3 per CU): cfg2 (C = 8, 4096
+  // tiles) 27.6 / 27.0; the same at B = 40 (2560 tiles) 18.9 / 18.8; C = 32, B = 16: 24.5 / 24.8; N = 4096, C = 16:
+  // 8.9 / 9.2; 2 per CU: 30.0 at cfg2. So: three for narrow rows on launches of >= 4096 tiles, no limit otherwise.
+  const int knob = g_fwd_wg_limit.load();
+  const int64_t tiles_total = B * (int64_t)(pk.tiles_full + (pk.ragged ? 1 : 0));
+  a.wg_per_cu = knob == 0 ? ((pk.tgs <= 1 && pk.nt == 256 && tiles_total >= 4096) ? 3 : 0) : (knob == 1 ? 0 : knob);
   return window_launches(pk, pk.all_edge, B, N, L, C, v_batch_stride, true, &a.gm, &a.edge,
                          [&] { return launch_win(pk, L, a); }, "chord_fwd_win launch");
 }

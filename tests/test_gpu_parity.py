@@ -133,6 +133,19 @@ def test_forward_xcd_remap_off(gpu):
     assert np.array_equal(got, _oracle_fwd(W, V))
 
 
+@pytest.mark.parametrize("limit", [0, 1, 2, 3, 4])
+def test_forward_workgroups_per_cu_limit(gpu, limit):
+    """fwd_wg_limit only changes how much LDS a launch asks for (an occupancy cap): results stay bit-exact."""
+    import sparsefactorization_amd as sfa
+    W, V, R = _mk((3, 2048, 12), 21), _mk((3, 2048, 8), 22), _mk((3, 2048, 8), 23)
+    sfa.set_tuning("fwd_wg_limit", limit)
+    try:
+        got = sfa.chord_spmm(_t(W, gpu), _t(V, gpu), _t(R, gpu)).cpu().numpy()
+    finally:
+        sfa.set_tuning("fwd_wg_limit", 0)
+    assert np.array_equal(got, _oracle_fwd(W, V, R))
+
+
 def test_forward_broadcast_first_operand(gpu):
     """Unbatched eye(N) as in ChangedPSF (pathfinder_inference.py:57,75-81)."""
     import sparsefactorization_amd as sfa
