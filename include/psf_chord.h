@@ -237,6 +237,9 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
  *                      launch with the sequence resident in LDS (default); 0 = always M per-step launches
  *   key "fwd_wg_limit": LDS-window forward kernel, workgroups per CU: 0 = auto (3 for rows of <= 8 channels on
  *                      launches of >= 4096 tiles, else unlimited), 1 = unlimited, 2..4 = that many
+ *   key "chain_zigzag": per-step launches of psf_chord_chain_fwd_*: 1 = every XCD walks its tile range forwards on
+ *                      even steps and backwards on odd ones, so a launch starts on the tiles whose inputs the
+ *                      previous launch wrote last (default); 0 = always forwards
  *   key "chain_cc"   : fused chain: 0 = auto channel groups per workgroup (default), 1 = one
  *   key "mlp_variant": psf_mlp_fwd_f32: 0 = auto (default: the split-bf16 kernel for E <= 32, else the f32-MFMA
  *                      kernel), 1 = f32 MFMA with streamed weights, 2 = f32 MFMA with LDS-resident weights,

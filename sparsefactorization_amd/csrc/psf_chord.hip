@@ -52,6 +52,9 @@ std::atomic<int> g_chain_cc{0};     // fused chain: 0 = auto channel groups per 
 std::atomic<int> g_fwd_wide{0};
 // Forward window kernel, workgroups per CU: 0 = auto (3 for narrow rows on large launches), 1 = no limit, 2..4 = cap
 std::atomic<int> g_fwd_wg_limit{0};
+// Per-step launches of a chain: 1 = alternate the direction in which each XCD walks its tile range
+std::atomic<int> g_chain_zigzag{1};
+thread_local bool t_walk_backwards = false;  // set by chain_impl around the launches of odd steps
 
 }  // namespace
 // Fused producer MLPs: 0 = auto (split-bf16 kernel of mlp_fwd_x3.hip where it applies, else the f32-MFMA kernel of
@@ -69,6 +72,7 @@ Knob g_knobs[] = {
     {"fwd_rows", &g_fwd_rows, 0, 8},       {"fwd_split", &g_fwd_split, 0, 1},     {"bwd_rows", &g_bwd_rows, 0, 8},
     {"fwd_wide", &g_fwd_wide, 0, 2},
     {"fwd_wg_limit", &g_fwd_wg_limit, 0, 4},
+    {"chain_zigzag", &g_chain_zigzag, 0, 1},
     {"chain_fused", &g_chain_fused, 0, 1},
     {"chain_cc", &g_chain_cc, 0, 1},
     {"mlp_variant", &psf_g_mlp_variant, 0, 3},
@@ -136,7 +140,7 @@ int make_geom(int64_t B, int64_t N, int32_t L, int64_t C, int vec, int tg_shift,
   gm->nblocks = (uint32_t)nb;
   gm->xq = gm->nblocks / kXcds;
   gm->xr = gm->nblocks % kXcds;
-  gm->remap = g_xcd_remap.load();
+  gm->remap = g_xcd_remap.load() ? (t_walk_backwards && g_chain_zigzag.load() ? 2 : 1) : 0;
   gm->v_bstride = v_bstride;
   return PSF_OK;
 }
@@ -451,8 +455,12 @@ int chain_impl(const T* const* W_steps, const T* V0, T* const* out_steps, int32_
   for (int m = 0; m < M; ++m) {
     const T* in = m == 0 ? V0 : out_steps[m - 1];
     const int64_t stride = m == 0 ? v0_batch_stride : N * C;
+    // zigzag: every XCD walks its tile range forwards on even steps and backwards on odd ones, so a launch begins
+    // with the tiles whose inputs the previous launch wrote LAST (still in that XCD's L2), not first
+    t_walk_backwards = (m & 1) != 0;
     int rc = fwd_impl<T>(W_steps[m], in, use_residual ? V0 : nullptr, out_steps[m], B, N, L, C, stride, offsets,
                          stream);
+    t_walk_backwards = false;
     if (rc) return rc;
   }
   return PSF_OK;

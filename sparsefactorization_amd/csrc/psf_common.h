@@ -45,6 +45,10 @@ __device__ __forceinline__ uint32_t logical_block(const Geom& gm) {
   if (!gm.remap) return bid;
   const uint32_t xcd = bid % kXcds, idx = bid / kXcds;
   const uint32_t base = xcd < gm.xr ? xcd * (gm.xq + 1) : gm.xr * (gm.xq + 1) + (xcd - gm.xr) * gm.xq;
+  if (gm.remap == 2) {  // the XCD walks its range backwards (odd steps of a chain: start where the last launch ended)
+    const uint32_t cnt = gm.xq + (xcd < gm.xr ? 1u : 0u);
+    return base + (cnt - 1u - idx);
+  }
   return base + idx;
 }
 

@@ -146,6 +146,25 @@ def test_forward_workgroups_per_cu_limit(gpu, limit):
     assert np.array_equal(got, _oracle_fwd(W, V, R))
 
 
+@pytest.mark.parametrize("zigzag", [0, 1])
+def test_chain_zigzag_tile_order(gpu, zigzag):
+    """chain_zigzag only changes which workgroup computes which tile on odd steps (also with a ragged last tile and
+    a workgroup count that is not a multiple of 8): the chain stays bit-exact against the oracle."""
+    import sparsefactorization_amd as sfa
+    B, N, M, L, C = 3, 2304 + 37, 4, 12, 8
+    Ws = [_mk((B, N, L), 31 + m) * 0.3 for m in range(M)]
+    V0 = _mk((B, N, C), 40)
+    sfa.set_tuning("chain_zigzag", zigzag)
+    sfa.set_tuning("chain_fused", 0)  # per-step launches also for this short sequence
+    try:
+        got = sfa.chord_chain([_t(w, gpu) for w in Ws], _t(V0, gpu), True).cpu().numpy()
+    finally:
+        sfa.set_tuning("chain_zigzag", 1)
+        sfa.set_tuning("chain_fused", 1)
+    rows, cols = oc.chord_indices(N, L)
+    assert np.array_equal(got, oc.chain(np.stack([rows, cols]), np.stack(Ws), V0, True)[-1])
+
+
 def test_forward_broadcast_first_operand(gpu):
     """Unbatched eye(N) as in ChangedPSF (pathfinder_inference.py:57,75-81)."""
     import sparsefactorization_amd as sfa
