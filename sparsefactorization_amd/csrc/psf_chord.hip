@@ -353,14 +353,8 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
       // default rows per thread (r01 sweep, us at cfg2): dV R=2 31.3 vs R=1 32.7; dW R=1 22.9 vs R=2 28.7
       const int knob = g_bwd_rows.load();
       const int rows_dv = knob ? knob : 2, rows_dw = knob ? knob : 1;
-      if (dV && pick_window(W, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(dV, 16), &pk,
-                            rows_dv, true)) {
-        BwdWinArgs a{dZ, W, dV, Geom{}, offs, w_total, false, s};
-        int rc = window_launches(pk, pk.all_edge, B, N, L, C, N * C, true, &a.gm, &a.edge,
-                                 [&] { return launch_dv(pk, L, a); }, "chord_dv_win");
-        if (rc) return rc;
-        dV = nullptr;
-      }
+      // dW before dV: dV's output is the next (earlier) step's dZ, read first thing by that step's kernels; writing
+      // it last leaves it cache-hot (dV 27.4 -> 26.9 us, dW 20.5 -> 20.4 us in the Order training step)
       if (dW && C / 4 <= TGmax &&
           pick_window(dW, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(V, 16), &pk,
                       rows_dw, false)) {
@@ -371,6 +365,14 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
                                  [&] { return launch_dw(pk, L, a); }, "chord_dw_win");
         if (rc) return rc;
         dW = nullptr;
+      }
+      if (dV && pick_window(W, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(dV, 16), &pk,
+                            rows_dv, true)) {
+        BwdWinArgs a{dZ, W, dV, Geom{}, offs, w_total, false, s};
+        int rc = window_launches(pk, pk.all_edge, B, N, L, C, N * C, true, &a.gm, &a.edge,
+                                 [&] { return launch_dv(pk, L, a); }, "chord_dv_win");
+        if (rc) return rc;
+        dV = nullptr;
       }
     }
   }
