@@ -9,6 +9,10 @@ What comes from the reference itself (imported from /root/reference, executed un
   * PSFNet.__init__/forward (the hot loop, the reshape of W, the residual, the heads)
                                                  SyntheticExperiments/psf.py:62-191, LRA/psf.py:63-250
   * trained weights                              LRA/attention_maps/pathfinder_epoch27.pt
+  * TrainModel (the training / evaluation loop)  SyntheticExperiments/psf_utils.py:48-137 — called as it is; its
+                                                 `.cuda()` calls are made the identity for the run (no GPU here)
+  * the stand-alone attention block              attention_block.py:70-178 (imported with an empty
+                                                 `torch_geometric` module: line 9 only imports it)
 What does NOT: `torch_sparse.spmm`. torch-sparse==0.6.11 (requirements.txt:146) is an un-vendored third-party
 dependency that is neither in /root/reference nor installed, so `from torch_sparse import spmm`
 (psf.py:5) is satisfied with oracle.chord_oracle.torch_spmm_port — the published algorithm
@@ -240,6 +244,115 @@ def gen_lra(lra):
     save("checkpoint_layouts.npz", layouts=np.asarray(lines))
 
 
+# ---------------------------------------------------------------------------------------------------
+# 3. the reference's TrainModel run as it is: loss after every optimiser step, evaluation numbers
+# ---------------------------------------------------------------------------------------------------
+class RecordingLoss(torch.nn.Module):
+    """Wraps the loss module handed to TrainModel and keeps every value it returns, in call order."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+        self.values = []
+
+    def forward(self, pred, target):
+        out = self.inner(pred, target)
+        self.values.append(float(out.detach()))
+        return out
+
+
+TRAIN_BATCH, TRAIN_BATCHES, EVAL_BATCHES, TRAIN_EPOCHS = 40, 8, 2, 2
+
+
+def gen_training(se, utils):
+    """cfg1 (N = 128, n_W = 7, batch 40; synthetic_training_config.py:4-18,72-86), `seed_everything(42)` as
+    psf_training.py:16, Adam(lr) and the loss choice of psf_training.py:50-58, the reference's own TrainModel over
+    8 fixed training batches per epoch (shuffle off), 2 epochs, evaluation after each (test_freq = 1)."""
+    import contextlib
+    import io
+    import re
+    from torch.utils.data import DataLoader
+    from sparsefactorization_amd import synth_data  # input data only: seeded Adding / Temporal-Order sequences
+
+    N, n_W = 128, 7
+    model_cfg = {
+        "adding": dict(vocab_size=1, add_init_linear_layer=True, embedding_size=32, n_vec=N, n_W=n_W, Ws=[32, 'GELU'],
+                       V=[32, 'GELU'], n_channels_V=8, n_class=1, pooling_type="FLATTEN", head=['linear'],
+                       use_cuda=False, use_residuals=True, use_pos_embedding=False, problem="adding"),
+        "order": dict(vocab_size=6, add_init_linear_layer=False, embedding_size=32, n_vec=N, n_W=n_W, Ws=[32, 'GELU'],
+                      V=[32, 'GELU'], n_channels_V=8, n_class=4, pooling_type="FLATTEN", head=['linear'],
+                      use_cuda=False, use_residuals=True, use_pos_embedding=True, problem="order"),
+    }
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self  # TrainModel moves every batch with X.cuda() (psf_utils.py:65-66)
+    try:
+        for problem, cfg in model_cfg.items():
+            utils.seed_everything(42)
+            net = se.PSFNet(**cfg)
+            sd0 = state_arrays(net)
+            optimizer = torch.optim.Adam(net.parameters(), lr=0.001)
+            loss = RecordingLoss(torch.nn.MSELoss() if problem == "adding" else torch.nn.CrossEntropyLoss())
+            g = torch.Generator().manual_seed(2024)
+            make = synth_data.adding if problem == "adding" else synth_data.temporal_order
+            Xtr, Ytr = make(TRAIN_BATCH * TRAIN_BATCHES, N, generator=g)
+            Xva, Yva = make(TRAIN_BATCH * EVAL_BATCHES, N, generator=g)
+            Xte, Yte = make(TRAIN_BATCH * EVAL_BATCHES, N, generator=g)
+            mk = lambda X, Y: DataLoader(utils.DatasetCreator(X, Y), batch_size=TRAIN_BATCH, shuffle=False,  # noqa: E731
+                                         drop_last=True, num_workers=0)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+                utils.TrainModel(net=net, trainloader=mk(Xtr, Ytr), valloader=mk(Xva, Yva), testloader=mk(Xte, Yte),
+                                 n_epochs=TRAIN_EPOCHS, test_freq=1, optimizer=optimizer, loss=loss, problem=problem,
+                                 saving_criteria=1e9)
+            text = buf.getvalue()
+            num = r"(?:tensor\()?([-+0-9.eE]+)"
+            printed = {key: [float(x) for x in re.findall(pat + num, text)]
+                       for key, pat in (("train_loss", r"Training loss:\s+"), ("val_loss", r"Val  loss: "),
+                                        ("test_loss", r"Test loss: "), ("val_acc", r"Val  accuracy: "),
+                                        ("test_acc", r"Test accuracy: "))}
+            per_epoch = TRAIN_BATCHES + 2 * EVAL_BATCHES
+            assert len(loss.values) == TRAIN_EPOCHS * per_epoch and all(len(v) == TRAIN_EPOCHS for v in printed.values())
+            vals = np.asarray(loss.values, dtype=np.float64).reshape(TRAIN_EPOCHS, per_epoch)
+            to_np = (lambda t: t.numpy()) if problem == "adding" else (lambda t: t.numpy().astype(np.uint8))
+            save(f"train_{problem}_n128.npz", Xtr=to_np(Xtr), Ytr=to_np(Ytr), Xva=to_np(Xva), Yva=to_np(Yva),
+                 Xte=to_np(Xte), Yte=to_np(Yte), step_loss=vals[:, :TRAIN_BATCHES].copy(),
+                 val_batch_loss=vals[:, TRAIN_BATCHES:TRAIN_BATCHES + EVAL_BATCHES].copy(),
+                 test_batch_loss=vals[:, TRAIN_BATCHES + EVAL_BATCHES:].copy(),
+                 **{"printed_" + k: np.asarray(v) for k, v in printed.items()}, **sd0,
+                 **{"final::" + k[4:]: v for k, v in state_arrays(net).items()})
+            print(f"  {problem}: step losses epoch0 {vals[0, :3]} ... epoch1 {vals[1, TRAIN_BATCHES - 1]:.6f}; printed {printed}")
+    finally:
+        torch.Tensor.cuda = real_cuda
+
+
+# ---------------------------------------------------------------------------------------------------
+# 4. attention_block.py
+# ---------------------------------------------------------------------------------------------------
+def gen_attention_block():
+    """The stand-alone block (attention_block.py:70-178): n_W = ceil(log2(max_seq_len)), C = E, output [B, N, E].
+    The module constructs and prints a 1024-token network when imported (181-192); that one is not used."""
+    import contextlib
+    import io
+    sys.modules.setdefault("torch_geometric", types.ModuleType("torch_geometric"))  # imported, never used (line 9)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ab = import_reference("ref_attention_block", "attention_block.py")
+    for tag, seed, cfg, B in (
+            ("n300_e32_res", 46, dict(vocab_size=50, embedding_size=32, max_seq_len=300, use_cuda=False,
+                                      use_residuals=True, dropout1_p=0, dropout2_p=0, dropout3_p=0), 2),
+            ("n64_e16", 47, dict(vocab_size=11, embedding_size=16, max_seq_len=64, use_cuda=False,
+                                 use_residuals=False, dropout1_p=0, dropout2_p=0, dropout3_p=0), 3)):
+        torch.manual_seed(seed)
+        net = ab.PSFNet(**cfg)
+        net.n_vec = cfg["max_seq_len"]  # run_and_capture reshapes with net.n_vec
+        g = torch.Generator().manual_seed(seed + 100)
+        x = torch.randint(0, cfg["vocab_size"], (B, cfg["max_seq_len"]), generator=g)
+        gout = torch.randn(B, cfg["max_seq_len"], cfg["embedding_size"], generator=g)
+        res = run_and_capture(net, x, lambda out: (out * gout).sum(), vfinal_module=net.dropout3)
+        save(f"attention_block_{tag}.npz", x=x.numpy(), gout=gout.numpy(), out=res.pop("logits"), **res,
+             **state_arrays(net), chord_indicies=net.chord_indicies.numpy(),
+             n_W=np.asarray(net.n_W), n_links=np.asarray(net.n_links))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # deterministic CPU reductions
@@ -248,6 +361,8 @@ def main():
     gen_indices(se)
     gen_synthetic(se)
     gen_lra(lra)
+    gen_training(se, import_reference("ref_se_psf_utils", "SyntheticExperiments/psf_utils.py"))
+    gen_attention_block()
 
 
 if __name__ == "__main__":

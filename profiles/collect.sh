@@ -9,8 +9,9 @@ TAG=${1:-r01}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+python3 -c "from sparsefactorization_amd.build import csrc_hash; print(csrc_hash())" > "$OUT/csrc_hash.txt"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train"
 
 run() {  # name, rocprofv3 args...
   local name=$1; shift

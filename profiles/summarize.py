@@ -30,7 +30,11 @@ def find(d, pattern):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-    out = {"tag": tag, "kernels": {}}
+    # hash of the kernel sources the counters were collected on, written by collect.sh on the GPU box at collection
+    # time (sparsefactorization_amd/build.py: csrc_hash); bench.py withholds roofline.traffic when csrc has changed
+    hfile = os.path.join(src, "csrc_hash.txt")
+    chash = open(hfile).read().strip() if os.path.exists(hfile) else None
+    out = {"tag": tag, "csrc_hash": chash, "kernels": {}}
     md = [f"# rocprofv3 summary — {tag}", "", "Command: `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline` "
           "(N=16384, M=14, L=15, C=8, B=64; 25 chains x 14 launches)", ""]
 

@@ -35,6 +35,21 @@ HIPCC_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-ffp-con
                "-Wno-pass-failed"]
 
 
+def csrc_hash() -> str:
+    """SHA-256 over the kernel sources (every file under csrc/ plus include/psf_chord.h, names and contents, sorted).
+    Identifies the code a profile was collected on: profiles/*_pmc.json records it and bench.py withholds
+    ``roofline.traffic`` when it no longer matches (no .git on the GPU box, so a content hash instead of a commit)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip")))
+    files.append(os.path.join(PKG_DIR, "..", "include", "psf_chord.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

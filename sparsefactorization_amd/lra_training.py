@@ -104,7 +104,8 @@ def main(argv=None):
     ap.add_argument("--max-steps", type=int, default=None)
     ap.add_argument("--json", action="store_true", help="print one JSON line with training throughput")
     ap.add_argument("--graph", action="store_true",
-                    help="capture the training step in a HIP graph and replay it (single process; train.GraphedStep)")
+                    help="capture the training step in a HIP graph and replay it (train.GraphedStep; with several ranks the "
+                         "gradient all-reduce and the optimizer step stay outside the graph)")
     args = ap.parse_args(argv)
 
     rank, world, device = dp.init_from_env()
@@ -120,9 +121,7 @@ def main(argv=None):
     if rank == 0:
         print('Number of trainable parameters', count_params(net))
     loss = nn.CrossEntropyLoss()
-    if args.graph and world > 1:
-        raise SystemExit("--graph captures a single-process step (no gradient all-reduce inside the graph)")
-    optimizer = make_adam(net.parameters(), cfg_training['learning_rate'], capturable=args.graph)
+    optimizer = make_adam(net.parameters(), cfg_training['learning_rate'], capturable=args.graph and world == 1)
     reducer = dp.FlatGradAllReduce(net.parameters()) if world > 1 else None
 
     splits = {}
@@ -141,7 +140,7 @@ def main(argv=None):
     mk = lambda s, shuffle: DeviceBatches(*splits[s], batch, shuffle=shuffle, drop_last=True)  # noqa: E731
     trainloader, valloader, testloader = mk("train", True), mk("val", False), mk("test", False)
 
-    graphed = GraphedStep(net, optimizer, loss, *next(iter(trainloader))) if args.graph else None
+    graphed = GraphedStep(net, optimizer, loss, *next(iter(trainloader)), reducer=reducer) if args.graph else None
 
     if args.json:
         train_epoch(net, trainloader, optimizer, loss, reducer, max_steps=3, graphed=graphed)

@@ -61,6 +61,65 @@ def make_split(problem: str, n_seq: int, n_vec: int, device, seed: int):
     return fn(n_seq, n_vec, device=device, generator=g)
 
 
+def train_benchmark(problem: str, n_vec: int, batch: int, steps: int, warmup: int, device, rank: int = 0,
+                    world: int = 1, graph: bool = False, n_batches: int = 4) -> dict:
+    """Time ``steps`` optimisation steps of the reference training loop body (psf_utils.py:62-71: zero_grad, forward,
+    loss, backward, [gradient all-reduce,] Adam step) on this rank's shard: ``batch`` sequences per rank per step,
+    synthetic data of the task's distribution generated on the device (rank-offset seed), replicas started from rank
+    0's weights. Returns per-rank numbers; the caller aggregates over ranks (bench.py --train, ``--json`` below).
+    The region is bracketed by a barrier + device synchronisation on both sides when a process group exists."""
+    import torch.distributed as dist
+    seed_everything(42)
+    net = build_model(problem, n_vec).to(device)
+    dp.broadcast_parameters(net)
+    lr = config[problem]["training"]["learning_rate"]
+    use_graph_dp = graph and world > 1
+    optimizer = make_adam(net.parameters(), lr, capturable=graph and world == 1)
+    loss = nn.MSELoss() if problem == "adding" else nn.CrossEntropyLoss()
+    reducer = dp.FlatGradAllReduce(net.parameters(), timing=True) if world > 1 else None
+    X, Y = make_split(problem, batch * n_batches, n_vec, device, 1000 + rank)
+    batches = [(X[i * batch:(i + 1) * batch], Y[i * batch:(i + 1) * batch]) for i in range(n_batches)]
+    graphed = GraphedStep(net, optimizer, loss, *batches[0], reducer=reducer) if graph else None
+
+    def one(i):
+        x, y = batches[i % n_batches]
+        if graphed is not None:
+            return graphed(x, y)
+        optimizer.zero_grad(set_to_none=True)
+        out = loss(net(x).squeeze(), y)
+        out.backward()
+        if reducer is not None:
+            reducer()
+        optimizer.step()
+        return out.detach()
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for i in range(warmup):
+        one(i)
+    if reducer is not None:
+        sync()
+        reducer.reset_timing()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync()
+    t0 = time.perf_counter()
+    e0.record()
+    last = None
+    for i in range(steps):
+        last = one(i)
+    e1.record()
+    sync()
+    dt = time.perf_counter() - t0
+    return {"seconds": dt, "event_ms": e0.elapsed_time(e1), "steps": steps, "loss": float(last),
+            "allreduce_us": reducer.mean_us() if reducer is not None else None,
+            "grad_bytes": 4 * sum(p.numel() for p in net.parameters() if p.requires_grad),
+            "hip_graph": ("fwd+bwd" if use_graph_dp else "step") if graph else None}
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--problem", choices=["adding", "order"], default="adding")
@@ -72,7 +131,10 @@ def main(argv=None):
     ap.add_argument("--max-steps", type=int, default=None, help="stop an epoch early (benchmarking)")
     ap.add_argument("--json", action="store_true", help="print one JSON line with training throughput")
     ap.add_argument("--graph", action="store_true",
-                    help="capture the training step in a HIP graph and replay it (single process; train.GraphedStep)")
+                    help="capture the training step in a HIP graph and replay it (train.GraphedStep; with several ranks the "
+                         "gradient all-reduce and the optimizer step stay outside the graph)")
+    ap.add_argument("--force-allreduce", action="store_true",
+                    help="run the flat gradient all-reduce even in a 1-rank group (RCCL path check on a 1-GPU box)")
     args = ap.parse_args(argv)
 
     rank, world, device = dp.init_from_env()
@@ -87,11 +149,12 @@ def main(argv=None):
     dp.broadcast_parameters(net)
     if rank == 0:
         print('Number of trainable parameters', count_params(net))
-    if args.graph and world > 1:
-        raise SystemExit("--graph captures a single-process step (no gradient all-reduce inside the graph)")
-    optimizer = make_adam(net.parameters(), cfg_training["learning_rate"], capturable=args.graph)
+    # --graph: one process captures the whole step (optimizer included: capturable Adam); under data parallelism the
+    # graph holds forward + backward and the all-reduce + optimizer step stay eager (train.GraphedStep)
+    optimizer = make_adam(net.parameters(), cfg_training["learning_rate"], capturable=args.graph and world == 1)
     loss = nn.MSELoss() if args.problem == "adding" else nn.CrossEntropyLoss()
-    reducer = dp.FlatGradAllReduce(net.parameters()) if world > 1 else None
+    force = args.force_allreduce and torch.distributed.is_initialized()
+    reducer = dp.FlatGradAllReduce(net.parameters(), force=force) if (world > 1 or force) else None
 
     # every rank draws its own shard of the global data (rank-offset seed), validation/test are replicated
     lo, hi = dp.shard_bounds(args.train_seqs, rank, world)
@@ -101,7 +164,7 @@ def main(argv=None):
     mk = lambda X, Y, shuffle: DeviceBatches(X, Y, batch, shuffle=shuffle, drop_last=True)  # noqa: E731
     trainloader, valloader, testloader = mk(Xtr, Ytr, True), mk(Xva, Yva, False), mk(Xte, Yte, False)
 
-    graphed = GraphedStep(net, optimizer, loss, *next(iter(trainloader))) if args.graph else None
+    graphed = GraphedStep(net, optimizer, loss, *next(iter(trainloader)), reducer=reducer) if args.graph else None
 
     if args.json:
         train_epoch(net, trainloader, optimizer, loss, reducer, max_steps=3, graphed=graphed)  # warm-up
@@ -116,11 +179,12 @@ def main(argv=None):
                               "ms_per_step": dt * 1e3 / max(stats["steps"], 1),
                               "value": world * batch * args.n_vec * stats["steps"] / dt, "unit": "tokens/s",
                               "loss": stats["loss"], "hip_graph": bool(args.graph)}))
-        return
+        return {"net": net, "reducer": reducer, "stats": stats}
 
-    TrainModel(net=net, trainloader=trainloader, valloader=valloader, testloader=testloader, n_epochs=epochs,
+    history = TrainModel(net=net, trainloader=trainloader, valloader=valloader, testloader=testloader, n_epochs=epochs,
                test_freq=cfg_training["eval_frequency"], optimizer=optimizer, loss=loss, problem=args.problem,
                saving_criteria=99.5, reducer=reducer, is_main=rank == 0, graphed=graphed)
+    return {"net": net, "reducer": reducer, "history": history}
 
 
 if __name__ == "__main__":

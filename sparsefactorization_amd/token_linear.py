@@ -74,11 +74,19 @@ EMB_MAX_VOCAB, EMB_MAX_WIDTH = 512, 4096  # limits of psf_embed_tokens_bwd_f32
 def embedding_wgrad(idx: torch.Tensor, dout: torch.Tensor, vocab: int, padding_idx) -> torch.Tensor:
     """d(table) [vocab, E] of ``table[idx]`` given d(out) [..., E]: ``psf_embed_tokens_bwd_f32`` (csrc/embed.hip —
     per-slice LDS tables with single-owner accumulation, fixed-order reduction: deterministic, no host read-back, so
-    a training step stays capturable in a HIP graph). Vocabularies beyond its LDS table use PyTorch's kernel."""
+    a training step stays capturable in a HIP graph). Vocabularies beyond its LDS table use PyTorch's kernel — in
+    eager mode only: under stream capture that case raises (the aten operator is not capturable)."""
     E = dout.shape[-1]
     d2 = dout.reshape(-1, E).contiguous()
     T = d2.shape[0]
     if vocab > EMB_MAX_VOCAB or E > EMB_MAX_WIDTH or dout.dtype != torch.float32 or T == 0:
+        if dout.is_cuda and torch.cuda.is_current_stream_capturing():
+            # aten::embedding_dense_backward sizes a rocprim partition from a host read-back: not capturable, and a
+            # replay of such a capture faulted the GPU (profiles/r01_graph_step_lab.log). Refuse instead.
+            raise RuntimeError(
+                f"embedding gradient for a {vocab} x {E} {dout.dtype} table cannot be captured in a HIP graph: the "
+                f"capturable kernel psf_embed_tokens_bwd_f32 is limited to vocab <= {EMB_MAX_VOCAB}, width <= "
+                f"{EMB_MAX_WIDTH}, float32, and the fallback aten::embedding_dense_backward reads sizes back to the host")
         pad = -1 if padding_idx is None else padding_idx
         return torch.ops.aten.embedding_dense_backward(dout.contiguous(), idx, vocab, pad, False)
     lib = _lib.load()

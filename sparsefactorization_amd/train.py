@@ -125,37 +125,93 @@ def evaluate(net, loader: Iterable, loss, problem: str) -> Dict[str, float]:
     return {"loss": float(loss_sum) / max(batches, 1), "accuracy": 100.0 * float(correct) / max(total, 1)}
 
 
+def check_capturable(net: torch.nn.Module) -> None:
+    """Raise before a capture if a token embedding of ``net`` would send its weight gradient through
+    ``aten::embedding_dense_backward``: that operator sizes a rocprim partition from a host read-back, which cannot be
+    captured, and REPLAYING such a capture faulted the GPU (profiles/r01_graph_step_lab.log). The capturable kernel,
+    ``psf_embed_tokens_bwd_f32``, holds the table in LDS: vocab <= EMB_MAX_VOCAB, width <= EMB_MAX_WIDTH, fp32."""
+    from .token_linear import EMB_MAX_VOCAB, EMB_MAX_WIDTH, TokenEmbedding
+    for name, m in net.named_modules():
+        if isinstance(m, TokenEmbedding) and m.weight.requires_grad:
+            if m.num_embeddings > EMB_MAX_VOCAB or m.embedding_dim > EMB_MAX_WIDTH or m.weight.dtype != torch.float32:
+                raise RuntimeError(
+                    f"GraphedStep: embedding '{name}' ({m.num_embeddings} x {m.embedding_dim}, {m.weight.dtype}) is "
+                    f"outside the capturable table-gradient kernel's limits (vocab <= {EMB_MAX_VOCAB}, width <= "
+                    f"{EMB_MAX_WIDTH}, float32); its gradient would run on aten::embedding_dense_backward, which cannot "
+                    "be captured in a HIP graph. Train this model eagerly (no --graph).")
+
+
 class GraphedStep:
     """The training step of psf_utils.py:62-71 (zero_grad, forward, loss, backward, optimizer.step) captured ONCE in a
     HIP graph and replayed per batch: for the small LRA models a step is ~150 kernel launches for ~1 ms of GPU work,
-    i.e. launch-bound from Python; a replay costs one launch. Single process only (no gradient all-reduce inside the
-    graph), fixed batch shape (``drop_last=True`` loaders), an optimizer built with ``make_adam(..., capturable=True)``.
+    i.e. launch-bound from Python; a replay costs one launch. Fixed batch shape (``drop_last=True`` loaders).
     Every kernel of this package takes its sizes from host arguments, never from device data (the token-embedding
-    gradient included — nn.Embedding's own backward is not capturable), so the captured step is shape-static."""
+    gradient included — nn.Embedding's own backward is not capturable, see ``check_capturable``), so the captured step
+    is shape-static.
 
-    def __init__(self, net, optimizer, loss, X: torch.Tensor, Y: torch.Tensor, warmup_steps: int = 3):
+    Single process (``reducer`` None): the whole step including the optimizer is one graph; the optimizer must be built
+    with ``make_adam(..., capturable=True)``. Data parallel (``reducer`` = ``dp.FlatGradAllReduce``): the graph holds
+    zero_grad + forward + loss + backward; the gradient all-reduce (a collective must not sit in a private capture of
+    one rank's stream) and the optimizer step run eagerly after each replay, on gradients that live at fixed addresses
+    in the graph's memory pool."""
+
+    def __init__(self, net, optimizer, loss, X: torch.Tensor, Y: torch.Tensor, warmup_steps: int = 3,
+                 reducer: Optional[Callable[[], None]] = None):
         if not X.is_cuda:
             raise RuntimeError("GraphedStep needs GPU tensors")
-        self.net, self.optimizer, self.loss = net, optimizer, loss
+        check_capturable(net)
+        self.net, self.optimizer, self.loss, self.reducer = net, optimizer, loss, reducer
         self.X, self.Y = X.clone(), Y.clone()
+        # a plain nn.Embedding that is actually looked up (not just a parameter holder like pos_embedding, whose
+        # .weight is added directly) has the same uncapturable gradient: watch for calls during the warm-up
+        called, hooks = [], []
+        for name, m in net.named_modules():
+            if type(m) is torch.nn.Embedding and m.weight.requires_grad:
+                hooks.append(m.register_forward_hook(lambda _m, _i, _o, _n=name: called.append(_n)))
+        # the warm-up steps are real optimisation steps; they are undone after the capture (parameters, buffers and
+        # optimizer state restored IN PLACE — the graph holds their addresses), so a graphed run starts from the same
+        # state, and follows the same trajectory, as an eager one (tests/test_reference_pins.py)
+        with torch.no_grad():
+            tensors = list(net.parameters()) + list(net.buffers())
+            snapshot = [t.detach().clone() for t in tensors]
+        opt_before = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in optimizer.state[p].items()}
+                      for p in optimizer.state}
         side = torch.cuda.Stream(device=X.device)
         side.wait_stream(torch.cuda.current_stream(X.device))
         with torch.cuda.stream(side):  # eager warm-up on a side stream (allocator, lazy initialisations, autotuning)
             for _ in range(warmup_steps):
                 self._step()
         torch.cuda.current_stream(X.device).wait_stream(side)
+        for h in hooks:
+            h.remove()
+        if called:
+            raise RuntimeError(f"GraphedStep: nn.Embedding module(s) {sorted(set(called))} are looked up in forward; their "
+                               "gradient (aten::embedding_dense_backward) cannot be captured in a HIP graph. Use "
+                               "token_linear.TokenEmbedding (same parameters and state_dict) or train eagerly.")
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
-            self.output = self._step(zero=False)
+            self.output = self._step(zero=False, eager_tail=False)
         self.warmup_steps = warmup_steps
+        with torch.no_grad():
+            for t, s0 in zip(tensors, snapshot):
+                t.copy_(s0)
+            for p, st in optimizer.state.items():
+                before = opt_before.get(id(p), {})
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.copy_(before[k]) if k in before else v.zero_()
 
-    def _step(self, zero: bool = True):
+    def _step(self, zero: bool = True, eager_tail: bool = True):
         if zero:
             self.optimizer.zero_grad(set_to_none=True)
         out = self.loss(self.net(self.X).squeeze(), self.Y)
         out.backward()
-        self.optimizer.step()
+        if self.reducer is None:
+            self.optimizer.step()
+        elif eager_tail:
+            self.reducer()
+            self.optimizer.step()
         return out.detach()
 
     def __call__(self, X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
@@ -163,13 +219,17 @@ class GraphedStep:
         self.X.copy_(X, non_blocking=True)
         self.Y.copy_(Y, non_blocking=True)
         self.graph.replay()
+        if self.reducer is not None:
+            self.reducer()
+            self.optimizer.step()
         return self.output
 
 
 def train_epoch(net, loader: Iterable, optimizer, loss, reducer: Optional[Callable[[], None]] = None,
                 max_steps: Optional[int] = None, graphed: Optional[GraphedStep] = None) -> Dict[str, float]:
     """One pass of the training loop (psf_utils.py:60-74). Returns mean loss, steps and seconds. With ``graphed``
-    every step is a replay of that captured step (same net / optimizer / loss)."""
+    every step is a replay of that captured step (same net / optimizer / loss; a data-parallel ``GraphedStep`` calls
+    its own reducer, ``reducer`` here is then ignored)."""
     dev = _device_of(net)
     running = torch.zeros((), device=dev)
     steps = 0

@@ -475,8 +475,9 @@ def test_full_size_properties(gpu):
     lhs = sfa.chord_chain(Ws, a * X + Y, False)
     rhs = a * sfa.chord_chain(Ws, X, False) + sfa.chord_chain(Ws, Y, False)
     assert float((lhs - rhs).abs().max() / rhs.abs().max()) <= TOL
-    # spot-check 2 batch elements of the full-size chain against the oracle
-    sel = [0, 37]
+    # spot-check 3 batch elements of the full-size chain against the oracle: the first, one in the middle and the
+    # LAST one (last XCD's range of the tile remap, tail of the zigzag walk)
+    sel = [0, 37, 63]
     W_np = np.stack([w[sel].cpu().numpy() for w in Ws])
     rows, cols = oc.chord_indices(16384, 15)
     want = oc.chain(np.stack([rows, cols]), W_np, V0[sel].cpu().numpy(), True)[-1]

@@ -1,0 +1,300 @@
+"""Pins of the callers of the hot path to outputs of the REFERENCE's own code, run in the build container by
+oracle/gen_golden.py (fixtures in tests/golden):
+
+  train_{adding,order}_n128.npz      the reference's TrainModel (SyntheticExperiments/psf_utils.py:48-137) on its
+                                     PSFNet at cfg1, seed_everything(42), Adam(1e-3), 2 epochs x 8 fixed batches of 40:
+                                     loss after every optimiser step, evaluation losses / accuracies it printed
+  attention_block_*.npz              attention_block.py:70-178 PSFNet: operands of its hot loop, output, gradients
+
+CPU tests: the oracle and the host-side construction logic against those fixtures. GPU tests (`-m gpu`): this
+package's train harness / attention block, through the HIP kernels, against the same numbers.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_state_dict, load_golden, rel_inf
+from oracle import chord_oracle as oc
+
+CFG1 = {
+    "adding": dict(vocab_size=1, add_init_linear_layer=True, embedding_size=32, n_vec=128, n_W=7, Ws=[32, 'GELU'],
+                   V=[32, 'GELU'], n_channels_V=8, n_class=1, pooling_type="FLATTEN", head=['linear'],
+                   use_residuals=True, use_pos_embedding=False, problem="adding"),
+    "order": dict(vocab_size=6, add_init_linear_layer=False, embedding_size=32, n_vec=128, n_W=7, Ws=[32, 'GELU'],
+                  V=[32, 'GELU'], n_channels_V=8, n_class=4, pooling_type="FLATTEN", head=['linear'],
+                  use_residuals=True, use_pos_embedding=True, problem="order"),
+}
+BLOCKS = {
+    "attention_block_n300_e32_res.npz": (46, dict(vocab_size=50, embedding_size=32, max_seq_len=300, use_residuals=True,
+                                                  dropout1_p=0, dropout2_p=0, dropout3_p=0)),
+    "attention_block_n64_e16.npz": (47, dict(vocab_size=11, embedding_size=16, max_seq_len=64, use_residuals=False,
+                                             dropout1_p=0, dropout2_p=0, dropout3_p=0)),
+}
+
+
+def _train_tensors(g, problem, device="cpu"):
+    cast = (lambda a: torch.from_numpy(a.copy())) if problem == "adding" else (lambda a: torch.from_numpy(a.astype(np.int64)))
+    return {k: cast(g[k]).to(device) for k in ("Xtr", "Ytr", "Xva", "Yva", "Xte", "Yte")}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# CPU
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("problem", ["adding", "order"])
+def test_training_fixture_is_the_reference_loop(problem):
+    """What TrainModel printed per epoch is the mean of the per-step values the loss module returned
+    (psf_utils.py:73-79: running_loss / len(trainloader)), and evaluation means likewise (92-121)."""
+    g = load_golden(f"train_{problem}_n128.npz")
+    assert g["step_loss"].shape == (2, 8) and g["val_batch_loss"].shape == (2, 2)
+    assert np.allclose(g["step_loss"].mean(1), g["printed_train_loss"], rtol=1e-12)
+    assert np.allclose(g["val_batch_loss"].mean(1), g["printed_val_loss"], rtol=1e-12)
+    assert np.allclose(g["test_batch_loss"].mean(1), g["printed_test_loss"], rtol=1e-12)
+    t = _train_tensors(g, problem)
+    assert t["Xtr"].shape[0] == 320 and t["Xva"].shape[0] == 80 and t["Xte"].shape[0] == 80
+
+
+@pytest.mark.parametrize("problem", ["adding", "order"])
+def test_seed_42_draws_the_reference_initial_weights(problem):
+    """Same construction order as SyntheticExperiments/psf.py:98-145 => seed_everything(42) gives the reference's
+    initial state_dict bit for bit (what makes a training trajectory comparable at all)."""
+    from sparsefactorization_amd.synthetic_psf import PSFNet
+    from sparsefactorization_amd.train import seed_everything
+    g = load_golden(f"train_{problem}_n128.npz")
+    seed_everything(42)
+    net = PSFNet(**CFG1[problem], use_cuda=False)
+    want = golden_state_dict(g)
+    have = net.state_dict()
+    assert list(have.keys()) == list(want.keys())
+    for k in want:
+        assert torch.equal(have[k], want[k]), k
+
+
+@pytest.mark.parametrize("fixture", sorted(BLOCKS))
+def test_attention_block_construction_matches_reference(fixture):
+    from sparsefactorization_amd.attention_block import PSFNet
+    seed, cfg = BLOCKS[fixture]
+    g = load_golden(fixture)
+    torch.manual_seed(seed)
+    net = PSFNet(**cfg, use_cuda=False)
+    assert net.n_W == int(g["n_W"]) and net.n_links == int(g["n_links"])
+    assert np.array_equal(net.chord_indicies.numpy(), g["chord_indicies"])
+    want = golden_state_dict(g)
+    have = net.state_dict()
+    assert list(have.keys()) == list(want.keys())
+    for k in want:
+        assert torch.equal(have[k], want[k]), k
+
+
+@pytest.mark.parametrize("fixture", sorted(BLOCKS))
+def test_oracle_matches_attention_block_loop(fixture):
+    """Oracle chain and gradients vs the tensors captured around the reference block's hot loop (158-174)."""
+    _, cfg = BLOCKS[fixture]
+    g = load_golden(fixture)
+    W, V0 = g["W"], g["V0"]
+    M, B, N, L = W.shape
+    res = cfg["use_residuals"]
+    rows, cols = oc.chord_indices(N, L)
+    steps = oc.chain(np.stack([rows, cols]), W, V0, res)
+    assert rel_inf(steps[-1], g["Vfin"]) <= 1e-6
+    assert rel_inf(steps[-1], g["out"]) <= 1e-6  # dropout3 with p = 0 is the identity
+    off = oc.spmul_offsets(L) % N
+    grad = g["gVfin"].copy()
+    res_acc = np.zeros_like(V0)
+    dW = np.zeros_like(W)
+    for m in range(M - 1, -1, -1):
+        x_in = V0 if m == 0 else steps[m - 1]
+        if res:
+            res_acc += grad
+        dW[m], grad = oc.spmul_bwd(grad, W[m], x_in, off)
+    assert rel_inf(dW, g["dW"]) <= 1e-5
+    assert rel_inf(grad + res_acc, g["dV0"]) <= 1e-5
+
+
+def test_bench_refuses_more_ranks_than_gpus_without_touching_a_gpu():
+    """`python bench.py --gpus N` starts N ranks itself; with fewer GPUs than ranks the parent says so and returns
+    non-zero before any rank (or any GPU call) is started. Here: no GPU at all, or a 1-GPU box."""
+    n = torch.cuda.device_count() + 1 if torch.cuda.device_count() else 2
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(max(n, 2)), "--steps", "1"],
+                          capture_output=True, text=True, timeout=300)
+    assert proc.returncode != 0
+    assert "GPU(s)" in proc.stderr and "one rank per GPU" in proc.stderr
+    assert '{"metric"' not in proc.stdout
+
+
+# ------------------------------------------------------------------------------------------------------------
+# GPU
+# ------------------------------------------------------------------------------------------------------------
+class _Recording(torch.nn.Module):
+    def __init__(self, inner):
+        super().__init__()
+        self.inner, self.values = inner, []
+
+    def forward(self, pred, target):
+        out = self.inner(pred, target)
+        self.values.append(out.detach().clone())
+        return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("problem", ["adding", "order"])
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_train_harness_follows_the_reference_trajectory(gpu, problem, mode):
+    """train.TrainModel (eager, and replaying train.GraphedStep) on the fixture's batches reproduces the loss after
+    each of the reference loop's 16 optimiser steps to 1e-4 relative, and the evaluation numbers it printed."""
+    from sparsefactorization_amd.synthetic_psf import PSFNet
+    from sparsefactorization_amd.train import DeviceBatches, GraphedStep, TrainModel, make_adam, seed_everything
+    g = load_golden(f"train_{problem}_n128.npz")
+    seed_everything(42)
+    net = PSFNet(**CFG1[problem], use_cuda=True).to(gpu)
+    for k, v in golden_state_dict(g).items():
+        assert torch.equal(net.state_dict()[k].cpu(), v), k
+    t = _train_tensors(g, problem, gpu)
+    mk = lambda X, Y: DeviceBatches(X, Y, 40, shuffle=False, drop_last=True)  # noqa: E731
+    loss = _Recording(torch.nn.MSELoss() if problem == "adding" else torch.nn.CrossEntropyLoss())
+    optimizer = make_adam(net.parameters(), 0.001, capturable=mode == "graph")
+    graphed = None
+    if mode == "graph":
+        graphed = GraphedStep(net, optimizer, loss.inner, t["Xtr"][:40], t["Ytr"][:40])
+        steps = []
+        real_call = graphed.__call__
+
+        class _Tap:  # record the loss each replay returns (the graph holds loss.inner, not the recorder)
+            def __call__(self, X, Y):
+                out = real_call(X, Y)
+                steps.append(out.detach().clone())
+                return out
+        tap = _Tap()
+    logs = []
+    hist = TrainModel(net=net, trainloader=mk(t["Xtr"], t["Ytr"]), valloader=mk(t["Xva"], t["Yva"]),
+                      testloader=mk(t["Xte"], t["Yte"]), n_epochs=2, test_freq=1, optimizer=optimizer, loss=loss,
+                      problem=problem, saving_criteria=1e9, log=logs.append, graphed=tap if graphed is not None else None)
+    vals = np.asarray([float(v) for v in loss.values])
+    if mode == "graph":
+        got_steps = np.asarray([float(v) for v in steps]).reshape(2, 8)
+        got_eval = vals.reshape(2, 4)
+    else:
+        got = vals.reshape(2, 12)
+        got_steps, got_eval = got[:, :8], got[:, 8:]
+    assert np.max(np.abs(got_steps - g["step_loss"]) / np.abs(g["step_loss"])) <= 1e-4, (got_steps, g["step_loss"])
+    assert np.allclose(got_eval[:, :2], g["val_batch_loss"], rtol=2e-4)
+    assert np.allclose(got_eval[:, 2:], g["test_batch_loss"], rtol=2e-4)
+    for e in range(2):
+        assert abs(hist[e]["train"]["loss"] - g["printed_train_loss"][e]) <= 1e-4 * g["printed_train_loss"][e]
+        assert abs(hist[e]["val"]["loss"] - g["printed_val_loss"][e]) <= 2e-4 * g["printed_val_loss"][e]
+        # accuracy is a count over 80 samples: allow one borderline sample (1.25 %)
+        assert abs(hist[e]["val"]["accuracy"] - g["printed_val_acc"][e]) <= 1.25 + 1e-6
+        assert abs(hist[e]["test"]["accuracy"] - g["printed_test_acc"][e]) <= 1.25 + 1e-6
+    assert any("Training loss" in s for s in logs)
+    # parameters after 16 Adam steps (each moves an element by at most lr = 1e-3)
+    final = {k[7:]: g[k] for k in g.files if k.startswith("final::")}
+    worst = max(float(np.max(np.abs(net.state_dict()[k].cpu().numpy() - v))) for k, v in final.items())
+    assert worst <= 5e-4, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture", sorted(BLOCKS))
+def test_attention_block_matches_reference(gpu, fixture):
+    """attention_block.PSFNet on the GPU: module output vs the reference's (<= 1e-4, the MLPs round differently),
+    the chain on the reference's captured operands vs its result (<= 1e-5; bit-equal to the oracle), gradients of
+    the chain vs autograd through the reference (<= 1e-5)."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.attention_block import PSFNet
+    _, cfg = BLOCKS[fixture]
+    g = load_golden(fixture)
+    net = PSFNet(**cfg, use_cuda=True)
+    net.load_state_dict(golden_state_dict(g), strict=True)
+    net = net.to(gpu).eval()
+    with torch.no_grad():
+        out = net(torch.from_numpy(g["x"]).to(gpu))
+    assert out.shape == g["out"].shape and rel_inf(out.cpu().numpy(), g["out"]) <= 1e-4
+
+    Ws = [torch.from_numpy(w.copy()).to(gpu).requires_grad_(True) for w in g["W"]]
+    V0 = torch.from_numpy(g["V0"].copy()).to(gpu).requires_grad_(True)
+    Vf = sfa.chord_chain(Ws, V0, cfg["use_residuals"])
+    assert rel_inf(Vf.detach().cpu().numpy(), g["Vfin"]) <= 1e-5
+    M, B, N, L = g["W"].shape
+    rows, cols = oc.chord_indices(N, L)
+    want = oc.chain(np.stack([rows, cols]), g["W"], g["V0"], cfg["use_residuals"])[-1]
+    assert np.array_equal(Vf.detach().cpu().numpy(), want)
+    Vf.backward(torch.from_numpy(g["gVfin"].copy()).to(gpu))
+    dW = np.stack([w.grad.cpu().numpy() for w in Ws])
+    assert rel_inf(dW, g["dW"]) <= 1e-5
+    assert rel_inf(V0.grad.cpu().numpy(), g["dV0"]) <= 1e-5
+
+    # and through the module: parameter gradients flow, the same loss as the fixture's
+    net.train()
+    out = net(torch.from_numpy(g["x"]).to(gpu))
+    loss = (out * torch.from_numpy(g["gout"]).to(gpu)).sum()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * max(1.0, abs(float(g["loss"])))
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+@pytest.mark.gpu
+def test_graphed_step_refuses_an_uncapturable_embedding(gpu):
+    """A 600-token vocabulary is beyond the capturable table-gradient kernel (vocab <= 512): its gradient would run
+    on aten::embedding_dense_backward, whose replay from a HIP graph faulted the GPU in round 1
+    (profiles/r01_graph_step_lab.log). GraphedStep must raise BEFORE capturing anything; eager training still works."""
+    from sparsefactorization_amd.lra_psf import PSFNet
+    from sparsefactorization_amd.token_linear import embedding_wgrad
+    from sparsefactorization_amd.train import GraphedStep, make_adam
+    torch.manual_seed(0)
+    net = PSFNet(vocab_size=600, embedding_size=16, n_vec=128, n_W=7, Ws=[16, 'GELU'], V=[16, 'GELU'], n_channels_V=8,
+                 n_class=2, pooling_type="FLATTEN", head=['linear'], use_cuda=True, use_residuals=False, dropout1_p=0,
+                 dropout2_p=0, dropout3_p=0, init_embedding_weights=False, use_pos_embedding=True,
+                 problem="pathfinder").to(gpu)
+    X = torch.randint(0, 600, (8, 128), device=gpu)
+    Y = torch.randint(0, 2, (8,), device=gpu)
+    loss = torch.nn.CrossEntropyLoss()
+    opt = make_adam(net.parameters(), 1e-3, capturable=True)
+    before = [p.detach().clone() for p in net.parameters()]
+    with pytest.raises(RuntimeError, match="vocab <= 512"):
+        GraphedStep(net, opt, loss, X, Y)
+    assert not torch.cuda.is_current_stream_capturing()
+    assert all(torch.equal(a, b) for a, b in zip(before, net.parameters()))  # nothing ran
+    # the eager path is untouched by the refusal
+    loss(net(X), Y).backward()
+    assert net.embedding.weight.grad is not None and torch.isfinite(net.embedding.weight.grad).all()
+    # and the operator itself refuses under capture instead of calling the aten fallback
+    idx = torch.randint(0, 600, (4096,), device=gpu)
+    dout = torch.randn(4096, 16, device=gpu)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="cannot be captured"):
+        with torch.cuda.graph(graph):
+            embedding_wgrad(idx, dout, 600, None)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_training_driver_under_a_one_rank_rccl_group(gpu, monkeypatch, capsys):
+    """psf_training.main inside a real RCCL process group (one rank — all a 1-GPU box has) with the flat gradient
+    all-reduce forced on: the collective path runs on the real PSFNet, replicas are broadcast, and parameters that
+    never receive a gradient (Adding: `embedding`, `pos_embedding`, SyntheticExperiments/psf.py:98-107) stay at
+    grad None through the reducer, in eager mode and with forward+backward replayed from a HIP graph."""
+    import socket
+    import torch.distributed as dist
+    from sparsefactorization_amd import psf_training
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    for k, v in dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)).items():
+        monkeypatch.setenv(k, v)
+    try:
+        for extra in ([], ["--graph"]):
+            r = psf_training.main(["--problem", "adding", "--n-vec", "256", "--train-seqs", "240", "--eval-seqs", "80",
+                                   "--json", "--max-steps", "4", "--force-allreduce", *extra])
+            assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+            net, reducer = r["net"], r["reducer"]
+            assert reducer is not None and reducer.calls >= 4
+            assert net.embedding.weight.grad is None and net.pos_embedding.weight.grad is None
+            assert net.final.weight.grad is not None and torch.isfinite(net.final.weight.grad).all()
+            assert np.isfinite(r["stats"]["loss"])
+            assert '"metric": "PSF train tokens/sec"' in capsys.readouterr().out
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()

@@ -11,10 +11,23 @@ from sparsefactorization_amd import synth_data
 from sparsefactorization_amd.train import DatasetCreator, TrainModel, count_params, evaluate, seed_everything
 
 
-def test_adding_distribution():
+def _device(request, name):
+    """'cpu', or the `gpu` fixture (skips without a GPU): the generators are written once for both and the
+    distribution checks run on the device the benchmark and the drivers actually generate on."""
+    return torch.device("cpu") if name == "cpu" else request.getfixturevalue("gpu")
+
+
+DEVICES = ["cpu", pytest.param("gpu", marks=pytest.mark.gpu)]
+
+
+@pytest.mark.parametrize("where", DEVICES)
+def test_adding_distribution(request, where):
     """synth_data_generation.py:8-28: x in (-1,1), exactly two distinct markers, label 0.5 + (x1+x2)/4."""
-    g = torch.Generator().manual_seed(0)
-    data, labels = synth_data.adding(5000, 64, generator=g)
+    dev = _device(request, where)
+    g = torch.Generator(device=dev).manual_seed(0)
+    data, labels = synth_data.adding(5000, 64, device=dev, generator=g)
+    assert data.device.type == dev.type
+    data, labels = data.cpu(), labels.cpu()
     assert data.shape == (5000, 64, 2) and data.dtype == torch.float32 and labels.shape == (5000,)
     x, y = data[..., 0], data[..., 1]
     assert float(x.min()) >= -1 and float(x.max()) <= 1 and abs(float(x.mean())) < 0.01
@@ -25,10 +38,14 @@ def test_adding_distribution():
     assert abs(float(first) - (64 - 2) / 3) < 1.0
 
 
-def test_temporal_order_distribution():
+@pytest.mark.parametrize("where", DEVICES)
+def test_temporal_order_distribution(request, where):
     """synth_data_generation.py:30-70: tokens 0..3, two ordered special positions from {4,5}, 4 classes."""
-    g = torch.Generator().manual_seed(1)
-    data, labels = synth_data.temporal_order(4000, 32, generator=g)
+    dev = _device(request, where)
+    g = torch.Generator(device=dev).manual_seed(1)
+    data, labels = synth_data.temporal_order(4000, 32, device=dev, generator=g)
+    assert data.device.type == dev.type
+    data, labels = data.cpu(), labels.cpu()
     assert data.shape == (4000, 32, 1) and data.dtype == torch.int64
     x = data[..., 0]
     special = x >= 4
