@@ -31,6 +31,8 @@ SHAPES = {
     "cfg4_train": (64, 1024, 11, 32, False),   # Pathfinder32
     "cfg4_map": (8, 1024, 11, 1024, False),    # attention map, C = N
     "genome": (16, 16384, 14, 32, True),
+    "imdb": (32, 4097, 12, 32, True),          # ragged last tile (4097 = 64*64 + 1)
+    "n2000_c16": (32, 2000, 11, 16, True),     # ragged, narrow rows
 }
 
 PS = {"chain_fused": 0}  # per-step launches (the shipped default fuses short sequences into one launch)

@@ -9,6 +9,7 @@
 
 #include <atomic>
 
+#include "bwd_dw_chunk.h"
 #include "bwd_window.h"
 #include "bwd_window_launch.h"
 
@@ -47,6 +48,32 @@ hipError_t launch_dv(const BwdWinArgs& a) {
   return hipGetLastError();
 }
 
+template <int L, int TGS, int R, int NT, bool EDGE>
+hipError_t launch_dwc(const BwdWinArgs& a) {
+  using Cfg = DwChunkCfg<L, TGS, R, NT>;
+  auto kern = chord_dw_chunk_k<L, TGS, R, NT, EDGE>;
+  static std::atomic<int> done{0};
+  if (hipError_t e = raise_lds_limit(kern, Cfg::lds_bytes, done); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(NT), Cfg::lds_bytes, a.stream, a.dZ, a.WV, a.out, a.gm, a.offs,
+                     a.w_total);
+  return hipGetLastError();
+}
+
+template <int TGS, int R, int NT>
+hipError_t launch_dwc_L(int L, const BwdWinArgs& a) {
+  switch (L) {
+#define PSF_CASE(LL) \
+  case LL:           \
+    return a.edge ? launch_dwc<LL, TGS, R, NT, true>(a) : launch_dwc<LL, TGS, R, NT, false>(a);
+    PSF_CASE(4) PSF_CASE(5) PSF_CASE(6) PSF_CASE(7) PSF_CASE(8) PSF_CASE(9) PSF_CASE(10) PSF_CASE(11)
+    PSF_CASE(12) PSF_CASE(13) PSF_CASE(14) PSF_CASE(15) PSF_CASE(16) PSF_CASE(17) PSF_CASE(18)
+    PSF_CASE(19) PSF_CASE(20)
+#undef PSF_CASE
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+
 template <int TGS, int R, int NT, bool DW>
 hipError_t launch_L(int L, const BwdWinArgs& a) {
   switch (L) {
@@ -73,6 +100,15 @@ hipError_t launch_dw_win(int rows, int L, const BwdWinArgs& a) {
   return hipErrorInvalidValue;
 }
 template hipError_t launch_dw_win<PSF_TGS>(int rows, int L, const BwdWinArgs& a);
+
+#if PSF_TGS >= 3 && PSF_TGS <= 4
+template <int TGS>
+hipError_t launch_dw_chunk(int L, const BwdWinArgs& a) {
+  static_assert(TGS >= kDwChunkTgsMin && TGS <= kDwChunkTgsMax, "chunk lanes per row");
+  return launch_dwc_L<TGS, 1, 256>(L, a);
+}
+template hipError_t launch_dw_chunk<PSF_TGS>(int L, const BwdWinArgs& a);
+#endif
 #endif
 
 template <int TGS, int NT>

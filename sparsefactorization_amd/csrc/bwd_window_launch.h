@@ -21,6 +21,13 @@ struct BwdWinArgs {
 
 template <int TGS>
 hipError_t launch_dw_win(int rows, int L, const BwdWinArgs& a);
+// chunk-looping dW (bwd_dw_chunk.h) for rows of >= 32 channels: 8 or 16 lanes per row chunk (TGS 3 / 4), 256 threads,
+// one row per thread. r02 sweep (profiles/r02c_dw_sweep*.log, us per launch at ListOps N=2000 C=128 / genome C=32):
+// TG=8 R=1 21.0 (15.3 in one launch) / 20.6; TG=16 R=1 15.2 / 20.7; R=2 25.5 / 24.8; 1024 threads x 1 row 28.2 / 33.5;
+// TG=4 27.6 / 26.3; whole-row kernel 29.0 / 26.1 — short tiles with many workgroups per CU win, so only R = 1 is built.
+constexpr int kDwChunkTgsMin = 3, kDwChunkTgsMax = 4;
+template <int TGS>
+hipError_t launch_dw_chunk(int L, const BwdWinArgs& a);
 template <int TGS, int NT>
 hipError_t launch_dv_win(int rows, int L, const BwdWinArgs& a);
 

@@ -41,8 +41,12 @@ std::atomic<int> g_fwd_variant{0};  // 0 auto, 1 generic, 2 window
 std::atomic<int> g_bwd_variant{0};  // 0 auto, 1 generic
 std::atomic<int> g_xcd_remap{1};
 std::atomic<int> g_fwd_rows{0};     // 0 = default, else rows per thread (R) of the window kernel
-std::atomic<int> g_fwd_split{1};    // 1 = full tiles on the predicate-free kernel + ragged tiles separately
+// 1 = full tiles on the predicate-free kernel + the ragged last tiles in a second small launch, except on small
+// problems (one predicated launch); 2 = always two launches; 0 = always one predicated launch
+std::atomic<int> g_fwd_split{1};
 std::atomic<int> g_bwd_rows{0};     // 0 = default, else rows per thread (R) of the backward window kernels
+std::atomic<int> g_dw_variant{0};   // dW: 0 = auto (chunk-looping kernel for C >= 32), 1 = whole-row window kernel, 2 = chunk forced
+std::atomic<int> g_dw_tgs{0};       // chunk-looping dW: 0 = auto, 4 = 8 lanes per row chunk, 5 = 16 lanes
 std::atomic<int> g_chain_fused{1};  // 1 = short sequences run the whole chain in one LDS-resident launch
 std::atomic<int> g_chain_cc{0};     // fused chain: 0 = auto channel groups per workgroup, 1 = one
 // Rows of >= 64 channels: 0 = one workgroup spans the whole row (default); 1 = 32-channel chunks on 1024-thread
@@ -69,8 +73,10 @@ struct Knob {
 };
 Knob g_knobs[] = {
     {"fwd_variant", &g_fwd_variant, 0, 2}, {"bwd_variant", &g_bwd_variant, 0, 1}, {"xcd_remap", &g_xcd_remap, 0, 1},
-    {"fwd_rows", &g_fwd_rows, 0, 8},       {"fwd_split", &g_fwd_split, 0, 1},     {"bwd_rows", &g_bwd_rows, 0, 8},
+    {"fwd_rows", &g_fwd_rows, 0, 8},       {"fwd_split", &g_fwd_split, 0, 2},     {"bwd_rows", &g_bwd_rows, 0, 8},
     {"fwd_wide", &g_fwd_wide, 0, 2},
+    {"dw_variant", &g_dw_variant, 0, 2},
+    {"dw_tgs", &g_dw_tgs, 0, 5},
     {"fwd_wg_limit", &g_fwd_wg_limit, 0, 4},
     {"chain_zigzag", &g_chain_zigzag, 0, 1},
     {"chain_fused", &g_chain_fused, 0, 1},
@@ -186,6 +192,53 @@ hipError_t launch_dv(const WinPick& pk, int L, const BwdWinArgs& a) {
 }
 #undef PSF_TGS_SWITCH
 
+// A ragged last tile per sequence (N % TR != 0) runs on the EDGE instance. In a second launch of its own it costs a
+// kernel boundary, ~2.7 us whatever the shape (r02d: IMDb N = 4097, C = 32: 15.3 us split vs 12.7 in one predicated
+// launch; N = 2000, C = 16: 7.7 vs 5.0; dW at N = 2000, C = 128: 21.9 vs 16.1); predicating EVERY tile costs 0-5 % of the
+// launch (r01c: cfg2 27.6 -> 28.9 us). So: one predicated launch unless the launch is long enough for 5 % to exceed the
+// boundary, i.e. beyond ~300 MB of algorithmic bytes.
+bool ragged_in_one_launch(bool ragged, int64_t B, int64_t N, int32_t L, int64_t C) {
+  return ragged && g_fwd_split.load() == 1 && 4 * B * N * (L + 3 * C) <= (int64_t)300 * 1000 * 1000;
+}
+
+hipError_t launch_dwc(const WinPick& pk, int L, const BwdWinArgs& a) {
+  switch (pk.tgs) {
+    case 3: return launch_dw_chunk<3>(L, a);
+    case 4: return launch_dw_chunk<4>(L, a);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// Chunk-looping dW (bwd_dw_chunk.h), rows of >= 32 channels whose channel groups split into chunks of 8 (or 16) lanes:
+// 256 threads x 1 row, so tiles of 32 (16) rows. Fills `pick` when the kernel applies.
+bool pick_dw_chunk(const void* dW, int64_t B, int64_t N, int32_t L, int64_t C, const Offsets& offs, bool vec_ok,
+                   WinPick* pick) {
+  if (!vec_ok || L < kWinLmin || L > kWinLmax) return false;
+  const int64_t CG = C / 4;
+  if (CG % 8 != 0 || CG / 8 > 4096) return false;
+  int tgs = 3;
+  const int knob = g_dw_tgs.load();
+  // 16 lanes per row chunk (16-row tiles) when that spares the launch its ragged last tile (ListOps: N = 2000 = 125 * 16)
+  if (knob == 5 || (knob == 0 && CG % 16 == 0 && N % 32 != 0 && N % 16 == 0)) tgs = CG % 16 == 0 ? 4 : 3;
+  const int TR = win_tile_rows(tgs, 1, 256);
+  if (N < 2 * (int64_t)TR) return false;
+  int KN = 2;
+  for (int t = TR; t > 1; t >>= 1) ++KN;
+  if (KN > L) KN = L;
+  for (int k = 0; k < KN; ++k)
+    if (offs.v[k] != (k == 0 ? 0 : 1 << (k - 1))) return false;  // near offsets are compile-time in this kernel
+  if (N * C >= ((int64_t)1 << 31)) return false;                 // 32-bit element offsets inside a batch element
+  pick->tgs = tgs;
+  pick->rows = 1;
+  pick->nt = 256;
+  pick->TR = TR;
+  pick->KN = KN;
+  pick->tiles_full = (int)(N / TR);
+  pick->ragged = (N % TR) != 0;
+  pick->all_edge = ragged_in_one_launch(pick->ragged, B, N, L, C) || !aligned_to(dW, 16) || ((N * (int64_t)L) % 4) != 0 || !g_fwd_split.load();
+  return true;
+}
+
 hipError_t launch_dw(const WinPick& pk, int L, const BwdWinArgs& a) {
   switch (pk.tgs) {
     case 0: return launch_dw_win<0>(pk.rows, L, a);
@@ -233,7 +286,8 @@ bool pick_window(const void* W, int64_t B, int64_t N, int32_t L, int64_t C, cons
   pick->tiles_full = (int)(N / TR);
   pick->ragged = (N % TR) != 0;
   const int TG = 1 << tgs;
-  pick->all_edge = (CG % TG) != 0 || !aligned_to(W, 16) || ((B * N * (int64_t)L) % 4) != 0 || !g_fwd_split.load();
+  pick->all_edge = (CG % TG) != 0 || !aligned_to(W, 16) || ((B * N * (int64_t)L) % 4) != 0 || !g_fwd_split.load() ||
+                   ragged_in_one_launch(pick->ragged, B, N, L, C);
   return true;
 }
 
@@ -355,6 +409,18 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
       const int rows_dv = knob ? knob : 2, rows_dw = knob ? knob : 1;
       // dW before dV: dV's output is the next (earlier) step's dZ, read first thing by that step's kernels; writing
       // it last leaves it cache-hot (dV 27.4 -> 26.9 us, dW 20.5 -> 20.4 us in the Order training step)
+      const int dwv = g_dw_variant.load();
+      if (dW && dwv != 1 &&
+          pick_dw_chunk(dW, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(V, 16), &pk)) {
+        BwdWinArgs a{dZ, V, dW, Geom{}, offs, w_total, false, s};
+        int rc = window_launches(pk, pk.all_edge, B, N, L, C, v_batch_stride, false, &a.gm, &a.edge,
+                                 [&] { return launch_dwc(pk, L, a); }, "chord_dw_chunk");
+        if (rc) return rc;
+        dW = nullptr;
+      } else if (dW && dwv == 2) {
+        return fail(PSF_E_TUNING, "dw_variant=2 forced but the chunk-looping dW kernel does not apply to N=%lld L=%d C=%lld",
+                    (long long)N, (int)L, (long long)C);
+      }
       if (dW && C / 4 <= TGmax &&
           pick_window(dW, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(V, 16), &pk,
                       rows_dw, false)) {

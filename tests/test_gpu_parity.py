@@ -68,7 +68,7 @@ def test_forward_window_rows_variants(gpu, B, N, L, C, rows):
     assert np.array_equal(got, _oracle_fwd(W, V, R))
 
 
-@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("split", [0, 1, 2])  # one predicated launch / auto / full tiles + ragged tiles in two launches
 @pytest.mark.parametrize("B,N,L,C,shift", [(3, 1101, 11, 8, 0), (3, 1101, 11, 8, 1), (2, 2000, 12, 16, 3),
                                            (1, 515, 9, 32, 2), (5, 777, 13, 8, 1)])
 def test_forward_window_w_alignment_edges(gpu, B, N, L, C, shift, split):
@@ -89,7 +89,7 @@ def test_forward_window_w_alignment_edges(gpu, B, N, L, C, shift, split):
     assert np.array_equal(got, _oracle_fwd(W, V, R))
 
 
-@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("split", [0, 1, 2])
 def test_forward_split_and_edge_kernels_agree_on_all_shapes(gpu, split):
     import sparsefactorization_amd as sfa
     sfa.set_tuning("fwd_split", split)
@@ -253,6 +253,78 @@ def test_backward_window_kernels(gpu, B, N, L, C, rows):
     for variant, (gW, gV) in got.items():
         assert np.array_equal(gV, dV), f"dV variant={variant}"
         assert rel_inf(gW, dF) <= TOL, f"dW variant={variant}"
+
+
+@pytest.mark.parametrize("split", [0, 2])
+@pytest.mark.parametrize("B,N,L,C", [(2, 1101, 11, 8), (1, 4097, 13, 8), (2, 2000, 12, 128), (2, 777, 9, 16)])
+def test_backward_window_kernels_launch_modes(gpu, B, N, L, C, split):
+    """Ragged shapes: one predicated launch (fwd_split=0) and full tiles + ragged tiles in two launches (2); the default
+    (1) picks between them by size and is what every other test runs."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.chord import _launch_bwd
+    W, V, dZ = _mk((B, N, L), 61), _mk((B, N, C), 62), _mk((B, N, C), 63)
+    dF, dV = oc.spmul_bwd(dZ, W, V)
+    for dw_variant in (0, 1):
+        sfa.set_tuning("fwd_split", split)
+        sfa.set_tuning("dw_variant", dw_variant)
+        try:
+            gW = torch.full((B, N, L), float("nan"), device=gpu)
+            gV = torch.full((B, N, C), float("nan"), device=gpu)
+            _launch_bwd(_t(dZ, gpu), _t(W, gpu), _t(V, gpu), gW, gV, B, N, L, C, N * C, None)
+        finally:
+            sfa.set_tuning("fwd_split", 1)
+            sfa.set_tuning("dw_variant", 0)
+        assert np.array_equal(gV.cpu().numpy(), dV)
+        assert rel_inf(gW.cpu().numpy(), dF) <= TOL
+
+
+@pytest.mark.parametrize("tgs", [0, 4, 5])  # auto / 8 lanes per row chunk / 16
+@pytest.mark.parametrize("split", [0, 1, 2])
+@pytest.mark.parametrize("B,N,L,C", [(2, 2000, 12, 128), (2, 2048, 12, 64), (3, 1000, 11, 32), (1, 4097, 13, 32),
+                                     (2, 515, 10, 96), (2, 700, 15, 160), (1, 16384, 15, 32), (2, 300, 20, 64)])
+def test_backward_dw_chunk_kernel(gpu, B, N, L, C, split, tgs):
+    """Chunk-looping dW (csrc/bwd_dw_chunk.h: rows of >= 32 channels, 8 or 16 lanes per 32- / 64-channel chunk, DPP
+    row sums) vs the oracle, <= 1e-5; forced on (dw_variant=2), every launch mode, chunk counts 1..5, ragged and
+    full tilings, non-power-of-two N; a view that starts 8 bytes into an allocation (element-wise tile ends)."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.chord import _launch_bwd
+    if tgs == 5 and (C // 4) % 16 != 0:
+        pytest.skip("16 lanes per chunk need C % 64 == 0")
+    W, V, dZ = _mk((B, N, L), 71), _mk((B, N, C), 72), _mk((B, N, C), 73)
+    dF, _ = oc.spmul_bwd(dZ, W, V)
+    for shift in (0, 2):
+        gbuf = torch.full((B * N * L + 8,), float("nan"), device=gpu)
+        gW = gbuf[shift:shift + B * N * L].view(B, N, L)
+        sfa.set_tuning("dw_variant", 2)
+        sfa.set_tuning("dw_tgs", tgs)
+        sfa.set_tuning("fwd_split", split)
+        try:
+            _launch_bwd(_t(dZ, gpu), _t(W, gpu), _t(V, gpu), gW, None, B, N, L, C, N * C, None)
+        finally:
+            sfa.set_tuning("dw_variant", 0)
+            sfa.set_tuning("dw_tgs", 0)
+            sfa.set_tuning("fwd_split", 1)
+        assert rel_inf(gW.cpu().numpy(), dF) <= TOL, shift
+        assert torch.isnan(gbuf[:shift]).all() and torch.isnan(gbuf[shift + B * N * L:]).all()
+
+
+def test_backward_dw_chunk_kernel_is_the_default_for_wide_rows(gpu):
+    """dw_variant=2 raises where the chunk kernel does not apply, so: it applies at C = 32 / 128 and not at C = 8."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.chord import _launch_bwd
+    sfa.set_tuning("dw_variant", 2)
+    try:
+        for C, ok in ((32, True), (128, True), (8, False), (36, False)):
+            B, N, L = 1, 512, 10
+            args = [torch.zeros(B, N, C, device=gpu), torch.zeros(B, N, L, device=gpu), torch.zeros(B, N, C, device=gpu),
+                    torch.empty(B, N, L, device=gpu), None, B, N, L, C, N * C, None]
+            if ok:
+                _launch_bwd(*args)
+            else:
+                with pytest.raises(RuntimeError, match="dw_variant=2"):
+                    _launch_bwd(*args)
+    finally:
+        sfa.set_tuning("dw_variant", 0)
 
 
 @pytest.mark.parametrize("wide", [1, 2])
