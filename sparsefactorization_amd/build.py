@@ -72,6 +72,10 @@ def _units():
                       [f"-DPSF_TGS={t}"]))
         units.append((os.path.join(OBJ_DIR, f"bwd_window_tgs{t}.o"), os.path.join(CSRC, "bwd_window_inst.hip"),
                       [f"-DPSF_TGS={t}"]))
+    # dV at 512 threads x 1 row per thread for narrow rows (bwd_window_launch.h: kDvMidThreads, kDvMidTgsMax)
+    for t in range(4):
+        units.append((os.path.join(OBJ_DIR, f"bwd_window_mid_tgs{t}.o"), os.path.join(CSRC, "bwd_window_inst.hip"),
+                      [f"-DPSF_TGS={t}", "-DPSF_NT=512"]))
     # wide-row configuration (fwd_window_launch.h: kWideTgs, kWideThreads)
     wide = ["-DPSF_TGS=3", "-DPSF_NT=1024"]
     units.append((os.path.join(OBJ_DIR, "fwd_window_wide.o"), os.path.join(CSRC, "fwd_window_inst.hip"), wide))

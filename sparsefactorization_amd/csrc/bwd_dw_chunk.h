@@ -124,7 +124,7 @@ chord_dw_chunk_k(const float* __restrict__ dZ, const float* __restrict__ V, floa
 #pragma unroll
       for (int k = 0; k < L; ++k) {
         V4 x;
-        if (k < KN) x = sRow0[(j * RS + (k == 0 ? 0 : (1 << (k - 1)))) << TGS];
+        if (k < KN) x = sRow0[(j * RS + chord_off(k)) << TGS];
         else x = far[j][k - KN < NF ? k - KN : 0];
         T part = mul_rn(dz[j].e[0], x.e[0]);
 #pragma unroll

@@ -135,7 +135,7 @@ chord_dw_win_k(const T* __restrict__ dZ, const T* __restrict__ V, T* __restrict_
 #pragma unroll
     for (int k = 0; k < L; ++k) {
       V4 x;
-      if (k < KN) x = sWin[((pl + offs.v[k]) << TGS) + g];
+      if (k < KN) x = sWin[((pl + chord_off(k)) << TGS) + g];
       else x = far[j][k - KN < NF ? k - KN : 0];
       T part = T(0);
 #pragma unroll
@@ -243,7 +243,7 @@ chord_dv_win_k(const T* __restrict__ dZ, const T* __restrict__ W, T* __restrict_
     for (int i = 0; i < VEC; ++i) acc.e[i] = T(0);
 #pragma unroll
     for (int k = 0; k < KN; ++k) {
-      const int wr = TR + pl - offs.v[k];  // in [0, 2TR): offs.v[k] <= TR for near links
+      const int wr = TR + pl - chord_off(k);  // in [0, 2TR): near offsets are <= TR
       const T w = wr < TR ? sWpF[misP + wr * L + k] : sWcF[misC + (wr - TR) * L + k];
       axpy_rn<T, VEC>(acc, w, sWin[(wr << TGS) + g]);
     }

@@ -113,9 +113,11 @@ template hipError_t launch_dw_chunk<PSF_TGS>(int L, const BwdWinArgs& a);
 
 template <int TGS, int NT>
 hipError_t launch_dv_win(int rows, int L, const BwdWinArgs& a) {
-  static_assert(win_pair_compiled(TGS, NT), "not a compiled (TGS, NT) pair");
+  static_assert(dv_pair_compiled(TGS, NT), "not a compiled (TGS, NT) pair");
   if (rows == 1) return launch_L<TGS, 1, NT, false>(L, a);
-  if (rows == 2) return launch_L<TGS, 2, NT, false>(L, a);
+  if constexpr (NT != kDvMidThreads) {
+    if (rows == 2) return launch_L<TGS, 2, NT, false>(L, a);
+  }
   return hipErrorInvalidValue;
 }
 template hipError_t launch_dv_win<PSF_TGS, PSF_NT>(int rows, int L, const BwdWinArgs& a);

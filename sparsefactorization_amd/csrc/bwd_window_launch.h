@@ -28,6 +28,13 @@ hipError_t launch_dw_win(int rows, int L, const BwdWinArgs& a);
 constexpr int kDwChunkTgsMin = 3, kDwChunkTgsMax = 4;
 template <int TGS>
 hipError_t launch_dw_chunk(int L, const BwdWinArgs& a);
+// dV: the forward's (TGS, NT) pairs plus 512 threads x 1 row per thread for narrow rows (TGS <= 3): the same 256-row
+// tile as 256 threads x 2 rows at C = 8, with twice the waves per workgroup sharing the staged W tiles — r02 lab
+// (profiles/dvlab.hip): 28.65 vs 29.05 us at cfg2 next to the shipped kernel's 30.07.
+constexpr int kDvMidThreads = 512, kDvMidTgsMax = 3;
+constexpr bool dv_pair_compiled(int tgs, int nt) {
+  return win_pair_compiled(tgs, nt) || (nt == kDvMidThreads && tgs >= 0 && tgs <= kDvMidTgsMax);
+}
 template <int TGS, int NT>
 hipError_t launch_dv_win(int rows, int L, const BwdWinArgs& a);
 

@@ -156,7 +156,7 @@ __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* _
     const T* __restrict__ wrow = sWf + mis + pl * L;
 #pragma unroll
     for (int k = 0; k < KN; ++k) {
-      const V4 x = sWin[((pl + offs.v[k]) << TGS) + g];
+      const V4 x = sWin[((pl + chord_off(k)) << TGS) + g];
       axpy_rn<T, VEC>(acc, wrow[k], x);
     }
 #pragma unroll

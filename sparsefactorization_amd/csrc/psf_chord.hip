@@ -45,6 +45,8 @@ std::atomic<int> g_fwd_rows{0};     // 0 = default, else rows per thread (R) of 
 // problems (one predicated launch); 2 = always two launches; 0 = always one predicated launch
 std::atomic<int> g_fwd_split{1};
 std::atomic<int> g_bwd_rows{0};     // 0 = default, else rows per thread (R) of the backward window kernels
+// dV workgroup: 0 = auto, 1 = 256 threads (rows per thread from bwd_rows), 2 = 512 threads x 1 row (TGS <= 3)
+std::atomic<int> g_dv_threads{0};
 std::atomic<int> g_dw_variant{0};   // dW: 0 = auto (chunk-looping kernel for C >= 32), 1 = whole-row window kernel, 2 = chunk forced
 std::atomic<int> g_dw_tgs{0};       // chunk-looping dW: 0 = auto, 4 = 8 lanes per row chunk, 5 = 16 lanes
 std::atomic<int> g_chain_fused{1};  // 1 = short sequences run the whole chain in one LDS-resident launch
@@ -76,6 +78,7 @@ Knob g_knobs[] = {
     {"fwd_rows", &g_fwd_rows, 0, 8},       {"fwd_split", &g_fwd_split, 0, 2},     {"bwd_rows", &g_bwd_rows, 0, 8},
     {"fwd_wide", &g_fwd_wide, 0, 2},
     {"dw_variant", &g_dw_variant, 0, 2},
+    {"dv_threads", &g_dv_threads, 0, 2},
     {"dw_tgs", &g_dw_tgs, 0, 5},
     {"fwd_wg_limit", &g_fwd_wg_limit, 0, 4},
     {"chain_zigzag", &g_chain_zigzag, 0, 1},
@@ -188,6 +191,15 @@ hipError_t launch_win(const WinPick& pk, int L, const FwdWinArgs& a) {
 
 hipError_t launch_dv(const WinPick& pk, int L, const BwdWinArgs& a) {
   if (pk.nt == kWideThreads) return pk.tgs == kWideTgs ? launch_dv_win<kWideTgs, kWideThreads>(pk.rows, L, a) : hipErrorInvalidValue;
+  if (pk.nt == kDvMidThreads) {
+    switch (pk.tgs) {
+      case 0: return launch_dv_win<0, kDvMidThreads>(pk.rows, L, a);
+      case 1: return launch_dv_win<1, kDvMidThreads>(pk.rows, L, a);
+      case 2: return launch_dv_win<2, kDvMidThreads>(pk.rows, L, a);
+      case 3: return launch_dv_win<3, kDvMidThreads>(pk.rows, L, a);
+      default: return hipErrorInvalidValue;
+    }
+  }
   PSF_TGS_SWITCH(launch_dv_win, (pk.rows, L, a))
 }
 #undef PSF_TGS_SWITCH
@@ -226,7 +238,7 @@ bool pick_dw_chunk(const void* dW, int64_t B, int64_t N, int32_t L, int64_t C, c
   for (int t = TR; t > 1; t >>= 1) ++KN;
   if (KN > L) KN = L;
   for (int k = 0; k < KN; ++k)
-    if (offs.v[k] != (k == 0 ? 0 : 1 << (k - 1))) return false;  // near offsets are compile-time in this kernel
+    if (offs.v[k] != chord_off(k)) return false;  // near offsets are compile-time constants in this kernel
   if (N * C >= ((int64_t)1 << 31)) return false;                 // 32-bit element offsets inside a batch element
   pick->tgs = tgs;
   pick->rows = 1;
@@ -257,7 +269,7 @@ hipError_t launch_dw(const WinPick& pk, int L, const BwdWinArgs& a) {
 // `chunk_channels`: the kernel may split a row's channels over several workgroups (forward, dV) — then wide rows
 // (C >= 64) use the wide-row configuration: 32-channel chunks, 1024 threads, 256-row tiles.
 bool pick_window(const void* W, int64_t B, int64_t N, int32_t L, int64_t C, const Offsets& offs, bool vec_ok,
-                 WinPick* pick, int rows_pref, bool chunk_channels) {
+                 WinPick* pick, int rows_pref, bool chunk_channels, int nt_pref = 0) {
   if (!vec_ok || L < kWinLmin || L > kWinLmax) return false;
   const int64_t CG = C / 4;
   int tgs = ceil_log2(CG) > kWinTgsMax ? kWinTgsMax : ceil_log2(CG);
@@ -270,6 +282,9 @@ bool pick_window(const void* W, int64_t B, int64_t N, int32_t L, int64_t C, cons
     nt = kWideThreads;
   } else if (chunk_channels && wide == 2 && CG >= 16) {
     tgs = kWideTgs;  // 32-channel chunks on 256-thread workgroups
+  } else if (nt_pref == kDvMidThreads && tgs <= kDvMidTgsMax && N >= 2 * (int64_t)win_tile_rows(tgs, 1, kDvMidThreads)) {
+    nt = kDvMidThreads;  // dV: 512 threads x 1 row
+    rows = 1;
   }
   const int TR = win_tile_rows(tgs, rows, nt);
   if (N < 2 * (int64_t)TR) return false;  // the window may wrap at most once
@@ -277,7 +292,7 @@ bool pick_window(const void* W, int64_t B, int64_t N, int32_t L, int64_t C, cons
   for (int t = TR; t > 1; t >>= 1) ++KN;
   if (KN > L) KN = L;
   for (int k = 0; k < KN; ++k)
-    if (offs.v[k] > TR) return false;  // near links must fall inside the window
+    if (offs.v[k] != chord_off(k)) return false;  // near offsets are compile-time constants in the window kernels
   pick->tgs = tgs;
   pick->rows = rows;
   pick->nt = nt;
@@ -432,8 +447,11 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
         if (rc) return rc;
         dW = nullptr;
       }
+      // 512 threads x 1 row per thread instead of 256 x 2 (the same tile at C <= 8; r02 lab 28.65 vs 29.05 us at cfg2)
+      const int dvt = g_dv_threads.load();
+      const int nt_dv = (dvt == 2 || (dvt == 0 && !knob && C <= 8)) ? kDvMidThreads : 0;
       if (dV && pick_window(W, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(dV, 16), &pk,
-                            rows_dv, true)) {
+                            rows_dv, true, nt_dv)) {
         BwdWinArgs a{dZ, W, dV, Geom{}, offs, w_total, false, s};
         int rc = window_launches(pk, pk.all_edge, B, N, L, C, N * C, true, &a.gm, &a.edge,
                                  [&] { return launch_dv(pk, L, a); }, "chord_dv_win");

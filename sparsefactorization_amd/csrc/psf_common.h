@@ -96,6 +96,12 @@ __device__ __forceinline__ void axpy_rn(Vec<T, VEC>& acc, T w, const Vec<T, VEC>
   for (int i = 0; i < VEC; ++i) acc.e[i] = add_rn(acc.e[i], mul_rn(w, x.e[i]));
 }
 
+// The chord pattern's link offsets (get_chord_indices_assym, SyntheticExperiments/psf.py:7-32): 0, 1, 2, 4, ...
+// The LDS-window kernels serve the NEAR links (offset <= tile length < N, so never wrapped) with these as compile-time
+// constants — every window read is then a per-row base address plus an immediate; the host routes any other near
+// offsets to the generic kernels. Far offsets stay runtime values (they wrap mod N).
+constexpr int chord_off(int k) { return k == 0 ? 0 : 1 << (k - 1); }
+
 constexpr int ilog2_floor(int x) { return x <= 1 ? 0 : 1 + ilog2_floor(x >> 1); }
 constexpr int imin(int a, int b) { return a < b ? a : b; }
 constexpr int imax(int a, int b) { return a > b ? a : b; }
