@@ -30,16 +30,38 @@
 // through LDS and flushed to the workgroup's slot of the partial buffer.
 //
 // Limits: E <= 32 (multiple of 4), h <= 128, O <= 32, K <= 32; anything else stays on autograd.
+//
+// Two kernels share that structure (knob mlp_bwd_variant: 0 = auto -> the second, 1 = the first):
+//   mlp_bwd_k      all five GEMMs on v_mfma_f32_32x32x2_f32. That instruction occupies the vector ALU's datapath
+//                  (profiles/r01_mfmalab.log: MFMA cycles and VALU cycles add), so a tile-unit costs 72 x 64 MFMA
+//                  cycles PLUS ~2400 VALU cycles: 1.16 ms at Order N=16384, B=40 = 0.49 of the f32-MFMA peak.
+//   mlp_bwd_x3_k   all five GEMMs on v_mfma_f32_32x32x16_bf16 with the exact three-way bf16 split of mlp_x3_common.h
+//                  (6 products per k-step of 16: 54 MFMAs of 32 cycles on the separate matrix pipe instead of 72 of 64
+//                  on the shared one). Weights are split once per call by the pack kernel, X's step-1 operand once per
+//                  tile; per tile-unit the kernel splits dY (twice: by token for step 2, by output for step 4), G (twice:
+//                  registers for step 6, transposed through LDS for step 5), Hpost^T and X^T — 4.5 VALU per value on
+//                  packed subtractions. 512-thread workgroups (8 waves share the 20 KB split image; the f32 image is
+//                  8.6 KB) keep two waves per SIMD within 160 KB of LDS.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/psf_chord.h"
+#include "mlp_x3_common.h"
 
 extern "C" int psf_internal_fail(int code, const char* message);
+extern std::atomic<int> psf_g_mlp_bwd_variant;  // psf_chord.hip: tuning knob "mlp_bwd_variant"
 
 namespace {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
+using psf_x3::bf16x8;
+using psf_x3::cd_row;
+using psf_x3::f32x16;
+using psf_x3::Frag3;
+using psf_x3::mfma6;
+using psf_x3::split_pack8;
+using psf_x3::split_pack8_pk;
 
 constexpr int kMaxMlps = 32;
 constexpr int kMaxUnits = 128;
@@ -48,6 +70,23 @@ constexpr int kOffSa = 32 * 33;
 constexpr int kOffSb = kOffSa + 32;
 constexpr int kPart = 1024 + 1024 + 64 + 64;  // per (group, unit): dA [j][e] | dB^T [j][o] | da [half][j] | db [half][o]
 constexpr int kSlices = 64;                   // stage-1 reduction slices
+
+// split-bf16 unit image (bytes), every part already in MFMA operand order:
+//   A terms   3 x [32 j][80 B: 32 e bf16 + pad]            step 1, A operand (8 consecutive e of row j per ds_read_b128)
+//   sa        32 f32
+//   A^T terms 3 x [2 s][2 half][32 e][8 bf16]               step 6, A operand: A[ht + rho(s, half, i)][e]
+//   B^T terms 3 x [2 s][2 half][32 j][8 bf16]               step 2, A operand: B[o = 16 s + 8 half + i][ht + j]
+// rho(s, half, i) = (i & 3) + 16 s + 8 (i >> 2) + 4 half: the hidden row that accumulator register 8 s + i of a lane of
+// that half holds, so a lane's registers 8s..8s+7 ARE its B-operand fragment of k-step s (accumulator-as-operand).
+constexpr int kXARow = 80;
+constexpr int kXATerm = 32 * kXARow;                // 2560
+constexpr int kXOffSa = 3 * kXATerm;                // 7680
+constexpr int kXOffAT = kXOffSa + 128;              // 7808
+constexpr int kXFragTerm = 2 * 2 * 32 * 16;         // 2048
+constexpr int kXOffBT = kXOffAT + 3 * kXFragTerm;   // 13952
+constexpr int kXImgBytes = kXOffBT + 3 * kXFragTerm;  // 20096
+constexpr int kXImgVecs = kXImgBytes / 16;          // 1256
+constexpr int kImgFloatsMax = kXImgBytes / 4 > kImg ? kXImgBytes / 4 : kImg;  // workspace slot per unit, either variant
 
 struct BwdMlp {
   const float* A;   // [h, E]
@@ -73,8 +112,6 @@ struct BwdArgs {
   int64_t G;        // workgroups = partial slots
   int32_t E, K, U;
 };
-
-__device__ __forceinline__ int cd_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
 // y = GELU(x) = x Phi(x) and dy/dx = Phi(x) + x phi(x) for a PAIR of values on packed f32 math (v_pk_fma_f32 /
 // v_pk_mul_f32: two elements per instruction; here VALU cycles add to the f32-MFMA cycles). Phi by Abramowitz &
@@ -393,6 +430,339 @@ mlp_bwd_k(const BwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// split-bf16 variant
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mlp_bwd_x3_pack_k(const BwdArgs a) {
+  using psf_x3::bf16_bits;
+  using psf_x3::split3;
+  const int u = blockIdx.x;
+  const BwdMlp d = a.m[a.unit_k[u]];
+  const int ht = 32 * a.unit_hb[u], E = a.E;
+  unsigned char* img = reinterpret_cast<unsigned char*>(a.images) + (size_t)u * kXImgBytes;
+  uint16_t* img16 = reinterpret_cast<uint16_t*>(img);
+  float* img32 = reinterpret_cast<float*>(img);
+  for (int i = threadIdx.x; i < 32 * 40; i += 256) {  // A terms [j][e] (the pad columns are written as zeros)
+    const int j = i / 40, e = i - j * 40;
+    const float v = (e < E && ht + j < d.h) ? d.A[(ht + j) * E + e] : 0.f;
+    uint32_t t1, t2, t3;
+    split3(v, t1, t2, t3);
+    img16[(0 * kXATerm + j * kXARow) / 2 + e] = bf16_bits(t1);
+    img16[(1 * kXATerm + j * kXARow) / 2 + e] = bf16_bits(t2);
+    img16[(2 * kXATerm + j * kXARow) / 2 + e] = bf16_bits(t3);
+  }
+  for (int j = threadIdx.x; j < 32; j += 256) img32[kXOffSa / 4 + j] = ht + j < d.h ? d.a[ht + j] : 0.f;
+  for (int q = threadIdx.x; q < 2 * 2 * 32 * 8; q += 256) {
+    const int i = q & 7, col = (q >> 3) & 31, hf = (q >> 8) & 1, s = q >> 9;
+    uint32_t t1, t2, t3;
+    // A^T: [s][half][e = col][i] = A[ht + rho][e]
+    const int rho = (i & 3) + 16 * s + 8 * (i >> 2) + 4 * hf;
+    const float va = (col < E && ht + rho < d.h) ? d.A[(ht + rho) * E + col] : 0.f;
+    split3(va, t1, t2, t3);
+    img16[(kXOffAT + 0 * kXFragTerm) / 2 + q] = bf16_bits(t1);
+    img16[(kXOffAT + 1 * kXFragTerm) / 2 + q] = bf16_bits(t2);
+    img16[(kXOffAT + 2 * kXFragTerm) / 2 + q] = bf16_bits(t3);
+    // B^T: [s][half][j = col][i] = B[o = 16 s + 8 half + i][ht + j]
+    const int o = 16 * s + 8 * hf + i;
+    const float vb = (o < d.O && ht + col < d.h) ? d.B[o * d.h + ht + col] : 0.f;
+    split3(vb, t1, t2, t3);
+    img16[(kXOffBT + 0 * kXFragTerm) / 2 + q] = bf16_bits(t1);
+    img16[(kXOffBT + 1 * kXFragTerm) / 2 + q] = bf16_bits(t2);
+    img16[(kXOffBT + 2 * kXFragTerm) / 2 + q] = bf16_bits(t3);
+  }
+}
+
+__device__ __forceinline__ Frag3 load_frag3(const unsigned char* p, int term_stride) {
+  Frag3 f;
+  f.t1 = *reinterpret_cast<const bf16x8*>(p);
+  f.t2 = *reinterpret_cast<const bf16x8*>(p + term_stride);
+  f.t3 = *reinterpret_cast<const bf16x8*>(p + 2 * term_stride);
+  return f;
+}
+
+// 512 threads: eight waves share one unit image. launch_bounds(512, 1): one workgroup (two waves per SIMD) per CU,
+// <= 256 registers per lane.
+// FULL: steps 4 and 5 (the contractions over tokens) on the bf16 pipe as well; otherwise they stay on the f32 instruction.
+template <int TPW, int NDY, bool FULL>
+__global__ void __launch_bounds__(512, 1)
+mlp_bwd_x3_k(const BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int NW = 8;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int c = lane & 31, half = lane >> 5;
+  constexpr int SD = NDY == 8 ? 17 : 33;      // odd strides: conflict-free by row and by column
+  constexpr int kImgBufs = NDY == 8 ? 2 : 1;  // O > 16: wider dY tiles, one image buffer (LDS)
+  constexpr int NS2 = NDY == 8 ? 1 : 2;       // k-steps of step 2 (16 outputs each)
+  constexpr int kWaveLds = TPW * 32 * 33 + 32 * SD + 32 * 33;
+  float* lds_f = reinterpret_cast<float*>(lds_raw + kImgBufs * kXImgBytes);
+  float* SX = lds_f + wv * kWaveLds;  // the wave's X tiles [tok][33] (B operand of step 5)
+  float* S1 = SX + TPW * 32 * 33;     // dY tile [tok][SD]
+  float* S2 = S1 + 32 * SD;           // re-layout of Hpost^T / G; dX^T at the end
+  const int E = a.E, U = a.U;
+  const int64_t tiles = (a.T + 31) / 32;
+  const int64_t tiles_per_block = NW * TPW;
+  const unsigned char* images = reinterpret_cast<const unsigned char*>(a.images);
+
+  auto stage = [&](int u) {
+    const unsigned char* src = images + (size_t)u * kXImgBytes;
+    unsigned char* dst = lds_raw + (kImgBufs == 2 ? (u & 1) : 0) * kXImgBytes;
+    for (int v0 = 0; v0 < kXImgVecs; v0 += 64 * NW) {
+      const int v = v0 + tid;
+      if (v < kXImgVecs)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * v),
+                                         (__attribute__((address_space(3))) void*)(dst + 16 * (v0 + (tid & ~63))), 16, 0, 0);
+    }
+  };
+
+  for (int64_t blk = blockIdx.x; blk * tiles_per_block < tiles; blk += gridDim.x) {
+    Frag3 xf[TPW][2];  // X fragments: k-step s covers e = 16 s + 8 half + (0..7) of the lane's token (B operand, step 1)
+    f32x16 dxa[TPW];
+    int64_t t0[TPW];
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+      t0[tp] = (blk * tiles_per_block + wv * TPW + tp) * 32;
+      float* sx = SX + tp * 32 * 33;
+      tile_to_scratch<true>(a.X, a.T, E, t0[tp], sx, lane);
+      if (E < 32)
+        for (int i = lane; i < 32 * 32; i += 64)
+          if ((i & 31) >= E) sx[(i >> 5) * 33 + (i & 31)] = 0.f;  // columns >= E read as zero
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = sx[c * 33 + 16 * s + 8 * half + i];
+        xf[tp][s] = split_pack8(v);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dxa[tp][r] = 0.f;
+    }
+    float* part = a.partials + (blk * (int64_t)U) * kPart;  // one partial slot per workgroup
+    float dyn[NDY];
+    auto dy_fetch = [&](int u2, int64_t t02) {
+      const BwdMlp& d2 = a.m[a.unit_k[u2]];
+      const int W = d2.O;
+      const int64_t rows_left = a.T - t02;
+      const int n = (int)(rows_left >= 32 ? 32 : (rows_left > 0 ? rows_left : 0)) * W;
+      const float* src = d2.dY + t02 * W;
+#pragma unroll
+      for (int i = 0; i < NDY; ++i) {
+        const int f = lane + 64 * i;
+        dyn[i] = f < n ? src[f] : 0.f;
+      }
+    };
+    auto dy_commit = [&](int W) {  // registers -> S1[tok][SD]
+      const int q64 = 64 / W, r64 = 64 - q64 * W;
+      int tok = lane / W, col = lane - tok * W;
+#pragma unroll
+      for (int i = 0; i < NDY; ++i) {
+        if (lane + 64 * i < 32 * W) S1[tok * SD + col] = dyn[i];
+        tok += q64;
+        col += r64;
+        if (col >= W) {
+          col -= W;
+          ++tok;
+        }
+      }
+    };
+    dy_fetch(0, t0[0]);
+    if (kImgBufs == 2) {
+      __syncthreads();  // the previous block's last unit is done with both image buffers
+      stage(0);
+    }
+
+    for (int u = 0; u < U; ++u) {
+      __syncthreads();  // image u has landed (hipcc drains vmcnt before the barrier); unit u-1 is finished
+      if (kImgBufs == 2) {
+        if (u + 1 < U) stage(u + 1);
+      } else {
+        stage(u);
+        __syncthreads();
+      }
+      const unsigned char* img = lds_raw + (kImgBufs == 2 ? (u & 1) : 0) * kXImgBytes;
+      const float* sa = reinterpret_cast<const float*>(img + kXOffSa);
+      const BwdMlp& d = a.m[a.unit_k[u]];
+      const int O = d.O;
+
+      f32x16 dA, dBT;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dA[r] = dBT[r] = 0.f;
+      float da = 0.f, db = 0.f;
+
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) {
+        dy_commit(O);
+        if (tp + 1 < TPW)
+          dy_fetch(u, t0[tp + 1 < TPW ? tp + 1 : 0]);
+        else if (u + 1 < U)
+          dy_fetch(u + 1, t0[0]);
+        if (t0[tp] >= a.T) continue;  // wave-uniform
+        // 1. Hpre^T = A_u X^T + a_u on the bf16 pipe
+        f32x16 acc1, acc3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc1[r] = sa[cd_row(r, half)];
+          acc3[r] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          acc1 = mfma6(load_frag3(img + c * kXARow + 32 * s + 16 * half, kXATerm), xf[tp][s], acc1);
+        // 2. dHpost^T = B_u^T dY^T: B operand = dY[tok = c][o = 16 s + 8 half + i], split here
+#pragma unroll
+        for (int s = 0; s < NS2; ++s) {
+          float dv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int o = 16 * s + 8 * half + i;
+            dv[i] = o < O ? S1[c * SD + o] : 0.f;
+          }
+          acc3 = mfma6(load_frag3(img + kXOffBT + ((s * 2 + half) * 32 + c) * 16, kXFragTerm), split_pack8_pk(dv), acc3);
+        }
+        // 3. GELU and its derivative; Hpost^T -> S2[j][tok]
+        float g[16];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          f32x2 y, dy;
+          gelu_and_grad2(f32x2{acc1[r], acc1[r + 1]}, y, dy);
+          S2[cd_row(r, half) * 33 + c] = y.x;
+          S2[cd_row(r + 1, half) * 33 + c] = y.y;
+          g[r] = acc3[r] * dy.x;  // G = dHpre^T
+          g[r + 1] = acc3[r + 1] * dy.y;
+        }
+        if constexpr (FULL) {
+          // 4. dB^T[j][o] += Hpost^T[j][tok] · dY[tok][o]: contraction over the tile's 32 tokens, on the bf16 pipe.
+          //    A operand = 8 consecutive tokens of hidden row j = c from S2 [j][tok]; B operand = the same tokens of output
+          //    column o = c from the dY tile; both split here. All 32 LDS reads of the step are issued together (the f32
+          //    form read two operands per MFMA and waited for them: one exposed LDS round trip per instruction).
+          {
+            float dbs = 0.f;
+  #pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              float hv[8], yv[8];
+  #pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const int tok = 16 * s + 8 * half + i;
+                hv[i] = S2[c * 33 + tok];
+                yv[i] = c < O ? S1[tok * SD + c] : 0.f;
+                dbs += yv[i];
+              }
+              dBT = mfma6(split_pack8_pk(hv), split_pack8_pk(yv), dBT);
+            }
+            db += dbs;
+          }
+          // 5. dA[j][e] += G[j][tok] · X[tok][e]   (G re-laid through S2; X^T fragments split from the wave's X tile)
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 33 + c] = g[r];
+          {
+            float das = 0.f;
+  #pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              float gv[8], xv[8];
+  #pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const int tok = 16 * s + 8 * half + i;
+                gv[i] = S2[c * 33 + tok];
+                xv[i] = SX[tp * 32 * 33 + tok * 33 + c];
+                das += gv[i];
+              }
+              dA = mfma6(split_pack8_pk(gv), split_pack8_pk(xv), dA);
+            }
+            da += das;
+          }
+        } else {
+          // 4. dB^T += Hpost^T[j = c][tok = 2kk+half] · dY[tok = 2kk+half][o = c] on the f32 instruction. (Reading the
+          //    operands of four MFMAs ahead of them was tried: at two tiles per wave the 16 extra live registers go to
+          //    scratch, 1.05 -> 1.52 ms.)
+          {
+            float dbs = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+              const int q = 2 * kk + half;
+              const float dyt = c < O ? S1[q * SD + c] : 0.f;
+              dbs += dyt;
+              dBT = __builtin_amdgcn_mfma_f32_32x32x2f32(S2[c * 33 + q], dyt, dBT, 0, 0, 0);
+            }
+            db += dbs;
+          }
+          // 5. dA += G[j = c][tok = 2kk+half] · X[tok = 2kk+half][e = c]   (G re-laid through S2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 33 + c] = g[r];
+          {
+            float das = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+              const float gt = S2[c * 33 + 2 * kk + half];
+              das += gt;
+              dA = __builtin_amdgcn_mfma_f32_32x32x2f32(gt, SX[tp * 32 * 33 + (2 * kk + half) * 33 + c], dA, 0, 0, 0);
+            }
+            da += das;
+          }
+        }
+        // 6. dX^T += A_u^T · G on the bf16 pipe: the lane's registers g[8s..8s+7] are its B fragment of k-step s
+        if (a.dX) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            float gv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gv[i] = g[8 * s + i];
+            dxa[tp] = mfma6(load_frag3(img + kXOffAT + ((s * 2 + half) * 32 + c) * 16, kXFragTerm), split_pack8_pk(gv), dxa[tp]);
+          }
+        }
+      }
+      // Combine the eight waves' partial sums through LDS (fixed order w = 0..7) and flush once per workgroup.
+      float* pu = part + (int64_t)u * kPart;
+      const float* wave0 = lds_f + TPW * 32 * 33;  // wave 0's S1; wave w's is + w * kWaveLds
+      auto sum8 = [&](int off) {  // off: float offset from a wave's S1, 16-byte aligned
+        float4 acc = *reinterpret_cast<const float4*>(wave0 + off);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+          const float4 v = *reinterpret_cast<const float4*>(wave0 + w * kWaveLds + off);
+          acc.x += v.x;
+          acc.y += v.y;
+          acc.z += v.z;
+          acc.w += v.w;
+        }
+        return acc;
+      };
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 32 + c] = dA[r];
+      S1[lane] = da;
+      S1[64 + lane] = db;
+      __syncthreads();
+      if (wv < 4) *reinterpret_cast<float4*>(pu + wv * 256 + 4 * lane) = sum8(32 * SD + wv * 256 + 4 * lane);
+      if (wv == 4 && lane < 32) *reinterpret_cast<float4*>(pu + 2048 + 4 * lane) = sum8(4 * lane);  // da [2][32] | db [2][32]
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 32 + c] = dBT[r];
+      __syncthreads();
+      if (wv < 4) *reinterpret_cast<float4*>(pu + 1024 + wv * 256 + 4 * lane) = sum8(32 * SD + wv * 256 + 4 * lane);
+    }
+    __syncthreads();  // all combine reads of S2 are done before the dX epilogue reuses it
+
+    if (a.dX) {
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) {
+        if (t0[tp] >= a.T) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S2[c * 33 + cd_row(r, half)] = dxa[tp][r];
+        const int64_t rem = a.T - t0[tp];
+        const int n_el = (int)(rem < 32 ? rem : 32) * E;
+        float* xt = a.dX + t0[tp] * E;
+        const int q64 = 64 / E, r64 = 64 - q64 * E;
+        int tok = lane / E, e = lane - tok * E;
+        for (int f = lane; f < n_el; f += 64) {
+          xt[f] = S2[tok * 33 + e];
+          tok += q64;
+          e += r64;
+          if (e >= E) {
+            e -= E;
+            ++tok;
+          }
+        }
+      }
+    }
+  }
+}
+
 // stage 1: R1[s][i] = sum over the groups of slice s of P[g][i]   (i < U*kPart; fixed order)
 __global__ void __launch_bounds__(256) mlp_bwd_reduce1_k(const BwdArgs a) {
   const int64_t n = (int64_t)a.U * kPart;
@@ -437,7 +807,8 @@ __global__ void __launch_bounds__(256) mlp_bwd_reduce2_k(const BwdArgs a) {
 struct Plan {
   int U;
   int tpw;  // tiles per wave: 2, or 1 for short inputs (keeps >= 2 workgroups per CU in flight)
-  int64_t G;
+  int tpw8;
+  int64_t G, G8;
   uint8_t unit_k[kMaxUnits], unit_hb[kMaxUnits];
 };
 
@@ -454,12 +825,17 @@ bool make_plan(int64_t T, int32_t E, int32_t K, const int32_t* h, const int32_t*
   }
   const int64_t tiles = (T + 31) / 32;
   p->tpw = (tiles + 7) / 8 >= 512 ? 2 : 1;
-  p->G = (tiles + 4 * p->tpw - 1) / (4 * p->tpw);  // one workgroup (= one partial slot) per 4*TPW tiles
+  // one workgroup (= one partial slot) per waves*TPW tiles: 4 waves (f32 kernel) or 8 (split-bf16 kernel)
+  p->G = (tiles + 4 * p->tpw - 1) / (4 * p->tpw);
+  p->tpw8 = p->tpw;
+  p->G8 = (tiles + 8 * p->tpw8 - 1) / (8 * p->tpw8);
   return true;
 }
 
+// sized for either kernel variant (the knob may change between the workspace query and the call)
 int64_t workspace_floats(const Plan& p) {
-  return (int64_t)p.U * kImg + p.G * p.U * kPart + (int64_t)kSlices * p.U * kPart;
+  const int64_t slots = p.G > p.G8 ? p.G : p.G8;
+  return (int64_t)p.U * kImgFloatsMax + slots * p.U * kPart + (int64_t)kSlices * p.U * kPart;
 }
 
 }  // namespace
@@ -495,38 +871,51 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
     args.unit_k[u] = u < p.U ? p.unit_k[u] : 0;
     args.unit_hb[u] = u < p.U ? p.unit_hb[u] : 0;
   }
+  const bool x3 = psf_g_mlp_bwd_variant.load() != 1;  // split-bf16 kernel (512 threads) unless the f32 one is forced
   float* ws = reinterpret_cast<float*>(workspace);
   args.X = X;
   args.dX = dX;
   args.images = ws;
-  args.partials = ws + (int64_t)p.U * kImg;
-  args.stage1 = args.partials + p.G * p.U * kPart;
+  args.partials = ws + (int64_t)p.U * kImgFloatsMax;
+  args.stage1 = args.partials + (p.G > p.G8 ? p.G : p.G8) * p.U * kPart;
   args.T = T;
-  args.G = p.G;
+  args.G = x3 ? p.G8 : p.G;
   args.E = E;
   args.K = K;
   args.U = p.U;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(mlp_bwd_pack_k, dim3(p.U), dim3(256), 0, s, args);
+  if (x3) hipLaunchKernelGGL(mlp_bwd_x3_pack_k, dim3(p.U), dim3(256), 0, s, args);
+  else hipLaunchKernelGGL(mlp_bwd_pack_k, dim3(p.U), dim3(256), 0, s, args);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
 
-  // every slot of the partial buffer is written exactly once: one workgroup per 4*TPW tiles
-  const int64_t blocks = p.G;
+  // every slot of the partial buffer is written exactly once: one workgroup per waves*TPW tiles
+  const int64_t blocks = args.G;
   if (blocks > 0x7fffffff) return psf_internal_fail(PSF_E_SHAPE, "psf_mlp_bwd: T too large");
   int max_o = 1;
   for (int k = 0; k < K; ++k) max_o = O[k] > max_o ? O[k] : max_o;
-  auto launch = [&](auto kernel, int tpw, int sd, int img_bufs) {
-    const size_t lds_bytes = sizeof(float) * ((size_t)img_bufs * kImg + 4 * (tpw * 32 * 33 + 32 * sd + 32 * 33));
+  auto launch = [&](auto kernel, int waves, size_t img_bytes, int tpw, int sd, int img_bufs) {
+    const size_t lds_bytes = (size_t)img_bufs * img_bytes + sizeof(float) * (size_t)waves * (tpw * 32 * 33 + 32 * sd + 32 * 33);
     e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, s, args);
+    if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * waves), lds_bytes, s, args);
   };
-  if (max_o <= 16) {
-    if (p.tpw == 2) launch(mlp_bwd_k<2, 8>, 2, 17, 2);
-    else launch(mlp_bwd_k<1, 8>, 1, 17, 2);
+  if (x3) {
+    const bool full = psf_g_mlp_bwd_variant.load() == 2 || (psf_g_mlp_bwd_variant.load() == 0 && p.tpw8 == 1);
+    if (max_o <= 16) {
+      if (p.tpw8 == 2) launch(mlp_bwd_x3_k<2, 8, false>, 8, kXImgBytes, 2, 17, 2);
+      else if (full) launch(mlp_bwd_x3_k<1, 8, true>, 8, kXImgBytes, 1, 17, 2);
+      else launch(mlp_bwd_x3_k<1, 8, false>, 8, kXImgBytes, 1, 17, 2);
+    } else {
+      if (p.tpw8 == 2) launch(mlp_bwd_x3_k<2, 16, false>, 8, kXImgBytes, 2, 33, 1);
+      else if (full) launch(mlp_bwd_x3_k<1, 16, true>, 8, kXImgBytes, 1, 33, 1);
+      else launch(mlp_bwd_x3_k<1, 16, false>, 8, kXImgBytes, 1, 33, 1);
+    }
+  } else if (max_o <= 16) {
+    if (p.tpw == 2) launch(mlp_bwd_k<2, 8>, 4, kImg * sizeof(float), 2, 17, 2);
+    else launch(mlp_bwd_k<1, 8>, 4, kImg * sizeof(float), 1, 17, 2);
   } else {
-    if (p.tpw == 2) launch(mlp_bwd_k<2, 16>, 2, 33, 1);
-    else launch(mlp_bwd_k<1, 16>, 1, 33, 1);
+    if (p.tpw == 2) launch(mlp_bwd_k<2, 16>, 4, kImg * sizeof(float), 2, 33, 1);
+    else launch(mlp_bwd_k<1, 16>, 4, kImg * sizeof(float), 1, 33, 1);
   }
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
   const int64_t n = (int64_t)p.U * kPart;

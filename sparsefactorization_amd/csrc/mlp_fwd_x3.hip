@@ -28,11 +28,11 @@
 
 #include "../../include/psf_chord.h"
 #include "mlp_fwd_x3.h"
+#include "mlp_x3_common.h"
 
 namespace {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using namespace psf_x3;
 
 // unit image (bytes): A terms 3 x [32 j][80 B: 32 bf16 + pad] | sa 32 f32 | B' terms 3 x [2 s][2 half][32 o][8 bf16]
 // | sb 32 f32
@@ -64,52 +64,6 @@ struct X3Args {
   int32_t E, U;
 };
 
-__device__ __forceinline__ int cd_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
-
-// exact three-way truncation split; the results are f32 bit patterns whose low 16 bits are zero
-__device__ __forceinline__ void split3(float v, uint32_t& t1, uint32_t& t2, uint32_t& t3) {
-  t1 = __float_as_uint(v) & 0xffff0000u;
-  const float r1 = v - __uint_as_float(t1);
-  t2 = __float_as_uint(r1) & 0xffff0000u;
-  t3 = __float_as_uint(r1 - __uint_as_float(t2));
-}
-
-// eight f32 bit patterns (low halves zero) -> their bf16 high halves, element i in bits [16 (i&1), +16) of dword i/2
-__device__ __forceinline__ bf16x8 pack8(const uint32_t (&w)[8]) {
-  uint4 d;
-  d.x = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
-  d.y = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
-  d.z = __builtin_amdgcn_perm(w[5], w[4], 0x07060302u);
-  d.w = __builtin_amdgcn_perm(w[7], w[6], 0x07060302u);
-  return __builtin_bit_cast(bf16x8, d);
-}
-
-struct Frag3 {  // the three terms of one 8-element operand fragment
-  bf16x8 t1, t2, t3;
-};
-
-__device__ __forceinline__ Frag3 split_pack8(const float (&v)[8]) {
-  uint32_t a[8], b[8], c[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) split3(v[i], a[i], b[i], c[i]);
-  Frag3 f;
-  f.t1 = pack8(a);
-  f.t2 = pack8(b);
-  f.t3 = pack8(c);
-  return f;
-}
-
-// acc += sum of the six kept terms of (weights w) x (activations x), smallest first
-__device__ __forceinline__ f32x16 mfma6(const Frag3& w, const Frag3& x, f32x16 acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.t1, x.t3, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.t2, x.t2, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.t3, x.t1, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.t1, x.t2, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.t2, x.t1, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.t1, x.t1, acc, 0, 0, 0);
-  return acc;
-}
-
 // GELU(x) = x Phi(x) for a PAIR of values, on packed f32 math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two
 // elements per instruction — the kernel is VALU-issue-bound, rocprofv3: ~70 % VALU-busy, 22 % matrix-pipe-busy).
 // Phi by Abramowitz & Stegun 26.2.17 (the normal-CDF form of 7.1.26, |error| <= 7.5e-8):
@@ -138,8 +92,6 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
   dlt.y = copysignf(dlt.y, x.y);
   return x * (half2 + dlt);  // Phi = 0.5 + sign(x) (0.5 - q)
 }
-
-__device__ __forceinline__ uint16_t bf16_bits(uint32_t f32_pattern) { return (uint16_t)(f32_pattern >> 16); }
 
 // One workgroup per unit: split the weights and write them in operand order.
 __global__ void __launch_bounds__(256) x3_pack_k(const X3Args a) {
