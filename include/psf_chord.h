@@ -155,6 +155,14 @@ int psf_linear_wgrad_strided_f32(const float* X, int64_t ldx, const float* dY, i
                                  float* dWt, float* db, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * out[i] = ((srcs[0][i] + srcs[1][i]) + srcs[2][i]) + ...   i < n, in that order (separately rounded additions).
+ * The gradient of the chain's residual: dV_0 = dX_0 + sum over the steps of dX_m (V = V + res_conn,
+ * SyntheticExperiments/psf.py:187-188, reaches V_0 from every step), summed once instead of accumulated per step.
+ *   1 <= count <= 32; n a multiple of 4; every pointer 16-byte aligned; `out` may alias none of the sources.
+ */
+int psf_sum_tensors_f32(const float* const* srcs, int32_t count, int64_t n, float* out, void* stream);
+
+/*
  * Token embedding fused with the positional-embedding add — the first two lines of PSFNet.forward
  * (SyntheticExperiments/psf.py:152-163, LRA/psf.py:203-214):
  *     out[t,:] = table[idx[t],:] (+ pos[t mod N,:])        t < T = B*N

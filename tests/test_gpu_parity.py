@@ -596,3 +596,38 @@ def test_errors(gpu):
         sfa.spmm(bad, W.reshape(2, 64), 16, 16, V)
     with pytest.raises(ValueError):
         sfa.spmm(idx, W.reshape(2, 64), 16, 8, V)
+
+
+@pytest.mark.parametrize("count", [1, 2, 7, 8, 9, 15, 16, 23, 32])
+def test_sum_tensors_is_the_left_to_right_sum(gpu, count):
+    """psf_sum_tensors_f32 (csrc/sum_tensors.hip): ((t0 + t1) + t2) + ... bit for bit, for every pass structure
+    (8 sources in the first pass, 7 per later pass) — the residual gradient of the chain is summed with it."""
+    from sparsefactorization_amd.chord import _sum_tensors
+    g = torch.Generator(device=gpu).manual_seed(count)
+    terms = [torch.randn(3, 1001, 8, device=gpu, generator=g) * (10.0 ** (i % 5 - 2)) for i in range(count)]
+    want = terms[0].clone()
+    for t in terms[1:]:
+        want = want + t
+    got = _sum_tensors(terms)
+    assert torch.equal(got, want)
+    assert all(torch.equal(t, u) for t, u in zip(terms, [x.clone() for x in terms]))  # sources untouched
+
+
+def test_chain_backward_residual_gradient_one_pass_sum(gpu):
+    """dV0 of a residual chain (summed once at the end) equals the step-by-step autograd through chord_spmm bit for bit."""
+    import sparsefactorization_amd as sfa
+    B, N, M, C = 2, 3000, 11, 8
+    Ws = [_t(_mk((B, N, M + 1), 80 + m, 0.3), gpu).requires_grad_(True) for m in range(M)]
+    V0a = _t(_mk((B, N, C), 99), gpu).requires_grad_(True)
+    V0b = V0a.detach().clone().requires_grad_(True)
+    dZ = _t(_mk((B, N, C), 98), gpu)
+    sfa.chord_chain(Ws, V0a, True).backward(dZ)
+    gW = [w.grad.clone() for w in Ws]
+    for w in Ws:
+        w.grad = None
+    V = V0b
+    for w in Ws:
+        V = sfa.chord_spmm(w, V, V0b)
+    V.backward(dZ)
+    assert all(torch.equal(a, w.grad) for a, w in zip(gW, Ws))
+    assert rel_inf(V0a.grad.cpu().numpy(), V0b.grad.cpu().numpy()) <= 1e-6  # autograd adds the M+1 terms in its own order
