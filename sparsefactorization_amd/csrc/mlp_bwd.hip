@@ -483,15 +483,16 @@ __device__ __forceinline__ Frag3 load_frag3(const unsigned char* p, int term_str
 // 512 threads: eight waves share one unit image. launch_bounds(512, 1): one workgroup (two waves per SIMD) per CU,
 // <= 256 registers per lane.
 // FULL: steps 4 and 5 (the contractions over tokens) on the bf16 pipe as well; otherwise they stay on the f32 instruction.
-template <int TPW, int NDY, bool FULL>
-__global__ void __launch_bounds__(512, 1)
+// NW: waves per workgroup. 8 = one workgroup per CU, two image buffers; 4 = two workgroups per CU (their phases drift
+// apart, unlike the two waves of one workgroup that meet at every barrier) with ONE image buffer each.
+template <int TPW, int NDY, bool FULL, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2)
 mlp_bwd_x3_k(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  constexpr int NW = 8;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int c = lane & 31, half = lane >> 5;
   constexpr int SD = NDY == 8 ? 17 : 33;      // odd strides: conflict-free by row and by column
-  constexpr int kImgBufs = NDY == 8 ? 2 : 1;  // O > 16: wider dY tiles, one image buffer (LDS)
+  constexpr int kImgBufs = (NDY == 8 && NW == 8) ? 2 : 1;  // O > 16 (wider dY tiles) or 4 waves: one image buffer (LDS)
   constexpr int NS2 = NDY == 8 ? 1 : 2;       // k-steps of step 2 (16 outputs each)
   constexpr int kWaveLds = TPW * 32 * 33 + 32 * SD + 32 * 33;
   float* lds_f = reinterpret_cast<float*>(lds_raw + kImgBufs * kXImgBytes);
@@ -595,7 +596,9 @@ mlp_bwd_x3_k(const BwdArgs a) {
           dy_fetch(u, t0[tp + 1 < TPW ? tp + 1 : 0]);
         else if (u + 1 < U)
           dy_fetch(u + 1, t0[0]);
-        if (t0[tp] >= a.T) continue;  // wave-uniform
+        // wave-uniform. (Computing past-the-end tiles on zeros instead, so that the wave's two tiles form ONE basic block
+        // the scheduler can interleave, was tried: hipcc then overlaps both tiles' live ranges and spills, 1.05 -> 1.51 ms.)
+        if (t0[tp] >= a.T) continue;
         // 1. Hpre^T = A_u X^T + a_u on the bf16 pipe
         f32x16 acc1, acc3;
 #pragma unroll
@@ -729,7 +732,7 @@ mlp_bwd_x3_k(const BwdArgs a) {
       S1[64 + lane] = db;
       __syncthreads();
       if (wv < 4) *reinterpret_cast<float4*>(pu + wv * 256 + 4 * lane) = sum8(32 * SD + wv * 256 + 4 * lane);
-      if (wv == 4 && lane < 32) *reinterpret_cast<float4*>(pu + 2048 + 4 * lane) = sum8(4 * lane);  // da [2][32] | db [2][32]
+      if (wv == NW - 4 && lane < 32) *reinterpret_cast<float4*>(pu + 2048 + 4 * lane) = sum8(4 * lane);  // da [2][32] | db [2][32]
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 32 + c] = dBT[r];
@@ -871,7 +874,8 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
     args.unit_k[u] = u < p.U ? p.unit_k[u] : 0;
     args.unit_hb[u] = u < p.U ? p.unit_hb[u] : 0;
   }
-  const bool x3 = psf_g_mlp_bwd_variant.load() != 1;  // split-bf16 kernel (512 threads) unless the f32 one is forced
+  const bool x3 = psf_g_mlp_bwd_variant.load() != 1;  // split-bf16 kernel unless the f32 one is forced
+  const bool four_waves = psf_g_mlp_bwd_variant.load() == 4;  // split-bf16 kernel on 256-thread workgroups, two per CU
   float* ws = reinterpret_cast<float*>(workspace);
   args.X = X;
   args.dX = dX;
@@ -879,7 +883,7 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   args.partials = ws + (int64_t)p.U * kImgFloatsMax;
   args.stage1 = args.partials + (p.G > p.G8 ? p.G : p.G8) * p.U * kPart;
   args.T = T;
-  args.G = x3 ? p.G8 : p.G;
+  args.G = (x3 && !four_waves) ? p.G8 : p.G;
   args.E = E;
   args.K = K;
   args.U = p.U;
@@ -901,14 +905,22 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   };
   if (x3) {
     const bool full = psf_g_mlp_bwd_variant.load() == 2 || (psf_g_mlp_bwd_variant.load() == 0 && p.tpw8 == 1);
-    if (max_o <= 16) {
-      if (p.tpw8 == 2) launch(mlp_bwd_x3_k<2, 8, false>, 8, kXImgBytes, 2, 17, 2);
-      else if (full) launch(mlp_bwd_x3_k<1, 8, true>, 8, kXImgBytes, 1, 17, 2);
-      else launch(mlp_bwd_x3_k<1, 8, false>, 8, kXImgBytes, 1, 17, 2);
+    if (four_waves) {
+      if (max_o <= 16) {
+        if (p.tpw == 2) launch(mlp_bwd_x3_k<2, 8, false, 4>, 4, kXImgBytes, 2, 17, 1);
+        else launch(mlp_bwd_x3_k<1, 8, false, 4>, 4, kXImgBytes, 1, 17, 1);
+      } else {
+        if (p.tpw == 2) launch(mlp_bwd_x3_k<2, 16, false, 4>, 4, kXImgBytes, 2, 33, 1);
+        else launch(mlp_bwd_x3_k<1, 16, false, 4>, 4, kXImgBytes, 1, 33, 1);
+      }
+    } else if (max_o <= 16) {
+      if (p.tpw8 == 2) launch(mlp_bwd_x3_k<2, 8, false, 8>, 8, kXImgBytes, 2, 17, 2);
+      else if (full) launch(mlp_bwd_x3_k<1, 8, true, 8>, 8, kXImgBytes, 1, 17, 2);
+      else launch(mlp_bwd_x3_k<1, 8, false, 8>, 8, kXImgBytes, 1, 17, 2);
     } else {
-      if (p.tpw8 == 2) launch(mlp_bwd_x3_k<2, 16, false>, 8, kXImgBytes, 2, 33, 1);
-      else if (full) launch(mlp_bwd_x3_k<1, 16, true>, 8, kXImgBytes, 1, 33, 1);
-      else launch(mlp_bwd_x3_k<1, 16, false>, 8, kXImgBytes, 1, 33, 1);
+      if (p.tpw8 == 2) launch(mlp_bwd_x3_k<2, 16, false, 8>, 8, kXImgBytes, 2, 33, 1);
+      else if (full) launch(mlp_bwd_x3_k<1, 16, true, 8>, 8, kXImgBytes, 1, 33, 1);
+      else launch(mlp_bwd_x3_k<1, 16, false, 8>, 8, kXImgBytes, 1, 33, 1);
     }
   } else if (max_o <= 16) {
     if (p.tpw == 2) launch(mlp_bwd_k<2, 8>, 4, kImg * sizeof(float), 2, 17, 2);
