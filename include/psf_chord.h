@@ -138,6 +138,35 @@ int psf_chord_chain_fwd_f64(const double* const* W_steps, const double* V0, doub
                             const int64_t* offsets, void* stream);
 
 /*
+ * Training variants with a link-major SIDE COPY of W's far columns.
+ *
+ * dV[q] = sum_k W[q - off_k, k] * dZ[q - off_k] reads ONE column element of W per row and link. For the links the dV
+ * kernel serves from far source tiles that is a 4-byte read at a row stride of 4L bytes: every 128-byte line of the
+ * source rows is moved from L2 to the CU for 4 useful bytes — 300 of the kernel's 676 bytes of L2 traffic per row at
+ * N = 16384, L = 15, C = 8 (profiles/r02f_dvlab.log: 29.1 us with those reads, 25.0 us with them served from a
+ * link-major copy, 22.8 us with none). The forward step has each W tile in LDS anyway and can write those columns out
+ * link-major for 4(L - k0) extra bytes per row:
+ *     w_far[b][k - k0][n] = W[b][n][k]        k0 <= k < L            (a [B, L-k0, N] array)
+ *   psf_chord_bwd_far_first_link  k0 for this shape: the first link the dV window kernel treats as far; returns L when
+ *                                 a side copy would not be used (no window kernel, no far links), < 0 on bad arguments
+ *   psf_chord_chain_fwd_far_f32   psf_chord_chain_fwd_f32 that also fills wfar_steps[m] (each [B, L-k0, N]; entries or
+ *                                 the table may be NULL = no copy for that step). Steps that run on a kernel which
+ *                                 cannot emit the copy (the single-launch LDS chain, the generic kernel) report it:
+ *                                 *copied_mask gets bit m set for every step whose copy was written (may be NULL).
+ *   psf_chord_spmm_bwd_far_f32    psf_chord_spmm_bwd_f32 with w_far (or NULL) for the same W; k0 as returned above.
+ * Results are bit-identical with and without the copy (same values, same order).
+ */
+int32_t psf_chord_bwd_far_first_link(int64_t B, int64_t N, int32_t L, int64_t C);
+int psf_chord_chain_fwd_far_f32(const float* const* W_steps, const float* V0, float* const* out_steps,
+                                float* const* wfar_steps, int32_t far_k0, uint64_t* copied_mask,
+                                int32_t M, int32_t use_residual,
+                                int64_t B, int64_t N, int32_t L, int64_t C, int64_t v0_batch_stride,
+                                const int64_t* offsets, void* stream);
+int psf_chord_spmm_bwd_far_f32(const float* dZ, const float* W, const float* V, float* dW, float* dV,
+                               int64_t B, int64_t N, int32_t L, int64_t C, int64_t v_batch_stride,
+                               const int64_t* offsets, const float* w_far, int32_t far_k0, void* stream);
+
+/*
  * Producer side: weight / bias gradient of the token-wise Linear layers of MLPBlock
  * (SyntheticExperiments/psf.py:35-60) that produce W_m = fs[m](data) and V = g(data) — a reduction over
  * T = B*N tokens into an n x m tile, done on the f32 matrix core (exact f32) with a fixed-order reduction:

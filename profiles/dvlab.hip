@@ -169,7 +169,7 @@ void launch_prod(const float* dZ, const float* W, const float*, float* dV, const
   auto k = chord_dv_win_k<float, LL, TGSS, R, NTT, false>;
   static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::lds_dv), true);
   (void)once;
-  hipLaunchKernelGGL(k, dim3(gm.nblocks), dim3(NTT), Cfg::lds_dv, 0, dZ, W, dV, gm, offs, wt);
+  hipLaunchKernelGGL(k, dim3(gm.nblocks), dim3(NTT), Cfg::lds_dv, 0, dZ, W, dV, gm, offs, wt, (const float*)nullptr, 0);
 }
 
 template <int R, int FLAGS, int NT = NTT>

@@ -214,7 +214,7 @@ void launch_prod(const float* W, const float* V, const float* res, float* out, c
   auto k = chord_fwd_win_k<float, 15, 1, R, NT, DMA, /*RES=*/true, /*EDGE=*/false>;
   static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::lds_bytes), true);
   (void)once;
-  hipLaunchKernelGGL(k, dim3(gm.nblocks), dim3(NT), Cfg::lds_bytes, 0, W, V, res, out, gm, offs, wt);
+  hipLaunchKernelGGL(k, dim3(gm.nblocks), dim3(NT), Cfg::lds_bytes, 0, W, V, res, out, gm, offs, wt, (float*)nullptr, 0);
 }
 
 template <int R, int NT, int PF, int GRID>

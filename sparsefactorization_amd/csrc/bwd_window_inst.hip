@@ -44,7 +44,7 @@ hipError_t launch_dv(const BwdWinArgs& a) {
   static std::atomic<int> done{0};
   if (hipError_t e = raise_lds_limit(kern, Cfg::lds_dv, done); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(NT), Cfg::lds_dv, a.stream, a.dZ, a.WV, a.out, a.gm, a.offs,
-                     a.w_total);
+                     a.w_total, a.wfar, a.far_k0);
   return hipGetLastError();
 }
 

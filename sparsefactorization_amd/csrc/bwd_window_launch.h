@@ -17,6 +17,8 @@ struct BwdWinArgs {
   int64_t w_total;  // B*N*L
   bool edge;
   hipStream_t stream;
+  const float* wfar = nullptr;  // dV: link-major side copy of W's columns >= far_k0 (include/psf_chord.h), or nullptr
+  int far_k0 = 0;
 };
 
 template <int TGS>

@@ -38,7 +38,7 @@ hipError_t launch_one(const FwdWinArgs& a) {
     }
   }
   hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(NT), lds, a.stream, a.W, a.V, a.res, a.out, a.gm,
-                     a.offs, a.w_total);
+                     a.offs, a.w_total, a.wfar, a.far_k0);
   return hipGetLastError();
 }
 

@@ -38,6 +38,8 @@ struct FwdWinArgs {
   int64_t w_total;  // B*N*L
   bool edge;        // true: the launch contains tiles that are not full (EDGE = true kernels)
   int wg_per_cu;    // 0: whatever fits; n > 0: at most n workgroups per CU (enforced by requesting more LDS)
+  float* wfar;      // training: link-major side copy of W's columns >= far_k0 ([B, L-far_k0, N]), or nullptr
+  int far_k0;
   hipStream_t stream;
 };
 

@@ -310,6 +310,16 @@ bool pick_window(const void* W, int64_t B, int64_t N, int32_t L, int64_t C, cons
   return true;
 }
 
+// The dV window kernel's configuration for a shape (also what psf_chord_bwd_far_first_link reports).
+// default rows per thread (r01 sweep, us at cfg2): dV R=2 31.3 vs R=1 32.7; 512 threads x 1 row per thread instead of
+// 256 x 2 is the same tile at C <= 8 (r02 lab 28.65 vs 29.05 us at cfg2)
+bool pick_dv(const void* W, int64_t B, int64_t N, int32_t L, int64_t C, const Offsets& offs, bool vec_ok, WinPick* pk) {
+  const int knob = g_bwd_rows.load();
+  const int dvt = g_dv_threads.load();
+  const int nt_dv = (dvt == 2 || (dvt == 0 && !knob && C <= 8)) ? kDvMidThreads : 0;
+  return pick_window(W, B, N, L, C, offs, vec_ok, pk, knob ? knob : 2, true, nt_dv);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // typed entry points
 // ------------------------------------------------------------------------------------------------------
@@ -343,8 +353,11 @@ int window_launches(const WinPick& pk, bool all_edge, int64_t B, int64_t N, int3
 }
 
 int fwd_window_f32(const WinPick& pk, const float* W, const float* V, const float* res, float* out, int64_t B,
-                   int64_t N, int32_t L, int64_t C, int64_t v_batch_stride, const Offsets& offs, hipStream_t s) {
+                   int64_t N, int32_t L, int64_t C, int64_t v_batch_stride, const Offsets& offs, hipStream_t s,
+                   float* wfar, int far_k0) {
   FwdWinArgs a;
+  a.wfar = wfar;
+  a.far_k0 = far_k0;
   a.W = W;
   a.V = V;
   a.res = res;
@@ -362,9 +375,13 @@ int fwd_window_f32(const WinPick& pk, const float* W, const float* V, const floa
                          [&] { return launch_win(pk, L, a); }, "chord_fwd_win launch");
 }
 
+// `wfar` (f32 only): ask the step to leave the link-major side copy of W's columns >= far_k0; *copied reports
+// whether the kernel that ran could write it.
 template <typename T>
 int fwd_impl(const T* W, const T* V, const T* res, T* out, int64_t B, int64_t N, int32_t L, int64_t C,
-             int64_t v_batch_stride, const int64_t* offsets, void* stream) {
+             int64_t v_batch_stride, const int64_t* offsets, void* stream, T* wfar = nullptr, int far_k0 = 0,
+             bool* copied = nullptr) {
+  if (copied) *copied = false;
   if (int rc = check_dims(B, N, L, C, v_batch_stride)) return rc;
   if (B == 0) return PSF_OK;
   if (!W || !V || !out) return fail(PSF_E_NULL, "W, V and out must be non-NULL");
@@ -383,8 +400,11 @@ int fwd_impl(const T* W, const T* V, const T* res, T* out, int64_t B, int64_t N,
   const int variant = g_fwd_variant.load();
   if constexpr (sizeof(T) == 4) {  // the window kernels are compiled for f32 only (f64 exists for gradcheck)
     WinPick pk;
-    if (variant != 1 && pick_window(W, B, N, L, C, offs, vec_ok, &pk, g_fwd_rows.load(), true))
-      return fwd_window_f32(pk, W, V, res, out, B, N, L, C, v_batch_stride, offs, s);
+    if (variant != 1 && pick_window(W, B, N, L, C, offs, vec_ok, &pk, g_fwd_rows.load(), true)) {
+      const bool emit = wfar != nullptr && far_k0 >= 0 && far_k0 < L;
+      if (copied) *copied = emit;
+      return fwd_window_f32(pk, W, V, res, out, B, N, L, C, v_batch_stride, offs, s, emit ? wfar : nullptr, far_k0);
+    }
   }
   if (variant == 2)
     return fail(PSF_E_TUNING, "fwd_variant=2 forced but the window kernel does not apply to N=%lld L=%d C=%lld",
@@ -403,7 +423,7 @@ int fwd_impl(const T* W, const T* V, const T* res, T* out, int64_t B, int64_t N,
 
 template <typename T>
 int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64_t N, int32_t L, int64_t C,
-             int64_t v_batch_stride, const int64_t* offsets, void* stream) {
+             int64_t v_batch_stride, const int64_t* offsets, void* stream, const T* wfar = nullptr, int far_k0 = 0) {
   if (int rc = check_dims(B, N, L, C, v_batch_stride)) return rc;
   if (B == 0) return PSF_OK;
   if (!dZ) return fail(PSF_E_NULL, "dZ must be non-NULL");
@@ -425,7 +445,7 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
       WinPick pk;
       // default rows per thread (r01 sweep, us at cfg2): dV R=2 31.3 vs R=1 32.7; dW R=1 22.9 vs R=2 28.7
       const int knob = g_bwd_rows.load();
-      const int rows_dv = knob ? knob : 2, rows_dw = knob ? knob : 1;
+      const int rows_dw = knob ? knob : 1;
       // dW before dV: dV's output is the next (earlier) step's dZ, read first thing by that step's kernels; writing
       // it last leaves it cache-hot (dV 27.4 -> 26.9 us, dW 20.5 -> 20.4 us in the Order training step)
       const int dwv = g_dw_variant.load();
@@ -451,12 +471,12 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
         if (rc) return rc;
         dW = nullptr;
       }
-      // 512 threads x 1 row per thread instead of 256 x 2 (the same tile at C <= 8; r02 lab 28.65 vs 29.05 us at cfg2)
-      const int dvt = g_dv_threads.load();
-      const int nt_dv = (dvt == 2 || (dvt == 0 && !knob && C <= 8)) ? kDvMidThreads : 0;
-      if (dV && pick_window(W, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(dV, 16), &pk,
-                            rows_dv, true, nt_dv)) {
+      if (dV && pick_dv(W, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(dV, 16), &pk)) {
         BwdWinArgs a{dZ, W, dV, Geom{}, offs, w_total, false, s};
+        if (wfar != nullptr && far_k0 >= 0 && far_k0 <= pk.KN && pk.KN < L) {  // the copy covers every far link
+          a.wfar = wfar;
+          a.far_k0 = far_k0;
+        }
         int rc = window_launches(pk, pk.all_edge, B, N, L, C, N * C, true, &a.gm, &a.edge,
                                  [&] { return launch_dv(pk, L, a); }, "chord_dv_win");
         if (rc) return rc;
@@ -493,7 +513,8 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
 template <typename T>
 int chain_impl(const T* const* W_steps, const T* V0, T* const* out_steps, int32_t M, int32_t use_residual,
                int64_t B, int64_t N, int32_t L, int64_t C, int64_t v0_batch_stride, const int64_t* offsets,
-               void* stream) {
+               void* stream, T* const* wfar_steps = nullptr, int far_k0 = 0, uint64_t* copied_mask = nullptr) {
+  if (copied_mask) *copied_mask = 0;
   if (M < 0) return fail(PSF_E_SHAPE, "M must be >= 0");
   if (M == 0) return PSF_OK;
   if (!W_steps || !out_steps || !V0) return fail(PSF_E_NULL, "W_steps, out_steps and V0 must be non-NULL");
@@ -509,6 +530,7 @@ int chain_impl(const T* const* W_steps, const T* V0, T* const* out_steps, int32_
   if constexpr (sizeof(T) == 4) {
     // Short sequences: the whole chain in ONE launch with the sequence's X slice resident in LDS.
     ChainLdsPlan plan;
+    // (the single-launch LDS chain reads W rows straight into registers: it cannot emit the far-column side copy)
     bool ok = g_chain_fused.load() && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, g_chain_cc.load()) &&
               aligned_to(V0, 16) && B * (int64_t)plan.chunks <= 0x7fffffff;
     for (int m = 0; ok && m < M; ++m) ok = aligned_to(W_steps[m], 4) && aligned_to(out_steps[m], 16);
@@ -548,10 +570,12 @@ int chain_impl(const T* const* W_steps, const T* V0, T* const* out_steps, int32_
     // zigzag: every XCD walks its tile range forwards on even steps and backwards on odd ones, so a launch begins
     // with the tiles whose inputs the previous launch wrote LAST (still in that XCD's L2), not first
     t_walk_backwards = (m & 1) != 0;
+    bool copied = false;
     int rc = fwd_impl<T>(W_steps[m], in, use_residual ? V0 : nullptr, out_steps[m], B, N, L, C, stride, offsets,
-                         stream);
+                         stream, wfar_steps ? wfar_steps[m] : nullptr, far_k0, &copied);
     t_walk_backwards = false;
     if (rc) return rc;
+    if (copied && copied_mask && m < 64) *copied_mask |= (uint64_t)1 << m;
   }
   return PSF_OK;
 }
@@ -636,6 +660,34 @@ int psf_chord_chain_fwd_f64(const double* const* W_steps, const double* V0, doub
                             int32_t use_residual, int64_t B, int64_t N, int32_t L, int64_t C,
                             int64_t v0_batch_stride, const int64_t* offsets, void* stream) {
   return chain_impl<double>(W_steps, V0, out_steps, M, use_residual, B, N, L, C, v0_batch_stride, offsets, stream);
+}
+
+int32_t psf_chord_bwd_far_first_link(int64_t B, int64_t N, int32_t L, int64_t C) {
+  if (int rc = check_dims(B, N, L, C, N * C)) return rc;
+  if (g_bwd_variant.load() == 1 || C % 4 != 0) return L;
+  Offsets offs;
+  make_offsets(N, L, nullptr, &offs);
+  WinPick pk;
+  if (!pick_dv(nullptr, B, N, L, C, offs, true, &pk)) return L;
+  return pk.KN < L ? pk.KN : L;
+}
+
+int psf_chord_chain_fwd_far_f32(const float* const* W_steps, const float* V0, float* const* out_steps,
+                                float* const* wfar_steps, int32_t far_k0, uint64_t* copied_mask, int32_t M,
+                                int32_t use_residual, int64_t B, int64_t N, int32_t L, int64_t C,
+                                int64_t v0_batch_stride, const int64_t* offsets, void* stream) {
+  if (wfar_steps && (far_k0 < 0 || far_k0 > L)) return fail(PSF_E_SHAPE, "far_k0 must be in [0, L]");
+  if (wfar_steps && M > 64) return fail(PSF_E_SHAPE, "the far-column side copy is reported for at most 64 steps");
+  // short sequences still take the single-launch LDS chain (forward speed first); it writes no copy: mask stays 0
+  return chain_impl<float>(W_steps, V0, out_steps, M, use_residual, B, N, L, C, v0_batch_stride, offsets, stream,
+                           (wfar_steps && far_k0 < L) ? wfar_steps : nullptr, far_k0, copied_mask);
+}
+
+int psf_chord_spmm_bwd_far_f32(const float* dZ, const float* W, const float* V, float* dW, float* dV, int64_t B,
+                               int64_t N, int32_t L, int64_t C, int64_t v_batch_stride, const int64_t* offsets,
+                               const float* w_far, int32_t far_k0, void* stream) {
+  if (w_far && !aligned_to(w_far, 4)) return fail(PSF_E_ALIGN, "w_far must be aligned to the element size");
+  return bwd_impl<float>(dZ, W, V, dW, dV, B, N, L, C, v_batch_stride, offsets, stream, w_far, far_k0);
 }
 
 int psf_set_tuning(const char* key, int32_t value) {

@@ -472,7 +472,7 @@ def test_fused_lds_chain_matches_oracle_and_per_step(gpu, B, N, M, L, C, residua
                 got[fused] = sfa.chord_chain(Ws, _t(V0, gpu), residual).cpu().numpy()       # ping-pong storage
             Wg = [w.clone().requires_grad_(True) for w in Ws]
             out = sfa.chord_chain(Wg, _t(V0, gpu), residual)                                # every step stored
-            steps = [t for t in out.grad_fn.saved_tensors][1 + M:]
+            steps = [t for t in out.grad_fn.saved_tensors][1 + M:2 * M]
             for m, t in enumerate(steps):
                 assert np.array_equal(t.cpu().numpy(), want[m]), f"fused={fused} stored step {m}"
             assert np.array_equal(out.detach().cpu().numpy(), want[-1])
@@ -631,3 +631,66 @@ def test_chain_backward_residual_gradient_one_pass_sum(gpu):
     V.backward(dZ)
     assert all(torch.equal(a, w.grad) for a, w in zip(gW, Ws))
     assert rel_inf(V0a.grad.cpu().numpy(), V0b.grad.cpu().numpy()) <= 1e-6  # autograd adds the M+1 terms in its own order
+
+
+FAR_SHAPES = [(2, 16384, 15, 8), (3, 4097, 13, 8), (2, 5000, 14, 32), (2, 8192, 14, 128), (1, 16385, 15, 16)]
+
+
+@pytest.mark.parametrize("B,N,L,C", FAR_SHAPES)
+def test_far_column_side_copy(gpu, B, N, L, C):
+    """Training forward steps leave w_far[b][k-k0][n] = W[b][n][k] for the links the dV kernel treats as far
+    (include/psf_chord.h, psf_chord_chain_fwd_far_f32); dV computed with that copy is bit-identical to dV without it
+    and to the oracle; full, ragged (N % tile != 0) and wide-row launches."""
+    import ctypes
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import _lib
+    from sparsefactorization_amd.chord import _launch_bwd
+    lib = _lib.load()
+    k0 = lib.psf_chord_bwd_far_first_link(B, N, L, C)
+    assert 2 <= k0 < L, k0
+    M = 3
+    W = [_mk((B, N, L), 110 + m, 0.3) for m in range(M)]
+    V0 = _mk((B, N, C), 120)
+    Wt = [_t(w, gpu) for w in W]
+    V0t = _t(V0, gpu)
+    outs = [torch.empty(B, N, C, device=gpu) for _ in range(M)]
+    fars = [torch.full((B, L - k0, N), float("nan"), device=gpu) if m != 1 else None for m in range(M)]  # step 1: no copy wanted
+    tab = lambda ts: (ctypes.c_void_p * M)(*[t.data_ptr() if t is not None else None for t in ts])  # noqa: E731
+    mask = ctypes.c_uint64(0)
+    rc = lib.psf_chord_chain_fwd_far_f32(tab(Wt), V0t.data_ptr(), tab(outs), tab(fars), k0, ctypes.byref(mask), M, 1,
+                                         B, N, L, C, N * C, None, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "psf_chord_chain_fwd_far_f32")
+    assert mask.value == 0b101
+    for m in (0, 2):
+        assert torch.equal(fars[m], Wt[m][:, :, k0:].transpose(1, 2))
+    # same chain outputs as the plain entry point
+    rows, cols = oc.chord_indices(N, L)
+    want = oc.chain(np.stack([rows, cols]), np.stack(W), V0, True)
+    for m in range(M):
+        assert np.array_equal(outs[m].cpu().numpy(), want[m])
+    # dV with and without the copy
+    dZ = _mk((B, N, C), 130)
+    dZt = _t(dZ, gpu)
+    plain = torch.empty(B, N, C, device=gpu)
+    with_copy = torch.full((B, N, C), float("nan"), device=gpu)
+    _launch_bwd(dZt, Wt[0], V0t, None, plain, B, N, L, C, N * C, None)
+    _launch_bwd(dZt, Wt[0], V0t, None, with_copy, B, N, L, C, N * C, None, fars[0], k0)
+    assert torch.equal(plain, with_copy)
+    assert np.array_equal(with_copy.cpu().numpy(), oc.spmul_bwd(dZ, W[0], V0)[1])
+
+
+def test_chain_backward_is_identical_with_and_without_the_side_copy(gpu):
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import chord
+    B, N, M, C = 2, 16384, 5, 8
+    grads = {}
+    for flag in (True, False):
+        chord.far_copy = flag  # (module default: False)
+        try:
+            Ws = [_t(_mk((B, N, M + 1 + 9), 140 + m, 0.2), gpu).requires_grad_(True) for m in range(M)]  # L = 15
+            V0 = _t(_mk((B, N, C), 150), gpu).requires_grad_(True)
+            sfa.chord_chain(Ws, V0, True).backward(_t(_mk((B, N, C), 151), gpu))
+            grads[flag] = [w.grad for w in Ws] + [V0.grad]
+        finally:
+            chord.far_copy = False
+    assert all(torch.equal(a, b) for a, b in zip(grads[True], grads[False]))
