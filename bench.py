@@ -65,12 +65,19 @@ def parse_args(argv=None):
 # ---------------------------------------------------------------------------------------------------------
 # parent side: start N ranks as a child job (no GPU call may happen in this process before or after)
 # ---------------------------------------------------------------------------------------------------------
+def rehearsal() -> bool:
+    """PSF_BENCH_REHEARSAL=1: run the N-rank code path (self-launch, barriers, gathers, the gradient reducer) on a box
+    with fewer GPUs than ranks — ranks share the GPUs round-robin and talk over gloo, because RCCL refuses two ranks on
+    one device. For checking the multi-rank plumbing only: the line is marked and its numbers mean nothing."""
+    return os.environ.get("PSF_BENCH_REHEARSAL", "0") == "1"
+
+
 def self_launch(args) -> int:
     import socket
 
     import torch  # importing torch does not initialise the GPU; device_count() does not either on this image
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not (rehearsal() and have >= 1):
         print(f"bench.py: --gpus {args.gpus} but this host exposes {have} GPU(s); "
               "one rank per GPU is required (no oversubscription)", file=sys.stderr, flush=True)
         return 2
@@ -223,14 +230,15 @@ def run_rank(args) -> int:
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr, flush=True)
         return 2
-    if torch.cuda.device_count() <= local_rank:
-        print(f"bench.py: rank {rank} needs GPU {local_rank} but this host exposes {torch.cuda.device_count()} GPU(s)",
+    n_dev = torch.cuda.device_count()
+    if n_dev <= local_rank and not (rehearsal() and n_dev >= 1):
+        print(f"bench.py: rank {rank} needs GPU {local_rank} but this host exposes {n_dev} GPU(s)",
               file=sys.stderr, flush=True)
         return 2
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU path)", file=sys.stderr)
         return 2
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % n_dev if rehearsal() else local_rank)
     torch.cuda.set_device(device)
 
     dist = None
@@ -238,7 +246,10 @@ def run_rank(args) -> int:
         import torch.distributed as dist  # backend "nccl" is RCCL on ROCm
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal():
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import sparsefactorization_amd as sfa
 
@@ -277,7 +288,7 @@ def run_rank(args) -> int:
 
     per_rank_ms = [ev_ms]
     if dist is not None:
-        t = torch.tensor([elapsed, ev_ms], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed, ev_ms], device="cpu" if rehearsal() else device, dtype=torch.float64)  # gloo gathers CPU tensors
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
         elapsed = max(float(g[0]) for g in gathered)  # MAX over ranks
@@ -332,6 +343,8 @@ def run_rank(args) -> int:
             },
             "rank_ms_per_step": {"min": min(per_rank_ms) / args.steps, "max": max(per_rank_ms) / args.steps},
         }
+        if rehearsal():
+            line["rehearsal"] = "ranks share GPUs over gloo: plumbing check only, the numbers are meaningless"
         if train is not None:
             line["train"] = train
         if world == 1 and not args.no_cpu_baseline:
@@ -359,7 +372,7 @@ def train_leg(args, device, rank, world, dist):
                             rank=rank, world=world, graph=args.train_graph)
         vals = [r["seconds"], r["event_ms"], r["allreduce_us"] if r["allreduce_us"] is not None else -1.0]
         if dist is not None:
-            t = torch.tensor(vals, device=device, dtype=torch.float64)
+            t = torch.tensor(vals, device="cpu" if rehearsal() else device, dtype=torch.float64)
             gathered = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(gathered, t)
             secs = max(float(g[0]) for g in gathered)

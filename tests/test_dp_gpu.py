@@ -1,0 +1,72 @@
+"""GPU, 2 processes sharing the one GPU of the box over gloo (RCCL refuses two ranks on one device): the data-parallel
+training path on the REAL model — broadcast of the replicas, batch shards, dp.FlatGradAllReduce over the HIP kernels'
+gradients, parameters without a gradient — against single-process training on the concatenated batch.
+(The 2-rank CPU test, tests/test_dp_gloo.py, can only use a toy model: the chord path has no CPU implementation.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(vocab_size=6, add_init_linear_layer=False, embedding_size=32, n_vec=512, n_W=9, Ws=[32, 'GELU'], V=[32, 'GELU'],
+           n_channels_V=8, n_class=4, pooling_type="FLATTEN", head=['linear'], use_cuda=True, use_residuals=True,
+           use_pos_embedding=True, problem="order")
+STEPS, GLOBAL_B = 3, 16
+
+
+def _batches(device):
+    g = torch.Generator().manual_seed(5)
+    return [(torch.randint(0, 6, (GLOBAL_B, 512, 1), generator=g).to(device), torch.randint(0, 4, (GLOBAL_B,), generator=g).to(device))
+            for _ in range(STEPS)]
+
+
+def _train(net, batches, reducer, rank, world):
+    from sparsefactorization_amd import dp
+    from sparsefactorization_amd.train import make_adam
+    opt = make_adam(net.parameters(), 1e-3)
+    loss = torch.nn.CrossEntropyLoss()
+    for X, Y in batches:
+        Xs, Ys = dp.shard_batch([X, Y], rank, world)
+        opt.zero_grad(set_to_none=True)
+        loss(net(Xs).squeeze(), Ys).backward()
+        if reducer is not None:
+            reducer()
+        opt.step()
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from sparsefactorization_amd import dp
+    from sparsefactorization_amd.synthetic_psf import PSFNet
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)  # replicas start different on purpose; the broadcast makes them rank 0's
+    net = PSFNet(**CFG).to(dev)
+    dp.broadcast_parameters(net, src=0)
+    reducer = dp.FlatGradAllReduce(net.parameters())
+    _train(net, _batches(dev), reducer, rank, world)
+    torch.save({k: v.cpu() for k, v in net.state_dict().items()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.save(reducer.calls, os.path.join(out_dir, f"calls{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_of_the_real_model_equals_single_process(gpu, tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    sd0, sd1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert torch.load(tmp_path / "calls0.pt") == STEPS
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), f"replicas diverged at {k}"
+    from sparsefactorization_amd.synthetic_psf import PSFNet
+    torch.manual_seed(100)
+    net = PSFNet(**CFG).to(gpu)
+    _train(net, _batches(gpu), None, 0, 1)
+    for k, v in net.state_dict().items():
+        assert torch.allclose(sd0[k], v.cpu(), rtol=2e-4, atol=2e-6), k

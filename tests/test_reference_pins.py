@@ -298,3 +298,25 @@ def test_training_driver_under_a_one_rank_rccl_group(gpu, monkeypatch, capsys):
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_on_one_gpu(gpu):
+    """The N-rank path of bench.py end to end — the parent starts torch.distributed.run as a child, two ranks, barriers,
+    per-rank gathers, the training leg with the flat gradient all-reduce and forward+backward replayed from a HIP graph
+    — on a 1-GPU box: PSF_BENCH_REHEARSAL=1 lets the ranks share the GPU and talk over gloo (RCCL refuses two ranks on
+    one device). The numbers mean nothing; that the line is produced and well-formed is the test."""
+    import json
+    env = dict(os.environ, PSF_BENCH_REHEARSAL="1")
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                           "--train-steps", "2", "--train-graph"], capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 128
+    assert len(line["roofline"]["frac_per_gpu"]) == 2 and "rehearsal" in line and "cpu_baseline" not in line
+    tr = line["train"]
+    assert "error" not in tr, tr
+    assert tr["global_batch"] == 80 and tr["allreduce_us"] > 0 and tr["allreduce_bytes"] > 4e6 and tr["hip_graph"] == "fwd+bwd"
+    assert np.isfinite(tr["loss"]) and tr["value"] > 0
