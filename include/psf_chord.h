@@ -265,8 +265,17 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
  *   key "bwd_variant": 0 = auto (LDS-window dV / dW kernels where they apply), 1 = generic kernels
  *   key "fwd_rows"   : 0 = per-shape default, else rows per thread of the LDS-window kernel (1, 2)
  *   key "bwd_rows"   : 0 = defaults (dV 2, dW 1), else rows per thread of both backward window kernels
- *   key "fwd_split"  : 1 = full tiles on the predicate-free kernel, ragged tiles in a second launch (default);
- *                      0 = every tile on the general (edge) kernel
+ *   key "fwd_split"  : window kernels (forward, dV, dW) on shapes with a ragged last tile per sequence: 1 = by size
+ *                      (default: one launch of the general (edge) instance below ~300 MB of algorithmic bytes, where the
+ *                      ~2.7 us of a second launch outweigh predicating every tile; above that as 2); 2 = full tiles on
+ *                      the predicate-free instance + the ragged tiles in a second launch; 0 = every tile on the edge
+ *                      instance
+ *   key "dw_variant" : dW: 0 = auto (chunk-looping kernel for rows of >= 32 channels whose channel groups split into
+ *                      chunks of 8, else the whole-row window kernel), 1 = whole-row window kernel, 2 = chunk-looping
+ *                      kernel or PSF_E_TUNING where it does not apply
+ *   key "dw_tgs"     : chunk-looping dW, lanes per row chunk: 0 = auto (8; 16 when that spares a ragged tile), 4 = 8, 5 = 16
+ *   key "dv_threads" : dV window kernel: 0 = auto (512 threads x 1 row for C <= 8, else 256 threads), 1 = 256 threads
+ *                      (rows per thread from "bwd_rows"), 2 = 512 threads x 1 row where compiled (C <= 32)
  *   key "fwd_wide"   : rows of >= 64 channels: 0 = one workgroup spans the whole row (default, fastest measured);
  *                      1 = 32-channel chunks on 1024-thread workgroups (256-row tiles); 2 = 32-channel chunks
  *                      on 256-thread workgroups
@@ -281,6 +290,10 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
  *   key "mlp_variant": psf_mlp_fwd_f32: 0 = auto (default: the split-bf16 kernel for E <= 32, else the f32-MFMA
  *                      kernel), 1 = f32 MFMA with streamed weights, 2 = f32 MFMA with LDS-resident weights,
  *                      3 = split-bf16 (each f32 operand as three exact bf16 terms, six product terms: f32 accuracy)
+ *   key "mlp_bwd_variant": psf_mlp_bwd_f32: 0 = auto (default: the split-bf16 kernel — steps 1, 2, 6 on the bf16
+ *                      matrix pipe, all five GEMMs at one tile per wave), 1 = all-f32-MFMA kernel, 2 / 3 = split-bf16 with
+ *                      all five / only steps 1, 2, 6 on bf16 at one tile per wave, 4 = split-bf16 on 256-thread
+ *                      workgroups (two per CU)
  *   key "xcd_remap"  : 1 = keep a batch element's tiles on one XCD group (default), 0 = linear
  * psf_get_tuning returns the value (>= 0) or PSF_E_TUNING.
  */
