@@ -36,22 +36,6 @@ struct DwChunkCfg {
   static constexpr int lds_bytes = win_bytes + w_passes * NT * 16;
 };
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-
-// Sum over the TG adjacent lanes that share a row (TG <= 16; a row group never straddles a DPP row of 16 lanes).
-// Every lane of the group ends up with the total.
-template <int TG>
-__device__ __forceinline__ float row_group_sum(float v) {
-  if constexpr (TG >= 16) v = add_rn(v, dpp_f32<0x140>(v));  // row_mirror: lane i <-> 15 - i
-  if constexpr (TG >= 8) v = add_rn(v, dpp_f32<0x141>(v));   // row_half_mirror: i <-> 7 - i
-  if constexpr (TG >= 4) v = add_rn(v, dpp_f32<0x4E>(v));    // quad_perm [2,3,0,1]
-  if constexpr (TG >= 2) v = add_rn(v, dpp_f32<0xB1>(v));    // quad_perm [1,0,3,2]
-  return v;
-}
-
 template <int L, int TGS, int R, int NT, bool EDGE>
 __global__ void __launch_bounds__(NT)
 chord_dw_chunk_k(const float* __restrict__ dZ, const float* __restrict__ V, float* __restrict__ dW, const Geom gm,

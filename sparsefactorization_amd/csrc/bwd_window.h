@@ -25,6 +25,27 @@
 
 namespace psf {
 
+// ---- cross-lane sums on DPP (one VALU instruction per stage; __shfl_xor compiles to ds_bpermute_b32, an LDS-crossbar
+//      round trip per stage) ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// Sum over the TG adjacent lanes that share a row. TG <= 16: a row group never straddles a DPP row of 16 lanes and the
+// whole reduction is DPP; wider groups do their upper stages with wave shuffles first. Every lane of the group ends up
+// with the total.
+template <int TG>
+__device__ __forceinline__ float row_group_sum(float v) {
+#pragma unroll
+  for (int s = TG >> 1; s >= 16; s >>= 1) v = add_rn(v, __shfl_xor(v, s, 64));
+  if constexpr (TG >= 16) v = add_rn(v, dpp_f32<0x140>(v));  // row_mirror: lane i <-> 15 - i
+  if constexpr (TG >= 8) v = add_rn(v, dpp_f32<0x141>(v));   // row_half_mirror: i <-> 7 - i
+  if constexpr (TG >= 4) v = add_rn(v, dpp_f32<0x4E>(v));    // quad_perm [2,3,0,1]
+  if constexpr (TG >= 2) v = add_rn(v, dpp_f32<0xB1>(v));    // quad_perm [1,0,3,2]
+  return v;
+}
+
 template <typename T, int L, int TGS, int R, int NT>
 struct BwdWinCfg {
   using F = FwdWinCfg<T, L, TGS, R, NT>;
@@ -140,8 +161,12 @@ chord_dw_win_k(const T* __restrict__ dZ, const T* __restrict__ V, T* __restrict_
       T part = T(0);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) part = add_rn(part, mul_rn(dz[j].e[i], x.e[i]));
+      if constexpr (sizeof(T) == 4) {
+        part = row_group_sum<TG>(part);
+      } else {
 #pragma unroll
-      for (int s = TG >> 1; s > 0; s >>= 1) part = add_rn(part, __shfl_xor(part, s, 64));
+        for (int s = TG >> 1; s > 0; s >>= 1) part = add_rn(part, __shfl_xor(part, s, 64));
+      }
       if (g == 0) sOutF[mis + pl * L + k] = part;
     }
   }
