@@ -694,3 +694,37 @@ def test_chain_backward_is_identical_with_and_without_the_side_copy(gpu):
         finally:
             chord.far_copy = False
     assert all(torch.equal(a, b) for a, b in zip(grads[True], grads[False]))
+
+
+def _random_shapes(n, seed):
+    rng = np.random.default_rng(seed)
+    shapes = []
+    for _ in range(n):
+        N = int(rng.choice([rng.integers(1, 64), rng.integers(64, 700), rng.integers(700, 6000)]))
+        L = int(rng.integers(1, 25))
+        C = int(rng.choice([rng.integers(1, 13), 4 * rng.integers(1, 12), 32 * rng.integers(1, 9), 4 * rng.integers(12, 70)]))
+        B = int(rng.integers(1, 4))
+        shapes.append((B, N, L, C))
+    return shapes
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_shapes_forward_and_backward(gpu, seed):
+    """Dispatcher sweep: 30 random (B, N, L, C) per seed — tiny and non-power-of-two N, L from 1 to 24 (inside and outside
+    the compiled window kernels), C not a multiple of 4, multiples of 32 (chunk-looping dW), ragged tilings — forward and
+    dV bit-exact against the oracle, dW <= 1e-5, with and without the residual."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.chord import _launch_bwd
+    for (B, N, L, C) in _random_shapes(30, seed):
+        W, V, R, dZ = _mk((B, N, L), 7 * seed + 1, 0.5), _mk((B, N, C), 7 * seed + 2), _mk((B, N, C), 7 * seed + 3), _mk((B, N, C), 7 * seed + 4)
+        tag = f"B={B} N={N} L={L} C={C}"
+        got = sfa.chord_spmm(_t(W, gpu), _t(V, gpu), _t(R, gpu)).cpu().numpy()
+        assert np.array_equal(got, _oracle_fwd(W, V, R)), tag
+        got = sfa.chord_spmm(_t(W, gpu), _t(V, gpu)).cpu().numpy()
+        assert np.array_equal(got, _oracle_fwd(W, V)), tag
+        gW = torch.full((B, N, L), float("nan"), device=gpu)
+        gV = torch.full((B, N, C), float("nan"), device=gpu)
+        _launch_bwd(_t(dZ, gpu), _t(W, gpu), _t(V, gpu), gW, gV, B, N, L, C, N * C, None)
+        dF, dV = oc.spmul_bwd(dZ, W, V)
+        assert np.array_equal(gV.cpu().numpy(), dV), tag
+        assert rel_inf(gW.cpu().numpy(), dF) <= TOL, tag
