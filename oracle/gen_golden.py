@@ -8,7 +8,8 @@ What comes from the reference itself (imported from /root/reference, executed un
   * get_chord_indices_assym                      SyntheticExperiments/psf.py:7-32
   * PSFNet.__init__/forward (the hot loop, the reshape of W, the residual, the heads)
                                                  SyntheticExperiments/psf.py:62-191, LRA/psf.py:63-250
-  * trained weights                              LRA/attention_maps/pathfinder_epoch27.pt
+  * trained weights                              LRA/attention_maps/{pathfinder_epoch27,imdb_epoch138,cifar10_epoch35}.pt
+  * the genome model                             Genome_Clf/psf.py:63-240
   * TrainModel (the training / evaluation loop)  SyntheticExperiments/psf_utils.py:48-137 — called as it is; its
                                                  `.cuda()` calls are made the identity for the run (no GPU here)
   * the stand-alone attention block              attention_block.py:70-178 (imported with an empty
@@ -235,6 +236,49 @@ def gen_lra(lra):
     save("lra_imdb_n4097.npz", x=x.numpy(), logits=res["logits"], Vfin=res["Vfin"], V0=res["V0"],
          W_sha=np.asarray(sha256(res["W"])), **state_arrays(net))
 
+    # (d) trained IMDb checkpoint (imdb_epoch138.pt), config LRA/psf_training_config.py:89-117: N = 4097 (4096 + CLS),
+    #     L = 13, C = 32, CLS pooling, residual. Logits, V after the loop (every 4th row) and the dense attention map as
+    #     ChangedPSF.forward builds it (imdb_inference.py:41,53-59: the same spmm on an unbatched eye(N); restated without
+    #     .cuda()): rows [::256], row sums. pos_embedding (4097 x 32, unused: use_pos_embedding = False) is left out of
+    #     the stored state to keep the fixture small.
+    cfg = dict(vocab_size=97, embedding_size=32, n_vec=4097, n_W=12, Ws=[128, 'GELU'], V=[128, 'GELU'], n_channels_V=32,
+               n_class=2, pooling_type="CLS", head=['linear'], use_cuda=False, use_residuals=True, dropout1_p=0.4,
+               dropout2_p=0, dropout3_p=0, init_embedding_weights=True, use_pos_embedding=False, problem="imdb")
+    net = lra.PSFNet(**cfg)
+    net.load_state_dict(torch.load(os.path.join(REF, "LRA/attention_maps/imdb_epoch138.pt"), map_location="cpu",
+                                   weights_only=True), strict=True)
+    net.eval()
+    g = torch.Generator().manual_seed(14)
+    x = torch.randint(0, 95, (1, 4097), generator=g)
+    x[0, 0] = 96  # CLS token id = vocab_size - 1 (imdb_training.py CLS block)
+    res = run_and_capture(net, x, None, vfinal_module=net.dropout3)
+    W_final = torch.eye(4097, 4097)
+    for m in range(net.n_W):
+        W = torch.from_numpy(res["W"][m])
+        W_final = torch_spmm_port(net.chord_indicies, W.reshape(W.size(0), W.size(1) * W.size(2)), 4097, 4097, W_final)
+    wf = W_final.numpy()
+    st = {k: v for k, v in state_arrays(net).items() if k != "sd::pos_embedding.weight"}
+    save("lra_imdb_ckpt.npz", x=x.numpy(), logits=res["logits"], V0_rows=res["V0"][:, ::4].copy(),
+         Vfin_rows=res["Vfin"][:, ::4].copy(), W_sha=np.asarray(sha256(res["W"])), Wfinal_rows=wf[0, ::256, :].copy(),
+         Wfinal_rowsum=wf.sum(-1), **st)
+    del W_final, wf
+
+    # (e) trained CIFAR-10 checkpoint (cifar10_epoch35.pt), config psf_training_config.py:31-58: N = 1024, L = 11, C = 16,
+    #     no residual. Chain level only (V after the loop); the 16384 x 16 head is left out of the stored state.
+    cfg = dict(vocab_size=256, embedding_size=16, n_vec=1024, n_W=10, Ws=[16, 'GELU'], V=[16, 'GELU'], n_channels_V=16,
+               n_class=10, pooling_type="FLATTEN", head=['non-linear', 16], use_cuda=False, use_residuals=False,
+               dropout1_p=0, dropout2_p=0.2, dropout3_p=0.8, init_embedding_weights=False, use_pos_embedding=True,
+               problem="cifar10")
+    net = lra.PSFNet(**cfg)
+    net.load_state_dict(torch.load(os.path.join(REF, "LRA/attention_maps/cifar10_epoch35.pt"), map_location="cpu",
+                                   weights_only=True), strict=True)
+    net.eval()
+    g = torch.Generator().manual_seed(15)
+    x = torch.randint(0, 256, (2, 1024), generator=g)
+    res = run_and_capture(net, x, None, vfinal_module=net.dropout3)
+    st = {k: v for k, v in state_arrays(net).items() if not k.startswith("sd::final.")}
+    save("lra_cifar10_ckpt.npz", x=x.numpy(), V0=res["V0"], Vfin=res["Vfin"], W_sha=np.asarray(sha256(res["W"])), **st)
+
     # state_dict layouts of every shipped PSF checkpoint (names and shapes only)
     lines = []
     for ck in ("pathfinder_epoch27.pt", "imdb_epoch138.pt", "cifar10_epoch35.pt", "PSF_5.pt"):
@@ -353,6 +397,23 @@ def gen_attention_block():
              n_W=np.asarray(net.n_W), n_links=np.asarray(net.n_links))
 
 
+# ---------------------------------------------------------------------------------------------------
+# 5. Genome_Clf/psf.py (the LRA model without `problem`)
+# ---------------------------------------------------------------------------------------------------
+def gen_genome(gen):
+    torch.manual_seed(48)
+    cfg = dict(vocab_size=6, embedding_size=16, n_vec=320, n_W=9, Ws=[16, 'GELU'], V=[16, 'GELU'], n_channels_V=16,
+               n_class=2, pooling_type="FLATTEN", head=['linear'], use_cuda=False, use_residuals=True, dropout1_p=0,
+               dropout2_p=0, dropout3_p=0, init_embedding_weights=True, use_pos_embedding=True)
+    net = gen.PSFNet(**cfg)
+    net.eval()
+    g = torch.Generator().manual_seed(16)
+    x = torch.randint(0, 6, (2, 320), generator=g)
+    res = run_and_capture(net, x, None, vfinal_module=net.dropout3)
+    save("genome_n320.npz", x=x.numpy(), logits=res["logits"], V0=res["V0"], Vfin=res["Vfin"], W=res["W"],
+         **state_arrays(net))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # deterministic CPU reductions
@@ -363,6 +424,7 @@ def main():
     gen_lra(lra)
     gen_training(se, import_reference("ref_se_psf_utils", "SyntheticExperiments/psf_utils.py"))
     gen_attention_block()
+    gen_genome(import_reference("ref_genome_psf", "Genome_Clf/psf.py"))
 
 
 if __name__ == "__main__":

@@ -320,3 +320,112 @@ def test_bench_two_rank_rehearsal_on_one_gpu(gpu):
     assert "error" not in tr, tr
     assert tr["global_batch"] == 80 and tr["allreduce_us"] > 0 and tr["allreduce_bytes"] > 4e6 and tr["hip_graph"] == "fwd+bwd"
     assert np.isfinite(tr["loss"]) and tr["value"] > 0
+
+
+# ------------------------------------------------------------------------------------------------------------
+# shipped checkpoints (IMDb, CIFAR-10) and the genome model
+# ------------------------------------------------------------------------------------------------------------
+IMDB_CKPT = dict(vocab_size=97, embedding_size=32, n_vec=4097, n_W=12, Ws=[128, 'GELU'], V=[128, 'GELU'], n_channels_V=32,
+                 n_class=2, pooling_type="CLS", head=['linear'], use_residuals=True, dropout1_p=0.4, dropout2_p=0,
+                 dropout3_p=0, init_embedding_weights=True, use_pos_embedding=False, problem="imdb")
+CIFAR_CKPT = dict(vocab_size=256, embedding_size=16, n_vec=1024, n_W=10, Ws=[16, 'GELU'], V=[16, 'GELU'], n_channels_V=16,
+                  n_class=10, pooling_type="FLATTEN", head=['non-linear', 16], use_residuals=False, dropout1_p=0,
+                  dropout2_p=0.2, dropout3_p=0.8, init_embedding_weights=False, use_pos_embedding=True, problem="cifar10")
+GENOME = dict(vocab_size=6, embedding_size=16, n_vec=320, n_W=9, Ws=[16, 'GELU'], V=[16, 'GELU'], n_channels_V=16, n_class=2,
+              pooling_type="FLATTEN", head=['linear'], use_residuals=True, dropout1_p=0, dropout2_p=0, dropout3_p=0,
+              init_embedding_weights=True, use_pos_embedding=True)
+
+
+def _cpu_links(twin, g, use_pos):
+    """W_m and V0 recomputed on the CPU from the stored weights exactly as the generator's reference run did."""
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        data = twin.embedding(torch.from_numpy(g["x"]))
+        if use_pos:
+            data = data + twin.pos_embedding.weight.unsqueeze(0)
+        return twin.g(data), twin.link_weights(data)
+
+
+def test_oracle_matches_genome_reference_loop():
+    g = load_golden("genome_n320.npz")
+    M, B, N, L = g["W"].shape
+    rows, cols = oc.chord_indices(N, L)
+    assert rel_inf(oc.chain(np.stack([rows, cols]), g["W"], g["V0"], True)[-1], g["Vfin"]) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_genome_model_matches_reference(gpu):
+    """Genome_Clf/psf.py:63-240 (the LRA model without `problem`): logits of the reference's run, chain bit-equal to the
+    oracle on its captured operands."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.genome_psf import PSFNet
+    g = load_golden("genome_n320.npz")
+    net = PSFNet(**GENOME, use_cuda=True)
+    net.load_state_dict(golden_state_dict(g), strict=True)
+    net = net.to(gpu).eval()
+    with torch.no_grad():
+        logits = net(torch.from_numpy(g["x"]).to(gpu))
+        Vf = sfa.chord_chain([torch.from_numpy(w.copy()).to(gpu) for w in g["W"]], torch.from_numpy(g["V0"].copy()).to(gpu), True)
+    assert rel_inf(logits.cpu().numpy(), g["logits"]) <= 1e-4
+    assert rel_inf(Vf.cpu().numpy(), g["Vfin"]) <= 1e-5
+    M, B, N, L = g["W"].shape
+    rows, cols = oc.chord_indices(N, L)
+    assert np.array_equal(Vf.cpu().numpy(), oc.chain(np.stack([rows, cols]), g["W"], g["V0"], True)[-1])
+
+
+@pytest.mark.gpu
+def test_imdb_checkpoint_logits_chain_and_attention_map(gpu):
+    """imdb_epoch138.pt (N = 4097 = 4096 + CLS, L = 13, C = 32, residual, CLS pooling): the chain on CPU-recomputed links
+    vs the reference's V after its loop, the whole model's logits, and the dense 4097 x 4097 attention map of
+    imdb_inference.py:41,53-59 (ChangedPSF) against rows and row sums of the reference op sequence's map."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.lra_psf import ChangedPSF, PSFNet
+    g = load_golden("lra_imdb_ckpt.npz")
+    sd = golden_state_dict(g)
+    twin = PSFNet(**IMDB_CKPT, use_cuda=False)
+    missing = twin.load_state_dict(sd, strict=False)
+    assert missing.missing_keys == ["pos_embedding.weight"] and not missing.unexpected_keys  # unused, left out of the fixture
+    twin.eval()
+    V0, Ws = _cpu_links(twin, g, use_pos=False)
+    assert rel_inf(V0.numpy()[:, ::4], g["V0_rows"]) <= 1e-6
+    with torch.no_grad():
+        Wg = [w.to(gpu) for w in Ws]
+        Vf = sfa.chord_chain(Wg, V0.to(gpu), True).cpu().numpy()
+        att = sfa.chord_chain(Wg, torch.eye(4097, device=gpu), False)
+    assert rel_inf(Vf[:, ::4], g["Vfin_rows"]) <= 1e-5
+    assert att.shape == (1, 4097, 4097)
+    att = att.cpu().numpy()
+    assert rel_inf(att[0, ::256, :], g["Wfinal_rows"]) <= 1e-5
+    assert rel_inf(att.sum(-1), g["Wfinal_rowsum"]) <= 1e-5
+    net = ChangedPSF(**IMDB_CKPT, use_cuda=True)
+    net.load_state_dict(sd, strict=False)
+    net = net.to(gpu).eval()
+    with torch.no_grad():
+        logits, att2 = net(torch.from_numpy(g["x"]).to(gpu))
+    assert rel_inf(logits.cpu().numpy(), g["logits"]) <= 1e-4
+    assert rel_inf(att2.cpu().numpy()[0, ::256, :], g["Wfinal_rows"]) <= 1e-4  # links from the GPU MLPs here
+
+
+@pytest.mark.gpu
+def test_cifar10_checkpoint_chain(gpu):
+    """cifar10_epoch35.pt (N = 1024, L = 11, C = 16, no residual): chain on CPU-recomputed links vs the reference's V after
+    its loop (the 16384 x 16 head is not part of the fixture), and the same through the module's `features`."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.lra_psf import PSFNet
+    g = load_golden("lra_cifar10_ckpt.npz")
+    sd = golden_state_dict(g)
+    twin = PSFNet(**CIFAR_CKPT, use_cuda=False)
+    missing = twin.load_state_dict(sd, strict=False)
+    assert all(k.startswith("final.") for k in missing.missing_keys) and not missing.unexpected_keys
+    twin.eval()
+    V0, Ws = _cpu_links(twin, g, use_pos=True)
+    assert rel_inf(V0.numpy(), g["V0"]) <= 1e-6
+    with torch.no_grad():
+        Vf = sfa.chord_chain([w.to(gpu) for w in Ws], V0.to(gpu), False).cpu().numpy()
+    assert rel_inf(Vf, g["Vfin"]) <= 1e-5
+    net = PSFNet(**CIFAR_CKPT, use_cuda=True)
+    net.load_state_dict(sd, strict=False)
+    net = net.to(gpu).eval()
+    with torch.no_grad():
+        V = net.features(torch.from_numpy(g["x"]).to(gpu))
+    assert rel_inf(V.cpu().numpy(), g["Vfin"]) <= 1e-4
