@@ -10,7 +10,8 @@ What comes from the reference itself (imported from /root/reference, executed un
                                                  SyntheticExperiments/psf.py:62-191, LRA/psf.py:63-250
   * trained weights                              LRA/attention_maps/{pathfinder_epoch27,imdb_epoch138,cifar10_epoch35}.pt
   * the genome model                             Genome_Clf/psf.py:63-240
-  * TrainModel (the training / evaluation loop)  SyntheticExperiments/psf_utils.py:48-137 — called as it is; its
+  * TrainModel / TrainPSF (the training /        SyntheticExperiments/psf_utils.py:48-137, LRA/psf_utils.py:48-128 — called as
+    evaluation loops)                            they are; their
                                                  `.cuda()` calls are made the identity for the run (no GPU here)
   * the stand-alone attention block              attention_block.py:70-178 (imported with an empty
                                                  `torch_geometric` module: line 9 only imports it)
@@ -369,6 +370,62 @@ def gen_training(se, utils):
         torch.Tensor.cuda = real_cuda
 
 
+def gen_training_lra(lra, utils):
+    """The LRA loop: the reference's TrainPSF (LRA/psf_utils.py:48-128) on its LRA PSFNet, ListOps-style — CLS pooling
+    with the CLS token (id vocab_size - 1) prepended as listops_training.py:65-72 does, padding_idx embedding, no
+    residual, dropouts 0 (psf_training_config.py:2-30) — at a small size: N = 1 + 127, n_W = 7, C = 16, 2 epochs x 6 fixed
+    batches of 32, CrossEntropyLoss, Adam(1e-3), seed_everything(42)."""
+    import contextlib
+    import io
+    import re
+    from torch.utils.data import DataLoader
+    cfg = dict(vocab_size=17, embedding_size=32, n_vec=128, n_W=7, Ws=[32, 'GELU'], V=[32, 'GELU'], n_channels_V=16,
+               n_class=10, pooling_type="CLS", head=['linear'], use_cuda=False, use_residuals=False, dropout1_p=0,
+               dropout2_p=0, dropout3_p=0, init_embedding_weights=False, use_pos_embedding=True, problem="listops")
+    BATCH, NB, NE, EPOCHS = 32, 6, 2, 2
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        utils.seed_everything(42)
+        net = lra.PSFNet(**cfg)
+        sd0 = state_arrays(net)
+        optimizer = torch.optim.Adam(net.parameters(), lr=0.001)
+        loss = RecordingLoss(torch.nn.CrossEntropyLoss())
+        g = torch.Generator().manual_seed(2025)
+
+        def split(n):
+            data = torch.randint(0, 15, (n, 127), generator=g)
+            labels = torch.randint(0, 10, (n,), generator=g)
+            cls_token = torch.tensor([[cfg['vocab_size'] - 1] * data.size(0)]).T  # listops_training.py:65-72
+            return data, torch.cat([cls_token, data], -1), labels
+
+        (raw_tr, Xtr, Ytr), (raw_va, Xva, Yva), (raw_te, Xte, Yte) = split(BATCH * NB), split(BATCH * NE), split(BATCH * NE)
+        mk = lambda X, Y: DataLoader(utils.DatasetCreator(X, Y), batch_size=BATCH, shuffle=False, drop_last=True,  # noqa: E731
+                                     num_workers=0)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+            utils.TrainPSF(net=net, trainloader=mk(Xtr, Ytr), valloader=mk(Xva, Yva), testloader=mk(Xte, Yte),
+                           n_epochs=EPOCHS, test_freq=1, optimizer=optimizer, loss=loss, problem="listops",
+                           saving_criteria=1e9)
+        text = buf.getvalue()
+        num = r"([-+0-9.eE]+)"
+        printed = {key: [float(x) for x in re.findall(pat + num, text)]
+                   for key, pat in (("train_loss", r"Training loss:\s+"), ("val_loss", r"Val  loss: "),
+                                    ("test_loss", r"Test loss: "), ("val_acc", r"Val  accuracy: "),
+                                    ("test_acc", r"Test accuracy: "))}
+        per_epoch = NB + 2 * NE
+        assert len(loss.values) == EPOCHS * per_epoch and all(len(v) == EPOCHS for v in printed.values())
+        vals = np.asarray(loss.values, dtype=np.float64).reshape(EPOCHS, per_epoch)
+        u8 = lambda t: t.numpy().astype(np.uint8)  # noqa: E731
+        save("train_lra_listops_n128.npz", raw_tr=u8(raw_tr), Ytr=u8(Ytr), raw_va=u8(raw_va), Yva=u8(Yva), raw_te=u8(raw_te),
+             Yte=u8(Yte), step_loss=vals[:, :NB].copy(), val_batch_loss=vals[:, NB:NB + NE].copy(),
+             test_batch_loss=vals[:, NB + NE:].copy(), **{"printed_" + k: np.asarray(v) for k, v in printed.items()},
+             **sd0, **{"final::" + k[4:]: v for k, v in state_arrays(net).items()})
+        print(f"  listops-style: step losses epoch0 {vals[0, :3]} ... printed {printed}")
+    finally:
+        torch.Tensor.cuda = real_cuda
+
+
 # ---------------------------------------------------------------------------------------------------
 # 4. attention_block.py
 # ---------------------------------------------------------------------------------------------------
@@ -423,6 +480,7 @@ def main():
     gen_synthetic(se)
     gen_lra(lra)
     gen_training(se, import_reference("ref_se_psf_utils", "SyntheticExperiments/psf_utils.py"))
+    gen_training_lra(lra, import_reference("ref_lra_psf_utils", "LRA/psf_utils.py"))
     gen_attention_block()
     gen_genome(import_reference("ref_genome_psf", "Genome_Clf/psf.py"))
 
