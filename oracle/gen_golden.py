@@ -10,6 +10,7 @@ What comes from the reference itself (imported from /root/reference, executed un
                                                  SyntheticExperiments/psf.py:62-191, LRA/psf.py:63-250
   * trained weights                              LRA/attention_maps/{pathfinder_epoch27,imdb_epoch138,cifar10_epoch35}.pt
   * the genome model                             Genome_Clf/psf.py:63-240
+  * the Adding / Temporal-Order data generators  SyntheticExperiments/synth_data_generation.py:8-70
   * TrainModel / TrainPSF (the training /        SyntheticExperiments/psf_utils.py:48-137, LRA/psf_utils.py:48-128 — called as
     evaluation loops)                            they are; their
                                                  `.cuda()` calls are made the identity for the run (no GPU here)
@@ -471,6 +472,24 @@ def gen_genome(gen):
          **state_arrays(net))
 
 
+# ---------------------------------------------------------------------------------------------------
+# 6. the reference's data generators
+# ---------------------------------------------------------------------------------------------------
+def gen_synth_data(gen):
+    """adding() and temporal_order() of SyntheticExperiments/synth_data_generation.py:8-70, run as they are (seeded):
+    samples of the distributions the on-device generators must match, and the reference's own labels for them."""
+    import contextlib
+    import io
+    import random
+    random.seed(42)
+    torch.manual_seed(42)
+    with contextlib.redirect_stderr(io.StringIO()):  # tqdm
+        xa, ya = gen.adding(512, 64)
+        xo, yo = gen.temporal_order(2048, 32)
+    save("synth_data_reference_samples.npz", adding_data=xa.numpy(), adding_labels=ya.numpy(),
+         order_data=xo.numpy().astype(np.uint8), order_labels=yo.numpy().astype(np.uint8))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # deterministic CPU reductions
@@ -482,6 +501,7 @@ def main():
     gen_training(se, import_reference("ref_se_psf_utils", "SyntheticExperiments/psf_utils.py"))
     gen_training_lra(lra, import_reference("ref_lra_psf_utils", "LRA/psf_utils.py"))
     gen_attention_block()
+    gen_synth_data(import_reference("ref_synth_data_generation", "SyntheticExperiments/synth_data_generation.py"))
     gen_genome(import_reference("ref_genome_psf", "Genome_Clf/psf.py"))
 
 

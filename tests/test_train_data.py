@@ -175,3 +175,64 @@ def test_make_adam_is_plain_adam_on_cpu():
     lin = torch.nn.Linear(3, 2)
     opt = make_adam(lin.parameters(), 0.01)
     assert isinstance(opt, torch.optim.Adam) and opt.defaults["lr"] == 0.01 and not opt.defaults.get("fused")
+
+
+def _golden_samples():
+    import numpy as np
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synth_data_reference_samples.npz")
+    return np.load(path)
+
+
+def test_label_rules_reproduce_the_reference_generators_labels():
+    """Samples drawn by the REFERENCE's adding() / temporal_order() (synth_data_generation.py:8-70, run by
+    oracle/gen_golden.py): the label rules this package's generators use — 0.5 + (x1 + x2) / 4 and
+    2 [first == Y] + [second == Y] — give the reference's labels on the reference's data, exactly."""
+    g = _golden_samples()
+    xa, ya = torch.from_numpy(g["adding_data"]), torch.from_numpy(g["adding_labels"])
+    x, y = xa[..., 0], xa[..., 1]
+    assert torch.all((y == 0) | (y == 1)) and torch.all(y.sum(1) == 2)
+    pos = y.argsort(dim=1, descending=True, stable=True)[:, :2].sort(dim=1).values
+    x1, x2 = x.gather(1, pos[:, :1]).squeeze(1), x.gather(1, pos[:, 1:]).squeeze(1)
+    assert torch.equal(0.5 + (x1 + x2) / 4, ya)
+    xo, yo = torch.from_numpy(g["order_data"].astype("int64"))[..., 0], torch.from_numpy(g["order_labels"].astype("int64"))
+    special = xo >= 4
+    assert torch.all(special.sum(1) == 2)
+    idx = special.float().argsort(dim=1, descending=True, stable=True)[:, :2].sort(dim=1).values
+    v1, v2 = xo.gather(1, idx[:, :1]).squeeze(1), xo.gather(1, idx[:, 1:]).squeeze(1)
+    assert torch.equal(2 * (v1 == 5).long() + (v2 == 5).long(), yo)
+
+
+@pytest.mark.parametrize("where", DEVICES)
+def test_generators_match_the_reference_samples_in_distribution(request, where):
+    """Two-sample comparison of this package's generators (CPU and GPU) with the reference's own output: value range
+    and mean, marker-gap and first-marker statistics, token and class frequencies."""
+    dev = _device(request, where)
+    g = _golden_samples()
+    gen = torch.Generator(device=dev).manual_seed(11)
+    # Adding, N = 64
+    ref = torch.from_numpy(g["adding_data"])
+    mine, labels = synth_data.adding(4096, 64, device=dev, generator=gen)
+    mine, labels = mine.cpu(), labels.cpu()
+    assert float(mine[..., 0].min()) >= -1 and float(mine[..., 0].max()) <= 1
+    assert abs(float(mine[..., 0].mean()) - float(ref[..., 0].mean())) < 0.02
+    assert abs(float(mine[..., 0].std()) - float(ref[..., 0].std())) < 0.02
+
+    def marker_stats(data):
+        pos = data[..., 1].argsort(dim=1, descending=True, stable=True)[:, :2].sort(dim=1).values.float()
+        return pos[:, 0].mean(), pos[:, 1].mean(), (pos[:, 1] - pos[:, 0]).mean()
+    for a, b in zip(marker_stats(mine), marker_stats(ref)):  # uniform unordered pair on 64: means 20.3 / 42.7 / 21.7
+        assert abs(float(a) - float(b)) < 2.5  # the reference sample has 512 sequences: sigma of its means ~0.65
+    assert abs(float(labels.mean()) - float(torch.from_numpy(g["adding_labels"]).mean())) < 0.03
+    # Temporal order, N = 32
+    ref_o = torch.from_numpy(g["order_data"].astype("int64"))[..., 0]
+    ref_y = torch.from_numpy(g["order_labels"].astype("int64"))
+    mine_o, mine_y = synth_data.temporal_order(8192, 32, device=dev, generator=gen)
+    mine_o, mine_y = mine_o.cpu()[..., 0], mine_y.cpu()
+    f_ref = torch.bincount(ref_o.flatten(), minlength=6).float() / ref_o.numel()
+    f_mine = torch.bincount(mine_o.flatten(), minlength=6).float() / mine_o.numel()
+    assert torch.all((f_ref - f_mine).abs() < 0.01)
+    c_ref = torch.bincount(ref_y, minlength=4).float() / ref_y.numel()
+    c_mine = torch.bincount(mine_y, minlength=4).float() / mine_y.numel()
+    assert torch.all((c_ref - c_mine).abs() < 0.04)
+    first = lambda x: (x >= 4).float().argmax(1).float().mean()  # noqa: E731
+    assert abs(float(first(ref_o)) - float(first(mine_o))) < 1.0
