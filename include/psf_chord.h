@@ -192,6 +192,19 @@ int psf_linear_wgrad_strided_f32(const float* X, int64_t ldx, const float* dY, i
 int psf_sum_tensors_f32(const float* const* srcs, int32_t count, int64_t n, float* out, void* stream);
 
 /*
+ * One Adam step over `count` tensors (the optimizer of the reference's training loop, optim.Adam(net.parameters(), lr),
+ * SyntheticExperiments/psf_training.py:50-53; no weight decay, no amsgrad):
+ *     m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;  p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ *   host tables of `count` device pointers (params, grads, exp_avg, exp_avg_sq) and element counts; every pointer 4-byte
+ *   aligned (16-byte alignment and counts that are multiples of 4 take the vector path). `step` = t >= 1 from the host,
+ *   or, when `step_dev` is non-NULL, t is read from that device float (a captured step must see it advance). 4096
+ *   elements per workgroup: the two 524 288-element tensors of a PSFNet at N = 16384 spread over 256 workgroups.
+ */
+int psf_adam_step_f32(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                      const int64_t* numels, int32_t count, float lr, float beta1, float beta2, float eps, float step,
+                      const float* step_dev, void* stream);
+
+/*
  * Token embedding fused with the positional-embedding add — the first two lines of PSFNet.forward
  * (SyntheticExperiments/psf.py:152-163, LRA/psf.py:203-214):
  *     out[t,:] = table[idx[t],:] (+ pos[t mod N,:])        t < T = B*N

@@ -42,6 +42,8 @@ SIGNATURES = {
     "psf_linear_wgrad_workspace": ([c_i64, c_i32, c_i32], c_i64),
     "psf_linear_wgrad_f32": ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp], ctypes.c_int),
     "psf_linear_wgrad_strided_f32": ([c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp], ctypes.c_int),
+    "psf_adam_step_f32": ([ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), _I64P, c_i32,
+                           ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_vp, c_vp], ctypes.c_int),
     "psf_sum_tensors_f32": ([ctypes.POINTER(c_vp), c_i32, c_i64, c_vp, c_vp], ctypes.c_int),
     "psf_embed_tokens_f32": ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp], ctypes.c_int),
     "psf_embed_tokens_bwd_workspace": ([c_i64, c_i32, c_i32], c_i64),

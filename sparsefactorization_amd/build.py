@@ -28,7 +28,7 @@ HEADERS = ["psf_common.h", "fwd_kernels.h", "fwd_window.h", "fwd_window_launch.h
            "bwd_window.h", "bwd_dw_chunk.h", "bwd_window_launch.h", "fwd_chain_lds.h", "fwd_chain_lds_launch.h", "mlp_fwd_x3.h", "mlp_x3_common.h",
            os.path.join("..", "..", "include", "psf_chord.h")]
 SOURCES = ["psf_chord.hip", "fwd_window_inst.hip", "bwd_window_inst.hip", "linear_wgrad.hip",
-           "fwd_chain_lds_inst.hip", "embed.hip", "flat_head.hip", "sum_tensors.hip", "mlp_fwd.hip", "mlp_fwd_x3.hip", "mlp_bwd.hip"]
+           "fwd_chain_lds_inst.hip", "embed.hip", "flat_head.hip", "sum_tensors.hip", "adam.hip", "mlp_fwd.hip", "mlp_fwd_x3.hip", "mlp_bwd.hip"]
 
 # -ffp-contract=off: products and sums stay separate roundings (bitwise parity with the CPU oracle).
 HIPCC_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
@@ -65,6 +65,7 @@ def _units():
              (os.path.join(OBJ_DIR, "embed.o"), os.path.join(CSRC, "embed.hip"), []),
              (os.path.join(OBJ_DIR, "flat_head.o"), os.path.join(CSRC, "flat_head.hip"), []),
              (os.path.join(OBJ_DIR, "sum_tensors.o"), os.path.join(CSRC, "sum_tensors.hip"), []),
+             (os.path.join(OBJ_DIR, "adam.o"), os.path.join(CSRC, "adam.hip"), []),
              (os.path.join(OBJ_DIR, "mlp_fwd.o"), os.path.join(CSRC, "mlp_fwd.hip"), []),
              (os.path.join(OBJ_DIR, "mlp_fwd_x3.o"), os.path.join(CSRC, "mlp_fwd_x3.hip"), []),
              (os.path.join(OBJ_DIR, "mlp_bwd.o"), os.path.join(CSRC, "mlp_bwd.hip"), [])]

@@ -78,15 +78,90 @@ class DeviceBatches:
                 yield self.data[lo:hi], self.labels[lo:hi]
 
 
-def make_adam(params, lr: float, capturable: bool = False) -> torch.optim.Adam:
-    """``optim.Adam(net.parameters(), lr=...)`` of psf_training.py:50 / listops_training.py:84. On the GPU the
-    single-kernel (``fused=True``) implementation of the same update: the per-tensor foreach version spends 0.6 ms of
-    host time per step on a PSFNet's ~60 small parameters. ``capturable``: step counters live on the device, so the
-    step can be captured in a HIP graph (``GraphedStep``)."""
+class ChunkedAdam(torch.optim.Optimizer):
+    """``torch.optim.Adam(params, lr, betas, eps)`` (no weight decay / amsgrad / maximize) on ``psf_adam_step_f32``
+    (csrc/adam.hip): one launch per <= 40 parameters with 4096-element chunks per workgroup. PyTorch's fused multi-tensor
+    Adam gives a workgroup 65 536 elements, which runs the two 524 288-element parameters of a PSFNet at N = 16384
+    (``pos_embedding``, ``final``) on 16 workgroups: 2 x 43 us per step against ~2 x 5 here.
+
+    State per parameter under torch's Adam's names (``step``, ``exp_avg``, ``exp_avg_sq``; ``step`` is a host float, or with
+    ``capturable`` the shared device scalar). ``capturable``: ONE device scalar counts the steps for all parameters (advanced by a one-element kernel, read by the update kernel), so a
+    captured step can be replayed; parameters whose ``.grad`` is None are skipped, as in torch."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, capturable: bool = False):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, capturable=capturable))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        import ctypes
+        from . import _lib
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for group in self.param_groups:
+            live = [p for p in group["params"] if p.grad is not None]
+            if not live:
+                continue
+            dev = live[0].device
+            cap = group["capturable"]
+            if cap and "_step_dev" not in group:
+                group["_step_dev"] = torch.zeros((), dtype=torch.float32, device=dev)
+            # host-side plan (pointer tables of the parameters and their moments), rebuilt only when the set of
+            # parameters with a gradient changes: the small LRA models are launch-bound, every microsecond here counts
+            key = tuple(map(id, live))
+            plan = group.get("_plan")
+            if plan is None or plan[0] != key:
+                for p in live:
+                    st = self.state[p]
+                    if not st:
+                        st["step"] = group["_step_dev"] if cap else 0.0
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                n = len(live)
+                tab = lambda ts: (ctypes.c_void_p * n)(*[x.data_ptr() for x in ts])  # noqa: E731
+                plan = (key, tab(live), tab([self.state[p]["exp_avg"] for p in live]),
+                        tab([self.state[p]["exp_avg_sq"] for p in live]), (ctypes.c_int64 * n)(*[p.numel() for p in live]),
+                        [self.state[p] for p in live])
+                group["_plan"] = plan
+            _, ptab, mtab, vtab, sizes, states = plan
+            n = len(live)
+            gtab = (ctypes.c_void_p * n)(*[(p.grad if p.grad.is_contiguous() else p.grad.contiguous()).data_ptr() for p in live])
+            b1, b2 = group["betas"]
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            with torch.cuda.device(dev):
+                if cap:
+                    group["_step_dev"].add_(1.0)
+                    rc = lib.psf_adam_step_f32(ptab, gtab, mtab, vtab, sizes, n, group["lr"], b1, b2, group["eps"], 1.0,
+                                               group["_step_dev"].data_ptr(), stream)
+                else:
+                    t0 = states[0]["step"] + 1.0
+                    uniform = True
+                    for st in states:
+                        st["step"] += 1.0
+                        uniform = uniform and st["step"] == t0
+                    if uniform:
+                        rc = lib.psf_adam_step_f32(ptab, gtab, mtab, vtab, sizes, n, group["lr"], b1, b2, group["eps"], t0,
+                                                   None, stream)
+                    else:  # parameters that skipped steps (grad None) have their own count: one call per tensor
+                        rc = 0
+                        for i, st in enumerate(states):
+                            one = lambda tb: (ctypes.c_void_p * 1)(tb[i])  # noqa: E731
+                            rc = rc or lib.psf_adam_step_f32(one(ptab), one(gtab), one(mtab), one(vtab),
+                                                             (ctypes.c_int64 * 1)(sizes[i]), 1, group["lr"], b1, b2,
+                                                             group["eps"], st["step"], None, stream)
+            _lib.check(rc, "psf_adam_step_f32")
+        return loss
+
+
+def make_adam(params, lr: float, capturable: bool = False) -> torch.optim.Optimizer:
+    """``optim.Adam(net.parameters(), lr=...)`` of psf_training.py:50 / listops_training.py:84. On the GPU (contiguous
+    fp32 parameters) the same update on ``ChunkedAdam``; otherwise torch's own Adam. ``capturable``: the step counter
+    lives on the device, so the step can be captured in a HIP graph (``GraphedStep``)."""
     params = list(params)
-    fused = all(p.is_cuda and p.is_floating_point() for p in params)
-    if fused:
-        return torch.optim.Adam(params, lr=lr, fused=True, capturable=capturable)
+    if params and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params):
+        return ChunkedAdam(params, lr=lr, capturable=capturable)
     return torch.optim.Adam(params, lr=lr)
 
 
@@ -198,9 +273,11 @@ class GraphedStep:
                 t.copy_(s0)
             for p, st in optimizer.state.items():
                 before = opt_before.get(id(p), {})
-                for k, v in st.items():
+                for k, v in list(st.items()):
                     if torch.is_tensor(v):
                         v.copy_(before[k]) if k in before else v.zero_()
+                    elif k == "step":  # a host-side step count (ChunkedAdam, not capturable)
+                        st[k] = before.get(k, 0.0)
 
     def _step(self, zero: bool = True, eager_tail: bool = True):
         if zero:
