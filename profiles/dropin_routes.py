@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""The three drop-in routes of INTEGRATION.md, timed end to end from Python (host launch overhead included), forward
+"""The drop-in routes of INTEGRATION.md, timed end to end from Python (host launch overhead included), forward
 only, no autograd:
   route 1  the reference's loop unchanged: V = spmm(index, W.reshape(B, N*L), N, N, V); V = V + res   (one library call +
            one PyTorch add per step)
   route 2  V = chord_spmm(W, V, residual=res) per step (residual fused, no index tensor)
   route 3  chord_chain(W_list, V0, use_residual)  (one library call for the whole loop; one launch when N <= 2048)
+  route 1L the loop of route 1, unchanged, with `from sparsefactorization_amd.lazy import spmm`: recorded and run as route 3
 Also under HIP-graph replay (the per-call host cost disappears; what remains is device time).
 
     python profiles/dropin_routes.py
@@ -55,7 +56,7 @@ def graphed(fn):
 
 def main():
     dev = torch.device("cuda:0")
-    print(f"{'shape':26s} {'route 1 spmm+add':>18s} {'route 2 chord_spmm':>19s} {'route 3 chord_chain':>20s}   (us per forward chain; eager | graph replay)")
+    print(f"{'shape':26s} {'route 1 spmm+add':>18s} {'route 2 chord_spmm':>19s} {'route 3 chord_chain':>20s} {'route 1L lazy.spmm':>19s}   (us per forward chain; eager | graph replay)")
     for name, (B, N, M, C, res) in SHAPES.items():
         L = M + 1
         g = torch.Generator(device=dev).manual_seed(0)
@@ -71,6 +72,16 @@ def main():
                     V = V + V0
             return V
 
+        from sparsefactorization_amd import lazy
+
+        def route1_lazy():
+            V = V0
+            for W in Ws:
+                V = lazy.spmm(index, W.reshape(B, N * L), N, N, V)
+                if res:
+                    V = V + V0
+            return V.contiguous()  # first use of the values: the recorded chain runs
+
         def route2():
             V = V0
             for W in Ws:
@@ -82,11 +93,11 @@ def main():
 
         with torch.no_grad():
             a, b, c = route1(), route2(), route3()
-            assert torch.equal(b, c)
+            assert torch.equal(b, c) and torch.equal(route1_lazy(), c)
             assert torch.allclose(a, c, rtol=1e-5, atol=1e-5 * float(c.abs().max()))
             iters = 200 if N <= 4097 else 50
             import statistics
-            routes = (route1, route2, route3)
+            routes = (route1, route2, route3, route1_lazy)
             samples = [[] for _ in routes]
             for _ in range(5):  # interleaved rounds, median; all eager runs before any capture
                 for i, fn in enumerate(routes):

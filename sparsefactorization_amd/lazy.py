@@ -1,0 +1,133 @@
+"""``lazy.spmm`` — the one-line drop-in for ``torch_sparse.spmm`` that still gets the whole-chain kernels.
+
+The reference's hot loop (SyntheticExperiments/psf.py:172-188 and its copies) makes one ``spmm`` call and one residual
+add per factor::
+
+    for m in range(self.n_W):
+        W = self.fs[m](data)
+        V = spmm(self.chord_indicies, W.reshape(W.size(0), W.size(1) * W.size(2)), self.n_vec, self.n_vec, V)
+        if self.use_residuals:
+            V = V + res_conn
+
+With ``from sparsefactorization_amd import spmm`` each call is its own launch (plus one for the add): correct, but
+launch-bound below N ~ 4096 (141 us per forward chain at cfg1 against 22 us for ``chord_chain``). With
+
+    from sparsefactorization_amd.lazy import spmm
+
+the SAME unmodified loop runs as ONE ``chord_chain`` call: ``spmm`` returns a ``LazyChordChain`` — a ``torch.Tensor``
+subclass that only records (W_m, residual?) — a following ``spmm`` on it extends the record, ``V + res_conn`` with
+``res_conn`` the tensor the chain started from marks the last step's fused residual, and the first operation that
+needs values (``V.view``, ``dropout``, ``V[:, 0, :]``, ``final(...)``, ``print`` ...) runs the recorded chain through
+``chord_chain`` (autograd node included) and continues on the result. Shape / dtype / device queries do not trigger it.
+
+Deferred evaluation reads W_m and the start tensor when the chain runs, not when ``spmm`` was called: do not modify
+them in place in between (the reference loop creates a fresh W per factor and never does).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch.utils._pytree import tree_map
+
+from .chord import chord_chain, chord_spmm, offsets_from_index
+
+__all__ = ["spmm", "LazyChordChain"]
+
+_ADD_FUNCS = {torch.add, torch.Tensor.add, torch.Tensor.__add__, torch.Tensor.__radd__, torch.Tensor.__iadd__,
+              torch.Tensor.add_}
+_METADATA_METHODS = {"size", "dim", "ndimension", "numel", "nelement", "is_floating_point", "is_complex", "element_size",
+                     "stride", "is_contiguous", "get_device", "type"}
+
+
+def _same_tensor(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return a is b or (isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and not isinstance(a, LazyChordChain)
+                      and not isinstance(b, LazyChordChain) and a.dtype == b.dtype and a.device == b.device
+                      and a.shape == b.shape and a.stride() == b.stride() and a.data_ptr() == b.data_ptr()
+                      and a._version == b._version)
+
+
+class LazyChordChain(torch.Tensor):
+    """A recorded, not yet executed chain ``X <- W_m (.) X (+ X_0)``; see the module docstring."""
+
+    @staticmethod
+    def __new__(cls, base, steps, offsets, grad_mode, shape):
+        r = torch.Tensor._make_wrapper_subclass(cls, shape, dtype=steps[0][0].dtype, device=steps[0][0].device,
+                                                requires_grad=False)
+        r._lc_start, r._lc_steps, r._lc_offsets, r._lc_grad_mode, r._lc_value = base, steps, offsets, grad_mode, None
+        # plain-Python copies of the metadata the recording code looks at: every attribute read on the tensor itself
+        # (r.shape, r.dtype, ...) is a __torch_function__ round trip of ~2.5 us, fifty of them per 7-step loop otherwise
+        r._lc_shape, r._lc_dtype, r._lc_device = tuple(shape), steps[0][0].dtype, steps[0][0].device
+        return r
+
+    # ---- evaluation -------------------------------------------------------------------------------------------
+    def materialize(self) -> torch.Tensor:
+        """Run the recorded chain (once) and return the real tensor."""
+        if self._lc_value is None:
+            Ws = [w for w, _ in self._lc_steps]
+            flags = [r for _, r in self._lc_steps]
+            with torch.set_grad_enabled(self._lc_grad_mode):
+                if all(flags) or not any(flags):
+                    out = chord_chain(Ws, self._lc_start, flags[0], self._lc_offsets)
+                else:  # a residual on some steps only: one fused step each (the residual is always the start tensor)
+                    out = self._lc_start
+                    for w, r in self._lc_steps:
+                        out = chord_spmm(w, out, self._lc_start if r else None, self._lc_offsets)
+            if tuple(out.shape) != self._lc_shape:
+                out = out.reshape(self._lc_shape)
+            self._lc_value = out
+        return self._lc_value
+
+    # ---- recording --------------------------------------------------------------------------------------------
+    def _extended(self, W: torch.Tensor) -> "LazyChordChain":
+        return LazyChordChain(self._lc_start, self._lc_steps + [(W, False)], self._lc_offsets, self._lc_grad_mode, self._lc_shape)
+
+    def _with_residual(self) -> "LazyChordChain":
+        steps = self._lc_steps[:-1] + [(self._lc_steps[-1][0], True)]
+        return LazyChordChain(self._lc_start, steps, self._lc_offsets, self._lc_grad_mode, self._lc_shape)
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):  # never reached: __torch_function__ materializes first
+        raise RuntimeError(f"LazyChordChain reached the dispatcher unmaterialized ({func})")
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", "")
+        if name == "__get__" or name in _METADATA_METHODS:  # shape, dtype, device, requires_grad, size(), dim(), ...
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        if func in _ADD_FUNCS and len(args) == 2 and not kwargs:  # V + res_conn: fuse into the last step
+            a, b = args
+            lazy, other = (a, b) if isinstance(a, LazyChordChain) else (b, a)
+            if (isinstance(lazy, LazyChordChain) and not isinstance(other, LazyChordChain) and lazy._lc_value is None
+                    and not lazy._lc_steps[-1][1] and isinstance(other, torch.Tensor) and _same_tensor(other, lazy._lc_start)
+                    and tuple(lazy._lc_start.shape) == lazy._lc_shape):
+                return lazy._with_residual()
+        real = lambda x: x.materialize() if isinstance(x, LazyChordChain) else x  # noqa: E731
+        return func(*tree_map(real, args), **tree_map(real, kwargs))
+
+
+def spmm(index: torch.Tensor, value: torch.Tensor, m: int, n: int, matrix: torch.Tensor) -> torch.Tensor:
+    """``torch_sparse.spmm(index, value, m, n, matrix)`` on chord-structured index lists, evaluated lazily (module
+    docstring). Same arguments and result values as ``sparsefactorization_amd.spmm``."""
+    if m != n:
+        raise ValueError(f"chord spmm is square: m={m} != n={n}")
+    offsets = offsets_from_index(index, m)
+    L = len(offsets)
+    if value.dim() != 2 or value.shape[1] != m * L:  # unbatched value etc.: nothing to chain, use the eager operator
+        from .chord import spmm as eager_spmm
+        real = matrix.materialize() if isinstance(matrix, LazyChordChain) else matrix
+        return eager_spmm(index, value, m, n, real)
+    W = value.reshape(value.shape[0], m, L)
+    B = W.shape[0]
+    if isinstance(matrix, LazyChordChain) and matrix._lc_value is None and matrix._lc_offsets == offsets \
+            and matrix._lc_shape[0] == B and matrix._lc_shape[1] == m and W.dtype == matrix._lc_dtype \
+            and W.device == matrix._lc_device:
+        return matrix._extended(W)
+    base = matrix.materialize() if isinstance(matrix, LazyChordChain) else matrix
+    if base.dim() not in (2, 3) or base.shape[-2] != m or base.dtype != W.dtype or base.device != W.device:
+        from .chord import spmm as eager_spmm
+        return eager_spmm(index, value, m, n, base)  # raises the operator's own shape / dtype errors
+    shape = (B, m, base.shape[-1])
+    return LazyChordChain(base, [(W, False)], offsets, torch.is_grad_enabled(), shape)
