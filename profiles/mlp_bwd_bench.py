@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Fused producer-MLP backward (csrc/mlp_bwd.hip): the all-f32-MFMA kernel (mlp_bwd_variant=1) vs the split-bf16 kernel
-(0: steps 1, 2, 6 on the bf16 matrix pipe), interleaved in one process, at the Temporal-Order training shape
+"""Fused producer-MLP backward (csrc/mlp_bwd.hip): the all-f32-MFMA kernel (mlp_bwd_variant=1) vs the split-bf16 kernels
+(3: steps 1, 2, 6 on the bf16 matrix pipe; 5: all steps, operands on dual-use LDS planes), interleaved in one process, at the Temporal-Order training shape
 (E = h = 32, g with 8 outputs + 14 link MLPs with 15, T = B*N tokens) and at the Pathfinder shape (E = 32, h = 128).
 Gradients of both variants are compared with float64 autograd through nn modules on a slice of the tokens.
 
@@ -17,6 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import sparsefactorization_amd as sfa  # noqa: E402
 from sparsefactorization_amd import fused_mlp  # noqa: E402
+
+
+LABELS = {0: "auto", 1: "f32-MFMA", 2: "split-bf16 all steps (re-split)", 3: "split-bf16 steps 1,2,6",
+          4: "split-bf16 steps 1,2,6, 4 waves x 2 workgroups/CU", 5: "split-bf16 on dual-use planes"}
 
 
 def make(E, h, outs, dev, seed=0):
@@ -50,6 +54,8 @@ def main():
     ap.add_argument("--tokens", type=int, default=40 * 16384)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--variants", type=int, nargs="+", default=[1, 3, 5, 0],
+                    help="mlp_bwd_variant values to interleave; speed-ups are relative to the first")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for name, E, h, outs, T in (("order_n16384_b40", 32, 32, [8] + [15] * 14, args.tokens),
@@ -62,7 +68,7 @@ def main():
         n = 4096
         dx_ref, gp_ref = reference(x[:n], params, [gy[:n] for gy in gys])
         errs = {}
-        VAR = (1, 0, 4)  # f32 MFMA | auto | split-bf16 on 256-thread workgroups, two per CU
+        VAR = tuple(args.variants)
         for v in VAR:
             sfa.set_tuning("mlp_bwd_variant", v)
             dX, grads = fused_mlp._backward_raw(x[:n].contiguous(), params, [gy[:n].contiguous() for gy in gys], True)
@@ -84,10 +90,10 @@ def main():
                 if r:
                     times[v].append(e0.elapsed_time(e1) / args.iters)
         sfa.set_tuning("mlp_bwd_variant", 0)
-        t1, t0, t3 = (statistics.median(times[v]) for v in VAR)
-        print(f"{name}: T={T} E={E} h={h} K={len(outs)}  f32-MFMA {t1:.3f} ms (max rel err {errs[1]:.2e})   "
-              f"auto {t0:.3f} ms (err {errs[0]:.2e}, {t1 / t0:.2f}x)   split-bf16, 4 waves x 2 workgroups/CU {t3:.3f} ms "
-              f"(err {errs[4]:.2e}, {t1 / t3:.2f}x)", flush=True)
+        med = {v: statistics.median(times[v]) for v in VAR}
+        base = med[VAR[0]]
+        print(f"{name}: T={T} E={E} h={h} K={len(outs)}   " + "   ".join(
+            f"{LABELS.get(v, v)} {med[v]:.3f} ms (max rel err {errs[v]:.2e}, {base / med[v]:.2f}x)" for v in VAR), flush=True)
 
 
 if __name__ == "__main__":

@@ -25,7 +25,7 @@ ARCH = "gfx950"
 WIN_TGS = list(range(7))
 
 HEADERS = ["psf_common.h", "fwd_kernels.h", "fwd_window.h", "fwd_window_launch.h", "bwd_kernels.h",
-           "bwd_window.h", "bwd_dw_chunk.h", "bwd_window_launch.h", "fwd_chain_lds.h", "fwd_chain_lds_launch.h", "mlp_fwd_x3.h", "mlp_x3_common.h",
+           "bwd_window.h", "bwd_dw_chunk.h", "bwd_window_launch.h", "fwd_chain_lds.h", "fwd_chain_lds_launch.h", "mlp_fwd_x3.h", "mlp_x3_common.h", "mlp_planes.h",
            os.path.join("..", "..", "include", "psf_chord.h")]
 SOURCES = ["psf_chord.hip", "fwd_window_inst.hip", "bwd_window_inst.hip", "linear_wgrad.hip",
            "fwd_chain_lds_inst.hip", "embed.hip", "flat_head.hip", "sum_tensors.hip", "adam.hip", "mlp_fwd.hip", "mlp_fwd_x3.hip", "mlp_bwd.hip"]

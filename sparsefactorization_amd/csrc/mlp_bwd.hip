@@ -48,6 +48,7 @@
 #include <atomic>
 
 #include "../../include/psf_chord.h"
+#include "mlp_planes.h"
 #include "mlp_x3_common.h"
 
 extern "C" int psf_internal_fail(int code, const char* message);
@@ -766,6 +767,349 @@ mlp_bwd_x3_k(const BwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// split-bf16 variant on dual-use LDS planes (mlp_planes.h): ALL five GEMMs on the bf16 pipe, every operand split ONCE
+// ------------------------------------------------------------------------------------------------------------------
+// What mlp_bwd_x3_k pays for the two contractions over tokens (steps 4, 5) is a second split of dY, G and X in the
+// transposed orientation — or, as built, the f32 instruction that shares the VALU's datapath. Here every activation is
+// split once, stored as bf16 planes, and the orientation an MFMA needs is chosen by the READ: ds_read_b128 along a row,
+// ds_read_b64_tr_b16 down a column (the hardware transposes 4 x 16 blocks on the way to the registers).
+//   X tile      split at block start into three planes [tok][e] per tile: row read = step-1 B operand, transposed read =
+//               step-5 B operand. No f32 copy of X in LDS, no X fragments held in registers.
+//   dY tile     each lane loads the 8 (16) outputs of ITS token straight from global memory = its step-2 B fragment; the
+//               same split terms go through a [tok][o] scratch plane and come back transposed as the step-4 B operand.
+//   Hpost^T, G  accumulator layout -> split16 -> one ds_write_b64 per four registers into a [tok][j] scratch plane ->
+//               transposed read = step-4 / step-5 A operand. G's packed terms ARE the step-6 B fragments.
+//   A_u         one [j][e] plane per term: row read = step-1 A operand, transposed read in accumulator order = step-6 A
+//               operand (the A^T copy of the x3 image is gone: 12.4 KB per unit image instead of 20 KB).
+// The scratch planes are used one term at a time (write term t, read it back transposed into registers, write term t+1
+// over it: LDS operations of one wave execute in order), so a wave needs 2 x 2 KB of scratch next to its X planes and two
+// tiles per wave x eight waves x two image buffers fit 160 KB.
+// da_u: per-lane sums of G over the wave's tiles, reduced over the 32 token lanes once per unit (DPP); db likewise from
+// the dY registers, in the ht = 0 unit only.
+constexpr int kPOffSa = 3 * psf_x3::kPlaneBytes;       // 6144: sa in accumulator-register order [half][16]
+constexpr int kPOffBT = kPOffSa + 128;                 // 6272: B^T terms as in the x3 image
+constexpr int kPImgBytes = kPOffBT + 3 * kXFragTerm;   // 12416
+constexpr int kPImgVecs = kPImgBytes / 16;             // 776
+constexpr int kPScrBytes = 2 * psf_x3::kPlaneBytes + 512;  // two scratch planes; as f32: combine tile [32][32] | da [2][32] | db [2][32]
+static_assert(kPImgBytes <= kXImgBytes, "the workspace slot per unit is sized for the x3 image");
+
+__global__ void __launch_bounds__(256) mlp_bwd_x3p_pack_k(const BwdArgs a) {
+  using psf_x3::bf16_bits;
+  using psf_x3::plane_off;
+  using psf_x3::split3;
+  const int u = blockIdx.x;
+  const BwdMlp d = a.m[a.unit_k[u]];
+  const int ht = 32 * a.unit_hb[u], E = a.E;
+  unsigned char* img = reinterpret_cast<unsigned char*>(a.images) + (size_t)u * kXImgBytes;
+  uint16_t* img16 = reinterpret_cast<uint16_t*>(img);
+  float* img32 = reinterpret_cast<float*>(img);
+  for (int i = threadIdx.x; i < 32 * 32; i += 256) {  // A planes [j][e], swizzled
+    const int j = i >> 5, e = i & 31;
+    const float v = (e < E && ht + j < d.h) ? d.A[(ht + j) * E + e] : 0.f;
+    uint32_t t1, t2, t3;
+    split3(v, t1, t2, t3);
+    const int at = (plane_off(j, e >> 3) >> 1) + (e & 7);
+    img16[at] = bf16_bits(t1);
+    img16[psf_x3::kPlaneBytes / 2 + at] = bf16_bits(t2);
+    img16[psf_x3::kPlaneBytes + at] = bf16_bits(t3);
+  }
+  for (int q = threadIdx.x; q < 32; q += 256) {  // sa[half][r] = a[ht + cd_row(r, half)]
+    const int j = ht + cd_row(q & 15, q >> 4);
+    img32[kPOffSa / 4 + q] = j < d.h ? d.a[j] : 0.f;
+  }
+  for (int q = threadIdx.x; q < 2 * 2 * 32 * 8; q += 256) {  // B^T: [s][half][j = col][i] = B[o = 16 s + 8 half + i][ht + j]
+    const int i = q & 7, col = (q >> 3) & 31, hf = (q >> 8) & 1, s = q >> 9;
+    const int o = 16 * s + 8 * hf + i;
+    const float vb = (o < d.O && ht + col < d.h) ? d.B[o * d.h + ht + col] : 0.f;
+    uint32_t t1, t2, t3;
+    split3(vb, t1, t2, t3);
+    img16[(kPOffBT + 0 * kXFragTerm) / 2 + q] = bf16_bits(t1);
+    img16[(kPOffBT + 1 * kXFragTerm) / 2 + q] = bf16_bits(t2);
+    img16[(kPOffBT + 2 * kXFragTerm) / 2 + q] = bf16_bits(t3);
+  }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 32 lanes of the lane's half of the wave; every lane ends up with the total
+__device__ __forceinline__ float half_sum(float v) {
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror
+  return v + __shfl_xor(v, 16, 64);
+}
+
+// 512 threads, one workgroup per CU (two waves per SIMD, <= 256 registers), two image buffers.
+// NDY: dY values per lane and tile = outputs of one token that one half of the wave covers: 8 (O <= 16) or 16.
+template <int TPW, int NDY>
+__global__ void __launch_bounds__(512, 1)
+mlp_bwd_x3p_k(const BwdArgs a) {
+  using namespace psf_x3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, half = lane >> 5;
+  constexpr int NW = 8;
+  constexpr int NS2 = NDY / 8;  // k-steps of the contraction over outputs (step 2)
+  constexpr int kWaveBytes = TPW * 3 * kPlaneBytes + kPScrBytes;
+  unsigned char* XP = lds_raw + 2 * kPImgBytes + wv * kWaveBytes;  // the wave's X planes [tile][term]
+  unsigned char* HP = XP + TPW * 3 * kPlaneBytes;                  // scratch plane: Hpost^T / G, one term at a time
+  unsigned char* YP = HP + kPlaneBytes;                            // scratch plane: dY, one term at a time
+  float* SCR = reinterpret_cast<float*>(HP);                       // the same bytes for the cross-wave combine
+  const PlaneLane L = plane_lane(lane);
+  const int E = a.E, U = a.U;
+  const int64_t tiles = (a.T + 31) / 32;
+  const int64_t tiles_per_block = NW * TPW;
+  const unsigned char* images = reinterpret_cast<const unsigned char*>(a.images);
+
+  auto stage = [&](int u) {
+    const unsigned char* src = images + (size_t)u * kXImgBytes;
+    unsigned char* dst = lds_raw + (u & 1) * kPImgBytes;
+    for (int v0 = 0; v0 < kPImgVecs; v0 += 64 * NW) {
+      const int v = v0 + tid;
+      if (v < kPImgVecs)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * v),
+                                         (__attribute__((address_space(3))) void*)(dst + 16 * (v0 + (tid & ~63))), 16, 0, 0);
+    }
+  };
+
+  for (int64_t blk = blockIdx.x; blk * tiles_per_block < tiles; blk += gridDim.x) {
+    f32x16 dxa[TPW];
+    int64_t t0[TPW];
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+      t0[tp] = (blk * tiles_per_block + wv * TPW + tp) * 32;
+      const int64_t tok = t0[tp] + c;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int e0 = 16 * s + 8 * half;
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+        if (tok < a.T && e0 < E) lo = *reinterpret_cast<const float4*>(a.X + tok * E + e0);
+        if (tok < a.T && e0 + 4 < E) hi = *reinterpret_cast<const float4*>(a.X + tok * E + e0 + 4);
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const Frag3 f = split_pack8_pk(v);
+        unsigned char* xp = XP + tp * 3 * kPlaneBytes + L.row[s];
+        *reinterpret_cast<bf16x8*>(xp) = f.t1;
+        *reinterpret_cast<bf16x8*>(xp + kPlaneBytes) = f.t2;
+        *reinterpret_cast<bf16x8*>(xp + 2 * kPlaneBytes) = f.t3;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dxa[tp][r] = 0.f;
+    }
+    float* part = a.partials + (blk * (int64_t)U) * kPart;  // one partial slot per workgroup
+    float dyn[NDY];
+    auto dy_fetch = [&](int u2, int64_t t02) {  // the lane's token: outputs 16 s + 8 half + i
+      const BwdMlp& d2 = a.m[a.unit_k[u2]];
+      const int W = d2.O;
+      const int64_t tok = t02 + c;
+      const float* src = d2.dY + tok * W;
+#pragma unroll
+      for (int s = 0; s < NS2; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int o = 16 * s + 8 * half + i;
+          dyn[8 * s + i] = (tok < a.T && o < W) ? src[o] : 0.f;
+        }
+    };
+    dy_fetch(0, t0[0]);
+    __syncthreads();  // the previous block's last unit is done with both image buffers
+    stage(0);
+
+    for (int u = 0; u < U; ++u) {
+      __syncthreads();  // image u has landed (vmcnt is drained before the barrier); unit u-1's combine is finished
+      if (u + 1 < U) stage(u + 1);
+      const unsigned char* img = lds_raw + (u & 1) * kPImgBytes;
+      const bool first_block_of_mlp = a.unit_hb[u] == 0;
+
+      f32x16 dA, dBT;
+      float P[16], dbp[NDY];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dA[r] = dBT[r] = P[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NDY; ++i) dbp[i] = 0.f;
+
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) {
+        // 0. this tile's dY values -> split terms (the lane's step-2 B fragments); start the next tile-unit's loads
+        Frag3 dy3[NS2];
+#pragma unroll
+        for (int s = 0; s < NS2; ++s) {
+          const float v[8] = {dyn[8 * s], dyn[8 * s + 1], dyn[8 * s + 2], dyn[8 * s + 3],
+                              dyn[8 * s + 4], dyn[8 * s + 5], dyn[8 * s + 6], dyn[8 * s + 7]};
+          dy3[s] = split_pack8_pk(v);
+        }
+        if (first_block_of_mlp) {
+#pragma unroll
+          for (int i = 0; i < NDY; ++i) dbp[i] += dyn[i];
+        }
+        if (tp + 1 < TPW)
+          dy_fetch(u, t0[tp + 1 < TPW ? tp + 1 : 0]);
+        else if (u + 1 < U)
+          dy_fetch(u + 1, t0[0]);
+        if (t0[tp] >= a.T) continue;  // wave-uniform
+        const unsigned char* xp = XP + tp * 3 * kPlaneBytes;
+
+        // 1. Hpre^T = A_u X^T + a_u : both operands by row reads
+        f32x16 acc1, acc3;
+        {
+          const float4* sa4 = reinterpret_cast<const float4*>(img + kPOffSa + 64 * half);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = sa4[q];
+            acc1[4 * q] = v.x;
+            acc1[4 * q + 1] = v.y;
+            acc1[4 * q + 2] = v.z;
+            acc1[4 * q + 3] = v.w;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const Frag3 wa{row_frag(img, L, s), row_frag(img + kPlaneBytes, L, s), row_frag(img + 2 * kPlaneBytes, L, s)};
+          const Frag3 xb{row_frag(xp, L, s), row_frag(xp + kPlaneBytes, L, s), row_frag(xp + 2 * kPlaneBytes, L, s)};
+          acc1 = mfma6(wa, xb, acc1);
+        }
+        // 2. dHpost^T = B_u^T dY^T : B operand = the lane's own dY fragment
+#pragma unroll
+        for (int s = 0; s < NS2; ++s)
+          acc3 = mfma6(load_frag3(img + kPOffBT + ((s * 2 + half) * 32 + c) * 16, kXFragTerm), dy3[s], acc3);
+        // 3. GELU and its derivative
+        float y[16], g[16];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          f32x2 yy, dd;
+          gelu_and_grad2(f32x2{acc1[r], acc1[r + 1]}, yy, dd);
+          y[r] = yy.x;
+          y[r + 1] = yy.y;
+          g[r] = acc3[r] * dd.x;  // G = dHpre^T
+          g[r + 1] = acc3[r + 1] * dd.y;
+          P[r] += g[r];
+          P[r + 1] += g[r + 1];
+        }
+        // 4. dB^T[j][o] += Hpost^T[j][tok] dY[tok][o] : both operands by transposed reads of the scratch planes
+        {
+          const Split16 ys = split16(y);
+          Frag3 ha[2], yb[2];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            store_acc_plane(HP, L, ys, t);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              const bf16x8 term = t == 0 ? dy3[s < NS2 ? s : 0].t1 : (t == 1 ? dy3[s < NS2 ? s : 0].t2 : dy3[s < NS2 ? s : 0].t3);
+              const bf16x8 zero = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+              *reinterpret_cast<bf16x8*>(YP + L.row[s]) = s < NS2 ? term : zero;  // outputs >= 16 of a narrow dY read as zero
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              const bf16x8 hf = tr_frag(HP, L, s), yf = tr_frag(YP, L, s);
+              if (t == 0) ha[s].t1 = hf, yb[s].t1 = yf;
+              if (t == 1) ha[s].t2 = hf, yb[s].t2 = yf;
+              if (t == 2) ha[s].t3 = hf, yb[s].t3 = yf;
+            }
+            asm volatile("" ::: "memory");
+          }
+#pragma unroll
+          for (int s = 0; s < 2; ++s) dBT = mfma6(ha[s], yb[s], dBT);
+        }
+        // 5. dA[j][e] += G[j][tok] X[tok][e]   and   6. dX^T[e][tok] += A_u^T[e][j] G[j][tok]
+        {
+          const Split16 gs = split16(g);
+          Frag3 ga[2];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            store_acc_plane(HP, L, gs, t);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              const bf16x8 gf = tr_frag(HP, L, s);
+              if (t == 0) ga[s].t1 = gf;
+              if (t == 1) ga[s].t2 = gf;
+              if (t == 2) ga[s].t3 = gf;
+            }
+            asm volatile("" ::: "memory");
+          }
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const Frag3 xb{tr_frag(xp, L, s), tr_frag(xp + kPlaneBytes, L, s), tr_frag(xp + 2 * kPlaneBytes, L, s)};
+            dA = mfma6(ga[s], xb, dA);
+          }
+          if (a.dX) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              const Frag3 at{tr_frag_acc(img, L, s), tr_frag_acc(img + kPlaneBytes, L, s), tr_frag_acc(img + 2 * kPlaneBytes, L, s)};
+              const Frag3 gb{acc_frag(gs, 0, s), acc_frag(gs, 1, s), acc_frag(gs, 2, s)};
+              dxa[tp] = mfma6(at, gb, dxa[tp]);
+            }
+          }
+        }
+      }
+      // da, db: the per-lane sums over the 32 token lanes of each half
+#pragma unroll
+      for (int r = 0; r < 16; ++r) P[r] = half_sum(P[r]);
+      if (first_block_of_mlp) {
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) dbp[i] = half_sum(dbp[i]);
+      }
+      // Combine the eight waves' partial sums through LDS (fixed order w = 0..7) and flush once per workgroup.
+      float* pu = part + (int64_t)u * kPart;
+      const float* wave0 = reinterpret_cast<const float*>(lds_raw + 2 * kPImgBytes + TPW * 3 * kPlaneBytes);  // wave 0's SCR
+      auto sum8 = [&](int off) {  // off: float offset into a wave's SCR, 16-byte aligned
+        float4 acc = *reinterpret_cast<const float4*>(wave0 + off);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+          const float4 v = *reinterpret_cast<const float4*>(wave0 + w * (kWaveBytes / 4) + off);
+          acc.x += v.x;
+          acc.y += v.y;
+          acc.z += v.z;
+          acc.w += v.w;
+        }
+        return acc;
+      };
+#pragma unroll
+      for (int r = 0; r < 16; ++r) SCR[cd_row(r, half) * 32 + c] = dA[r];
+      SCR[1024 + lane] = 0.f;  // da [2][32]: the whole sum goes to row 0
+      SCR[1088 + lane] = 0.f;  // db [2][32]
+      if (c == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) SCR[1024 + cd_row(r, half)] = P[r];
+#pragma unroll
+        for (int s = 0; s < NS2; ++s)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) SCR[1088 + 16 * s + 8 * half + i] = dbp[8 * s + i];
+      }
+      __syncthreads();
+      if (wv < 4) *reinterpret_cast<float4*>(pu + wv * 256 + 4 * lane) = sum8(wv * 256 + 4 * lane);
+      if (wv == 4 && lane < 32) *reinterpret_cast<float4*>(pu + 2048 + 4 * lane) = sum8(1024 + 4 * lane);
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) SCR[cd_row(r, half) * 32 + c] = dBT[r];
+      __syncthreads();
+      if (wv < 4) *reinterpret_cast<float4*>(pu + 1024 + wv * 256 + 4 * lane) = sum8(wv * 256 + 4 * lane);
+    }
+
+    if (a.dX) {  // the lane holds dX^T[e = 8 g + 4 half + (0..3)][tok = c] in registers 4 g .. 4 g + 3
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) {
+        const int64_t tok = t0[tp] + c;
+        if (tok < a.T) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int e0 = 8 * gq + 4 * half;
+            if (e0 < E)
+              *reinterpret_cast<float4*>(a.dX + tok * E + e0) =
+                  make_float4(dxa[tp][4 * gq], dxa[tp][4 * gq + 1], dxa[tp][4 * gq + 2], dxa[tp][4 * gq + 3]);
+          }
+        }
+      }
+    }
+  }
+}
+
 // stage 1: R1[s][i] = sum over the groups of slice s of P[g][i]   (i < U*kPart; fixed order)
 __global__ void __launch_bounds__(256) mlp_bwd_reduce1_k(const BwdArgs a) {
   const int64_t n = (int64_t)a.U * kPart;
@@ -874,8 +1218,12 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
     args.unit_k[u] = u < p.U ? p.unit_k[u] : 0;
     args.unit_hb[u] = u < p.U ? p.unit_hb[u] : 0;
   }
-  const bool x3 = psf_g_mlp_bwd_variant.load() != 1;  // split-bf16 kernel unless the f32 one is forced
-  const bool four_waves = psf_g_mlp_bwd_variant.load() == 4;  // split-bf16 kernel on 256-thread workgroups, two per CU
+  const int variant = psf_g_mlp_bwd_variant.load();
+  const bool x3 = variant != 1;         // split-bf16 kernels unless the f32 one is forced
+  const bool four_waves = variant == 4;  // split-bf16 kernel on 256-thread workgroups, two per CU
+  const bool planes = variant == 5;      // split-bf16 kernel on dual-use LDS planes
+  if (planes && dX && (reinterpret_cast<uintptr_t>(dX) & 15) != 0)
+    return psf_internal_fail(PSF_E_ALIGN, "psf_mlp_bwd: dX must be 16-byte aligned");
   float* ws = reinterpret_cast<float*>(workspace);
   args.X = X;
   args.dX = dX;
@@ -888,7 +1236,8 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   args.K = K;
   args.U = p.U;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (x3) hipLaunchKernelGGL(mlp_bwd_x3_pack_k, dim3(p.U), dim3(256), 0, s, args);
+  if (planes) hipLaunchKernelGGL(mlp_bwd_x3p_pack_k, dim3(p.U), dim3(256), 0, s, args);
+  else if (x3) hipLaunchKernelGGL(mlp_bwd_x3_pack_k, dim3(p.U), dim3(256), 0, s, args);
   else hipLaunchKernelGGL(mlp_bwd_pack_k, dim3(p.U), dim3(256), 0, s, args);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
@@ -903,7 +1252,20 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
     e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * waves), lds_bytes, s, args);
   };
-  if (x3) {
+  auto launch_planes = [&](auto kernel, int tpw) {
+    const size_t lds_bytes = 2 * (size_t)kPImgBytes + 8 * ((size_t)tpw * 3 * psf_x3::kPlaneBytes + kPScrBytes);
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(512), lds_bytes, s, args);
+  };
+  if (planes) {
+    if (max_o <= 16) {
+      if (p.tpw8 == 2) launch_planes(mlp_bwd_x3p_k<2, 8>, 2);
+      else launch_planes(mlp_bwd_x3p_k<1, 8>, 1);
+    } else {
+      if (p.tpw8 == 2) launch_planes(mlp_bwd_x3p_k<2, 16>, 2);
+      else launch_planes(mlp_bwd_x3p_k<1, 16>, 1);
+    }
+  } else if (x3) {
     const bool full = psf_g_mlp_bwd_variant.load() == 2 || (psf_g_mlp_bwd_variant.load() == 0 && p.tpw8 == 1);
     if (four_waves) {
       if (max_o <= 16) {

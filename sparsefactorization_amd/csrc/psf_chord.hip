@@ -88,7 +88,7 @@ Knob g_knobs[] = {
     {"chain_fused", &g_chain_fused, 0, 1},
     {"chain_cc", &g_chain_cc, 0, 1},
     {"mlp_variant", &psf_g_mlp_variant, 0, 3},
-    {"mlp_bwd_variant", &psf_g_mlp_bwd_variant, 0, 4},
+    {"mlp_bwd_variant", &psf_g_mlp_bwd_variant, 0, 5},
 };
 
 int ceil_log2(int64_t x) {
