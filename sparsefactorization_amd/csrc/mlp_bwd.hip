@@ -103,7 +103,10 @@ struct BwdMlp {
 
 struct BwdArgs {
   BwdMlp m[kMaxMlps];
-  uint8_t unit_k[kMaxUnits], unit_hb[kMaxUnits];  // unit -> (MLP, hidden block)
+  // unit -> MLP | hidden block << 8. Dwords, not bytes: a byte table indexed by the (uniform) unit counter becomes a
+  // global_load_ubyte + s_waitcnt vmcnt(0) — a full memory round trip that also drains every prefetch in flight — where
+  // a dword table is one s_load_dword.
+  uint32_t unit[kMaxUnits];
   const float* X;
   float* dX;        // [T, E] or nullptr
   float* images;    // U images of kImg floats
@@ -146,8 +149,8 @@ __device__ __forceinline__ void gelu_and_grad2(f32x2 x, f32x2& y, f32x2& dydx) {
 
 __global__ void __launch_bounds__(256) mlp_bwd_pack_k(const BwdArgs a) {
   const int u = blockIdx.x;
-  const BwdMlp d = a.m[a.unit_k[u]];
-  const int ht = 32 * a.unit_hb[u], E = a.E;
+  const BwdMlp d = a.m[a.unit[u] & 0xff];
+  const int ht = 32 * (int)(a.unit[u] >> 8), E = a.E;
   float* img = a.images + (int64_t)u * kImg;
   for (int i = threadIdx.x; i < kImg; i += 256) {
     float v = 0.f;
@@ -255,7 +258,7 @@ mlp_bwd_k(const BwdArgs a) {
     // waves per SIMD a load consumed right after its issue exposes the whole memory latency once per tile-unit.
     float dyn[NDY];
     auto dy_fetch = [&](int u2, int64_t t02) {
-      const BwdMlp& d2 = a.m[a.unit_k[u2]];
+      const BwdMlp& d2 = a.m[a.unit[u2] & 0xff];
       const int W = d2.O;
       const int64_t rows_left = a.T - t02;
       const int n = (int)(rows_left >= 32 ? 32 : (rows_left > 0 ? rows_left : 0)) * W;
@@ -297,7 +300,7 @@ mlp_bwd_k(const BwdArgs a) {
       const float* sA = lds + (kImgBufs == 2 ? (u & 1) : 0) * kImg;
       const float* sa = sA + kOffSa;
       const float* sB = sA + kOffSb;
-      const BwdMlp& d = a.m[a.unit_k[u]];
+      const BwdMlp& d = a.m[a.unit[u] & 0xff];
       const int O = d.O;
 
       f32x16 dA, dBT;
@@ -438,8 +441,8 @@ __global__ void __launch_bounds__(256) mlp_bwd_x3_pack_k(const BwdArgs a) {
   using psf_x3::bf16_bits;
   using psf_x3::split3;
   const int u = blockIdx.x;
-  const BwdMlp d = a.m[a.unit_k[u]];
-  const int ht = 32 * a.unit_hb[u], E = a.E;
+  const BwdMlp d = a.m[a.unit[u] & 0xff];
+  const int ht = 32 * (int)(a.unit[u] >> 8), E = a.E;
   unsigned char* img = reinterpret_cast<unsigned char*>(a.images) + (size_t)u * kXImgBytes;
   uint16_t* img16 = reinterpret_cast<uint16_t*>(img);
   float* img32 = reinterpret_cast<float*>(img);
@@ -541,7 +544,7 @@ mlp_bwd_x3_k(const BwdArgs a) {
     float* part = a.partials + (blk * (int64_t)U) * kPart;  // one partial slot per workgroup
     float dyn[NDY];
     auto dy_fetch = [&](int u2, int64_t t02) {
-      const BwdMlp& d2 = a.m[a.unit_k[u2]];
+      const BwdMlp& d2 = a.m[a.unit[u2] & 0xff];
       const int W = d2.O;
       const int64_t rows_left = a.T - t02;
       const int n = (int)(rows_left >= 32 ? 32 : (rows_left > 0 ? rows_left : 0)) * W;
@@ -582,7 +585,7 @@ mlp_bwd_x3_k(const BwdArgs a) {
       }
       const unsigned char* img = lds_raw + (kImgBufs == 2 ? (u & 1) : 0) * kXImgBytes;
       const float* sa = reinterpret_cast<const float*>(img + kXOffSa);
-      const BwdMlp& d = a.m[a.unit_k[u]];
+      const BwdMlp& d = a.m[a.unit[u] & 0xff];
       const int O = d.O;
 
       f32x16 dA, dBT;
@@ -785,8 +788,9 @@ mlp_bwd_x3_k(const BwdArgs a) {
 // The scratch planes are used one term at a time (write term t, read it back transposed into registers, write term t+1
 // over it: LDS operations of one wave execute in order), so a wave needs 2 x 2 KB of scratch next to its X planes and two
 // tiles per wave x eight waves x two image buffers fit 160 KB.
-// da_u: per-lane sums of G over the wave's tiles, reduced over the 32 token lanes once per unit (DPP); db likewise from
-// the dY registers, in the ht = 0 unit only.
+// da_u = G 1: three more MFMAs per k-step on G's transposed terms against a fragment of ones (every column of the result
+// is da_u; the matrix pipe has the slack, the VALU does not). db: per-lane sums of the dY registers, reduced over the 32
+// token lanes once per unit (DPP), in the ht = 0 unit only.
 constexpr int kPOffSa = 3 * psf_x3::kPlaneBytes;       // 6144: sa in accumulator-register order [half][16]
 constexpr int kPOffBT = kPOffSa + 128;                 // 6272: B^T terms as in the x3 image
 constexpr int kPImgBytes = kPOffBT + 3 * kXFragTerm;   // 12416
@@ -799,8 +803,8 @@ __global__ void __launch_bounds__(256) mlp_bwd_x3p_pack_k(const BwdArgs a) {
   using psf_x3::plane_off;
   using psf_x3::split3;
   const int u = blockIdx.x;
-  const BwdMlp d = a.m[a.unit_k[u]];
-  const int ht = 32 * a.unit_hb[u], E = a.E;
+  const BwdMlp d = a.m[a.unit[u] & 0xff];
+  const int ht = 32 * (int)(a.unit[u] >> 8), E = a.E;
   unsigned char* img = reinterpret_cast<unsigned char*>(a.images) + (size_t)u * kXImgBytes;
   uint16_t* img16 = reinterpret_cast<uint16_t*>(img);
   float* img32 = reinterpret_cast<float*>(img);
@@ -843,19 +847,34 @@ __device__ __forceinline__ float half_sum(float v) {
   return v + __shfl_xor(v, 16, 64);
 }
 
+#ifdef PSF_X3P_TRACE  // profiles/x3plab.hip: shader-clock timestamps of one unit of one workgroup, per wave
+__device__ unsigned long long psf_x3p_trace[8][32];
+#define PSF_TRACE(slot)                                                        \
+  do {                                                                         \
+    if (trace_on) {                                                            \
+      const unsigned long long t_ = clock64();                                 \
+      if (lane == 0) psf_x3p_trace[wv][(slot)] = t_;                           \
+    }                                                                          \
+  } while (0)
+#else
+#define PSF_TRACE(slot) do { } while (0)
+#endif
+
 // 512 threads, one workgroup per CU (two waves per SIMD, <= 256 registers), two image buffers.
 // NDY: dY values per lane and tile = outputs of one token that one half of the wave covers: 8 (O <= 16) or 16.
 template <int TPW, int NDY>
 __global__ void __launch_bounds__(512, 1)
 mlp_bwd_x3p_k(const BwdArgs a) {
   using namespace psf_x3;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 31, half = lane >> 5;
   constexpr int NW = 8;
   constexpr int NS2 = NDY / 8;  // k-steps of the contraction over outputs (step 2)
   constexpr int kWaveBytes = TPW * 3 * kPlaneBytes + kPScrBytes;
-  unsigned char* XP = lds_raw + 2 * kPImgBytes + wv * kWaveBytes;  // the wave's X planes [tile][term]
+  // static LDS: 2 images + 8 waves x (TPW x 3 X planes + scratch) = 160,000 bytes at TPW = 2
+  __shared__ __attribute__((aligned(16))) unsigned char img_lds[2 * kPImgBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char wave_lds[NW * kWaveBytes];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, half = lane >> 5;
+  unsigned char* XP = wave_lds + wv * kWaveBytes;  // the wave's X planes [tile][term]
   unsigned char* HP = XP + TPW * 3 * kPlaneBytes;                  // scratch plane: Hpost^T / G, one term at a time
   unsigned char* YP = HP + kPlaneBytes;                            // scratch plane: dY, one term at a time
   float* SCR = reinterpret_cast<float*>(HP);                       // the same bytes for the cross-wave combine
@@ -865,14 +884,22 @@ mlp_bwd_x3p_k(const BwdArgs a) {
   const int64_t tiles_per_block = NW * TPW;
   const unsigned char* images = reinterpret_cast<const unsigned char*>(a.images);
 
+  // Image u by LDS-DMA: 16 bytes per lane, global -> LDS without passing through registers. Issued as inline assembly,
+  // not through __builtin_amdgcn_global_load_lds: hipcc makes every later read of LDS that may alias a DMA in flight wait
+  // for vmcnt(0) (its alias rule for LDS-DMA is all-or-nothing), and that wait also drains the dY prefetch issued a few
+  // instructions earlier — a full memory round trip per unit at the first image read, measured (profiles/r02ac_x3plab.log).
+  // Hidden from the compiler, the DMA costs one explicit s_waitcnt vmcnt(0) in front of the barrier that publishes the image.
   auto stage = [&](int u) {
     const unsigned char* src = images + (size_t)u * kXImgBytes;
-    unsigned char* dst = lds_raw + (u & 1) * kPImgBytes;
+    unsigned char* dst = img_lds + (u & 1) * kPImgBytes;
     for (int v0 = 0; v0 < kPImgVecs; v0 += 64 * NW) {
       const int v = v0 + tid;
+      const uint32_t lds_at = __builtin_amdgcn_readfirstlane(
+          (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)(dst + 16 * (v0 + (tid & ~63)))));
+      uint32_t m0_saved;  // M0 = LDS address of the wave's 1 KB destination; the lane's 16 bytes go to M0 + 16 lane
       if (v < kPImgVecs)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * v),
-                                         (__attribute__((address_space(3))) void*)(dst + 16 * (v0 + (tid & ~63))), 16, 0, 0);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_saved) : "s"(lds_at), "v"(src + 16 * v) : "memory");
     }
   };
 
@@ -901,17 +928,21 @@ mlp_bwd_x3p_k(const BwdArgs a) {
     }
     float* part = a.partials + (blk * (int64_t)U) * kPart;  // one partial slot per workgroup
     float dyn[NDY];
-    auto dy_fetch = [&](int u2, int64_t t02) {  // the lane's token: outputs 16 s + 8 half + i
-      const BwdMlp& d2 = a.m[a.unit_k[u2]];
+    // The lane's token, outputs 16 s + 8 half + i. Loads only (no use of the values here: anything that touches a loaded
+    // register waits for it, and eight dependent round trips are what a select per load costs): rows past T and outputs
+    // past O read an in-bounds neighbour instead. Outputs >= O meet zero columns of B^T in step 2 and land in columns of
+    // dB^T / db that are never read; rows >= T are zeroed by dy_take in the one partial tile.
+    auto dy_fetch = [&](int u2, int64_t t02) {
+      const BwdMlp& d2 = a.m[a.unit[u2] & 0xff];
       const int W = d2.O;
       const int64_t tok = t02 + c;
-      const float* src = d2.dY + tok * W;
+      const float* src = d2.dY + (tok < a.T ? tok : 0) * W;
 #pragma unroll
       for (int s = 0; s < NS2; ++s)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int o = 16 * s + 8 * half + i;
-          dyn[8 * s + i] = (tok < a.T && o < W) ? src[o] : 0.f;
+          dyn[8 * s + i] = src[o < W ? o : 0];
         }
     };
     dy_fetch(0, t0[0]);
@@ -919,21 +950,48 @@ mlp_bwd_x3p_k(const BwdArgs a) {
     stage(0);
 
     for (int u = 0; u < U; ++u) {
-      __syncthreads();  // image u has landed (vmcnt is drained before the barrier); unit u-1's combine is finished
+#ifdef PSF_X3P_TRACE
+      const bool trace_on = blockIdx.x == 300 && u == 5;
+#endif
+      PSF_TRACE(0);
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's part of image u has landed
+      __syncthreads();  // image u is complete; unit u-1's combine is finished
+      PSF_TRACE(1);
       if (u + 1 < U) stage(u + 1);
-      const unsigned char* img = lds_raw + (u & 1) * kPImgBytes;
-      const bool first_block_of_mlp = a.unit_hb[u] == 0;
+      const unsigned char* img = img_lds + (u & 1) * kPImgBytes;
+      const bool first_block_of_mlp = (a.unit[u] >> 8) == 0;
 
-      f32x16 dA, dBT;
-      float P[16], dbp[NDY];
+      f32x16 dA, dBT, dav;  // dav[r] = sum over tokens of G[cd_row(r, half)][tok], the same in every column
+      float dbp[NDY];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dA[r] = dBT[r] = P[r] = 0.f;
+      for (int r = 0; r < 16; ++r) dA[r] = dBT[r] = dav[r] = 0.f;
 #pragma unroll
       for (int i = 0; i < NDY; ++i) dbp[i] = 0.f;
+      // An accumulator tile's three terms -> scratch planes -> back transposed (tr_frag). Terms 1 and 2 go through the two
+      // planes together and term 3 follows into the first (LDS operations of one wave execute in order): two exposed LDS
+      // round trips per operand instead of three.
+      auto transposed = [&](const Split16& x, Frag3 (&out)[2]) {
+        store_acc_plane(HP, L, x, 0);
+        store_acc_plane(YP, L, x, 1);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 2; ++s) out[s].t1 = tr_frag(HP, L, s), out[s].t2 = tr_frag(YP, L, s);
+        asm volatile("" ::: "memory");
+        store_acc_plane(HP, L, x, 2);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 2; ++s) out[s].t3 = tr_frag(HP, L, s);
+        asm volatile("" ::: "memory");
+      };
 
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp) {
         // 0. this tile's dY values -> split terms (the lane's step-2 B fragments); start the next tile-unit's loads
+        PSF_TRACE(2 + 8 * tp);
+        if (t0[tp] + 32 > a.T) {  // wave-uniform: the partial tile (and tiles past the end)
+#pragma unroll
+          for (int i = 0; i < NDY; ++i) dyn[i] = t0[tp] + c < a.T ? dyn[i] : 0.f;
+        }
         Frag3 dy3[NS2];
 #pragma unroll
         for (int s = 0; s < NS2; ++s) {
@@ -945,12 +1003,42 @@ mlp_bwd_x3p_k(const BwdArgs a) {
 #pragma unroll
           for (int i = 0; i < NDY; ++i) dbp[i] += dyn[i];
         }
+        // Pin the order "consume the old values, THEN issue the next loads". hipcc hoists the loads above the split, and the
+        // wait in front of the split is then vmcnt(0) (partial-sum stores are still pending and make the counter's order
+        // unknown to it), which drains the loads it has just issued: one memory round trip per tile-unit, measured.
+#pragma unroll
+        for (int s = 0; s < NS2; ++s)
+          asm volatile("" : "+v"(dy3[s].t1), "+v"(dy3[s].t2), "+v"(dy3[s].t3) : : "memory");
+#pragma unroll
+        for (int i = 0; i < NDY; i += 4) asm volatile("" : "+v"(dbp[i]), "+v"(dbp[i + 1]), "+v"(dbp[i + 2]), "+v"(dbp[i + 3]) : : "memory");
         if (tp + 1 < TPW)
           dy_fetch(u, t0[tp + 1 < TPW ? tp + 1 : 0]);
         else if (u + 1 < U)
           dy_fetch(u + 1, t0[0]);
         if (t0[tp] >= a.T) continue;  // wave-uniform
         const unsigned char* xp = XP + tp * 3 * kPlaneBytes;
+        PSF_TRACE(3 + 8 * tp);
+        // the same terms through the scratch planes [tok][o] and back transposed: the step-4 B operand. Issued first: the
+        // round trips overlap with the MFMAs of steps 1 and 2.
+        Frag3 yb[2];
+        {
+          const bf16x8 zero = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));  // outputs >= 16 of a narrow dY
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            *reinterpret_cast<bf16x8*>(HP + L.row[s]) = s < NS2 ? dy3[s < NS2 ? s : 0].t1 : zero;
+            *reinterpret_cast<bf16x8*>(YP + L.row[s]) = s < NS2 ? dy3[s < NS2 ? s : 0].t2 : zero;
+          }
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int s = 0; s < 2; ++s) yb[s].t1 = tr_frag(HP, L, s), yb[s].t2 = tr_frag(YP, L, s);
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(HP + L.row[s]) = s < NS2 ? dy3[s < NS2 ? s : 0].t3 : zero;
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int s = 0; s < 2; ++s) yb[s].t3 = tr_frag(HP, L, s);
+          asm volatile("" ::: "memory");
+        }
 
         // 1. Hpre^T = A_u X^T + a_u : both operands by row reads
         f32x16 acc1, acc3;
@@ -978,6 +1066,7 @@ mlp_bwd_x3p_k(const BwdArgs a) {
         for (int s = 0; s < NS2; ++s)
           acc3 = mfma6(load_frag3(img + kPOffBT + ((s * 2 + half) * 32 + c) * 16, kXFragTerm), dy3[s], acc3);
         // 3. GELU and its derivative
+        PSF_TRACE(4 + 8 * tp);
         float y[16], g[16];
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
@@ -987,56 +1076,30 @@ mlp_bwd_x3p_k(const BwdArgs a) {
           y[r + 1] = yy.y;
           g[r] = acc3[r] * dd.x;  // G = dHpre^T
           g[r + 1] = acc3[r + 1] * dd.y;
-          P[r] += g[r];
-          P[r + 1] += g[r + 1];
         }
-        // 4. dB^T[j][o] += Hpost^T[j][tok] dY[tok][o] : both operands by transposed reads of the scratch planes
+        // 4. dB^T[j][o] += Hpost^T[j][tok] dY[tok][o] : both operands by transposed reads
+        PSF_TRACE(5 + 8 * tp);
         {
           const Split16 ys = split16(y);
-          Frag3 ha[2], yb[2];
-#pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            store_acc_plane(HP, L, ys, t);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              const bf16x8 term = t == 0 ? dy3[s < NS2 ? s : 0].t1 : (t == 1 ? dy3[s < NS2 ? s : 0].t2 : dy3[s < NS2 ? s : 0].t3);
-              const bf16x8 zero = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
-              *reinterpret_cast<bf16x8*>(YP + L.row[s]) = s < NS2 ? term : zero;  // outputs >= 16 of a narrow dY read as zero
-            }
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              const bf16x8 hf = tr_frag(HP, L, s), yf = tr_frag(YP, L, s);
-              if (t == 0) ha[s].t1 = hf, yb[s].t1 = yf;
-              if (t == 1) ha[s].t2 = hf, yb[s].t2 = yf;
-              if (t == 2) ha[s].t3 = hf, yb[s].t3 = yf;
-            }
-            asm volatile("" ::: "memory");
-          }
+          Frag3 ha[2];
+          transposed(ys, ha);
 #pragma unroll
           for (int s = 0; s < 2; ++s) dBT = mfma6(ha[s], yb[s], dBT);
         }
-        // 5. dA[j][e] += G[j][tok] X[tok][e]   and   6. dX^T[e][tok] += A_u^T[e][j] G[j][tok]
+        // 5. dA[j][e] += G[j][tok] X[tok][e], da[j] += G[j][tok] 1   and   6. dX^T[e][tok] += A_u^T[e][j] G[j][tok]
+        PSF_TRACE(6 + 8 * tp);
         {
           const Split16 gs = split16(g);
           Frag3 ga[2];
-#pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            store_acc_plane(HP, L, gs, t);
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              const bf16x8 gf = tr_frag(HP, L, s);
-              if (t == 0) ga[s].t1 = gf;
-              if (t == 1) ga[s].t2 = gf;
-              if (t == 2) ga[s].t3 = gf;
-            }
-            asm volatile("" ::: "memory");
-          }
+          transposed(gs, ga);
+          const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             const Frag3 xb{tr_frag(xp, L, s), tr_frag(xp + kPlaneBytes, L, s), tr_frag(xp + 2 * kPlaneBytes, L, s)};
             dA = mfma6(ga[s], xb, dA);
+            dav = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[s].t3, ones, dav, 0, 0, 0);
+            dav = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[s].t2, ones, dav, 0, 0, 0);
+            dav = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[s].t1, ones, dav, 0, 0, 0);
           }
           if (a.dX) {
 #pragma unroll
@@ -1048,16 +1111,15 @@ mlp_bwd_x3p_k(const BwdArgs a) {
           }
         }
       }
-      // da, db: the per-lane sums over the 32 token lanes of each half
-#pragma unroll
-      for (int r = 0; r < 16; ++r) P[r] = half_sum(P[r]);
+      // db: the per-lane sums over the 32 token lanes of each half (da came off the matrix pipe)
+      PSF_TRACE(18);
       if (first_block_of_mlp) {
 #pragma unroll
         for (int i = 0; i < NDY; ++i) dbp[i] = half_sum(dbp[i]);
       }
       // Combine the eight waves' partial sums through LDS (fixed order w = 0..7) and flush once per workgroup.
       float* pu = part + (int64_t)u * kPart;
-      const float* wave0 = reinterpret_cast<const float*>(lds_raw + 2 * kPImgBytes + TPW * 3 * kPlaneBytes);  // wave 0's SCR
+      const float* wave0 = reinterpret_cast<const float*>(wave_lds + TPW * 3 * kPlaneBytes);  // wave 0's SCR
       auto sum8 = [&](int off) {  // off: float offset into a wave's SCR, 16-byte aligned
         float4 acc = *reinterpret_cast<const float4*>(wave0 + off);
 #pragma unroll
@@ -1076,20 +1138,26 @@ mlp_bwd_x3p_k(const BwdArgs a) {
       SCR[1088 + lane] = 0.f;  // db [2][32]
       if (c == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) SCR[1024 + cd_row(r, half)] = P[r];
+        for (int r = 0; r < 16; ++r) SCR[1024 + cd_row(r, half)] = dav[r];
 #pragma unroll
         for (int s = 0; s < NS2; ++s)
 #pragma unroll
           for (int i = 0; i < 8; ++i) SCR[1088 + 16 * s + 8 * half + i] = dbp[8 * s + i];
       }
+      PSF_TRACE(19);
       __syncthreads();
+      PSF_TRACE(20);
       if (wv < 4) *reinterpret_cast<float4*>(pu + wv * 256 + 4 * lane) = sum8(wv * 256 + 4 * lane);
       if (wv == 4 && lane < 32) *reinterpret_cast<float4*>(pu + 2048 + 4 * lane) = sum8(1024 + 4 * lane);
+      PSF_TRACE(21);
       __syncthreads();
+      PSF_TRACE(22);
 #pragma unroll
       for (int r = 0; r < 16; ++r) SCR[cd_row(r, half) * 32 + c] = dBT[r];
       __syncthreads();
+      PSF_TRACE(23);
       if (wv < 4) *reinterpret_cast<float4*>(pu + 1024 + wv * 256 + 4 * lane) = sum8(wv * 256 + 4 * lane);
+      PSF_TRACE(24);
     }
 
     if (a.dX) {  // the lane holds dX^T[e = 8 g + 4 half + (0..3)][tok = c] in registers 4 g .. 4 g + 3
@@ -1129,8 +1197,8 @@ __global__ void __launch_bounds__(256) mlp_bwd_reduce2_k(const BwdArgs a) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
   const int u = (int)(idx / kPart), i = (int)(idx - (int64_t)u * kPart);
-  const BwdMlp& d = a.m[a.unit_k[u]];
-  const int ht = 32 * a.unit_hb[u], E = a.E;
+  const BwdMlp& d = a.m[a.unit[u] & 0xff];
+  const int ht = 32 * (int)(a.unit[u] >> 8), E = a.E;
   auto total = [&](int64_t at) {
     float acc = 0.f;
     for (int s = 0; s < kSlices; ++s) acc += a.stage1[s * n + at];
@@ -1215,8 +1283,7 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
     args.m[k] = BwdMlp{A[k], a[k], B[k], dY[k], dA[k], da[k], dB[k], db[k], h[k], O[k]};
   }
   for (int u = 0; u < kMaxUnits; ++u) {
-    args.unit_k[u] = u < p.U ? p.unit_k[u] : 0;
-    args.unit_hb[u] = u < p.U ? p.unit_hb[u] : 0;
+    args.unit[u] = u < p.U ? ((uint32_t)p.unit_k[u] | ((uint32_t)p.unit_hb[u] << 8)) : 0u;
   }
   const int variant = psf_g_mlp_bwd_variant.load();
   const bool x3 = variant != 1;         // split-bf16 kernels unless the f32 one is forced
@@ -1252,10 +1319,8 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
     e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * waves), lds_bytes, s, args);
   };
-  auto launch_planes = [&](auto kernel, int tpw) {
-    const size_t lds_bytes = 2 * (size_t)kPImgBytes + 8 * ((size_t)tpw * 3 * psf_x3::kPlaneBytes + kPScrBytes);
-    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(512), lds_bytes, s, args);
+  auto launch_planes = [&](auto kernel, int) {  // static LDS: 2 images + 8 x (tpw x 3 planes + scratch) = 160,000 B at tpw = 2
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(512), 0, s, args);
   };
   if (planes) {
     if (max_o <= 16) {

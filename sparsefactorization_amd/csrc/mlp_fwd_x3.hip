@@ -57,7 +57,9 @@ struct X3Mlp {
 
 struct X3Args {
   X3Mlp m[32];
-  uint8_t unit_k[128], unit_hb[128], unit_last[128];  // unit -> (MLP, hidden block, last unit of its MLP)
+  // unit -> MLP | hidden block << 8 | (last unit of its MLP) << 16. Dwords: a byte table indexed by the unit counter is read
+  // with global_load_ubyte + s_waitcnt vmcnt(0) (a full memory round trip per unit); a dword table with one s_load_dword.
+  uint32_t unit[128];
   const float* X;
   unsigned char* images;
   int64_t T;
@@ -96,8 +98,8 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
 // One workgroup per unit: split the weights and write them in operand order.
 __global__ void __launch_bounds__(256) x3_pack_k(const X3Args a) {
   const int u = blockIdx.x;
-  const X3Mlp d = a.m[a.unit_k[u]];
-  const int ht = 32 * a.unit_hb[u], E = a.E;
+  const X3Mlp d = a.m[a.unit[u] & 0xff];
+  const int ht = 32 * (int)((a.unit[u] >> 8) & 0xff), E = a.E;
   unsigned char* img = a.images + (size_t)u * kImgBytes;
   uint16_t* img16 = reinterpret_cast<uint16_t*>(img);
   float* img32 = reinterpret_cast<float*>(img);
@@ -233,7 +235,7 @@ x3_fwd_k(const X3Args a) {
       const unsigned char* img = lds_raw + (u & 1) * kImgBytes;
       const float* sa = reinterpret_cast<const float*>(img + kOffSa);
       const float* sb = reinterpret_cast<const float*>(img + kOffSb);
-      const bool first = a.unit_hb[u] == 0, last = a.unit_last[u] != 0;
+      const bool first = ((a.unit[u] >> 8) & 0xff) == 0, last = (a.unit[u] >> 16) != 0;
 
       // weight fragments of this unit (shared by the wave's tiles)
       Frag3 wa[2], wb[2];
@@ -319,7 +321,7 @@ x3_fwd_k(const X3Args a) {
         for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
           for (int r = 0; r < 16; ++r) sw[tp * kScr + c * 33 + cd_row(r, half)] = acc2[tp][r];
-        pend = a.unit_k[u];
+        pend = (int)(a.unit[u] & 0xff);
       }
     }
     if (pend >= 0) flush();
@@ -364,9 +366,7 @@ hipError_t psf_x3_mlp_fwd_launch(const float* X, int64_t T, int32_t E, int32_t K
   for (int k = 0; k < 32; ++k) args.m[k] = X3Mlp{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
   for (int k = 0; k < K; ++k) args.m[k] = X3Mlp{A[k], a[k], B[k], b[k], Y[k], h[k], O[k]};
   for (int u = 0; u < 128; ++u) {
-    args.unit_k[u] = u < p.U ? p.unit_k[u] : 0;
-    args.unit_hb[u] = u < p.U ? p.unit_hb[u] : 0;
-    args.unit_last[u] = u < p.U ? p.unit_last[u] : 0;
+    args.unit[u] = u < p.U ? ((uint32_t)p.unit_k[u] | ((uint32_t)p.unit_hb[u] << 8) | ((uint32_t)p.unit_last[u] << 16)) : 0u;
   }
   args.X = X;
   args.images = reinterpret_cast<unsigned char*>(workspace);
