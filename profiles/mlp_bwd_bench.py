@@ -59,7 +59,8 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for name, E, h, outs, T in (("order_n16384_b40", 32, 32, [8] + [15] * 14, args.tokens),
-                                ("pathfinder_b64", 32, 128, [12] * 11, 64 * 1024)):
+                                ("pathfinder_b64", 32, 128, [12] * 11, 64 * 1024),
+                                ("wide_out_o32", 32, 32, [32] * 4, args.tokens)):
         params = make(E, h, outs, dev)
         g = torch.Generator(device=dev).manual_seed(1)
         x = torch.randn(T, E, device=dev, generator=g)

@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     std::printf("variant %d: %.3f ms per call\n", variant, ms / 10);
   }
-  unsigned long long tr[8][32];
+  unsigned long long tr[12][32];
   CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(psf_x3p_trace), sizeof(tr)));
   const char* names[25] = {"unit top", "after B0", "t0 start", "t0 dY split+prefetch issued", "t0 steps 1,2 issued", "t0 GELU done",
                            "t0 step 4 issued", "", "", "", "t1 start", "t1 dY split+prefetch issued", "t1 steps 1,2 issued",

@@ -31,17 +31,15 @@
 //
 // Limits: E <= 32 (multiple of 4), h <= 128, O <= 32, K <= 32; anything else stays on autograd.
 //
-// Two kernels share that structure (knob mlp_bwd_variant: 0 = auto -> the second, 1 = the first):
-//   mlp_bwd_k      all five GEMMs on v_mfma_f32_32x32x2_f32. That instruction occupies the vector ALU's datapath
+// Three kernels share that structure (knob mlp_bwd_variant; 0 = auto -> the third):
+//   mlp_bwd_k      (1) all five GEMMs on v_mfma_f32_32x32x2_f32. That instruction occupies the vector ALU's datapath
 //                  (profiles/r01_mfmalab.log: MFMA cycles and VALU cycles add), so a tile-unit costs 72 x 64 MFMA
-//                  cycles PLUS ~2400 VALU cycles: 1.16 ms at Order N=16384, B=40 = 0.49 of the f32-MFMA peak.
-//   mlp_bwd_x3_k   all five GEMMs on v_mfma_f32_32x32x16_bf16 with the exact three-way bf16 split of mlp_x3_common.h
-//                  (6 products per k-step of 16: 54 MFMAs of 32 cycles on the separate matrix pipe instead of 72 of 64
-//                  on the shared one). Weights are split once per call by the pack kernel, X's step-1 operand once per
-//                  tile; per tile-unit the kernel splits dY (twice: by token for step 2, by output for step 4), G (twice:
-//                  registers for step 6, transposed through LDS for step 5), Hpost^T and X^T — 4.5 VALU per value on
-//                  packed subtractions. 512-thread workgroups (8 waves share the 20 KB split image; the f32 image is
-//                  8.6 KB) keep two waves per SIMD within 160 KB of LDS.
+//                  cycles PLUS ~2400 VALU cycles: 1.17 ms at Order N=16384, B=40.
+//   mlp_bwd_x3_k   (2, 3, 4) steps 1, 2, 6 (optionally all) on v_mfma_f32_32x32x16_bf16 with the exact three-way bf16 split
+//                  of mlp_x3_common.h; operands of the token contractions are re-laid through f32 LDS tiles and split again
+//                  per orientation — or stay on the f32 instruction: 1.03 ms.
+//   mlp_bwd_x3p_k  (5, default) all five GEMMs on the bf16 pipe, every operand split ONCE into bf16 planes in LDS that serve
+//                  both orientations (row reads and ds_read_b64_tr_b16, mlp_planes.h): 0.86 ms. See the comment above it.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -866,7 +864,7 @@ template <int TPW, int NDY>
 __global__ void __launch_bounds__(512, 1)
 mlp_bwd_x3p_k(const BwdArgs a) {
   using namespace psf_x3;
-  constexpr int NW = 8;
+  constexpr int NW = 8;  // (twelve waves of one tile each, three per SIMD at 168 registers: 0.94 vs 0.86 ms, profiles/r02ae)
   constexpr int NS2 = NDY / 8;  // k-steps of the contraction over outputs (step 2)
   constexpr int kWaveBytes = TPW * 3 * kPlaneBytes + kPScrBytes;
   // static LDS: 2 images + 8 waves x (TPW x 3 X planes + scratch) = 160,000 bytes at TPW = 2
@@ -967,23 +965,6 @@ mlp_bwd_x3p_k(const BwdArgs a) {
       for (int r = 0; r < 16; ++r) dA[r] = dBT[r] = dav[r] = 0.f;
 #pragma unroll
       for (int i = 0; i < NDY; ++i) dbp[i] = 0.f;
-      // An accumulator tile's three terms -> scratch planes -> back transposed (tr_frag). Terms 1 and 2 go through the two
-      // planes together and term 3 follows into the first (LDS operations of one wave execute in order): two exposed LDS
-      // round trips per operand instead of three.
-      auto transposed = [&](const Split16& x, Frag3 (&out)[2]) {
-        store_acc_plane(HP, L, x, 0);
-        store_acc_plane(YP, L, x, 1);
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int s = 0; s < 2; ++s) out[s].t1 = tr_frag(HP, L, s), out[s].t2 = tr_frag(YP, L, s);
-        asm volatile("" ::: "memory");
-        store_acc_plane(HP, L, x, 2);
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int s = 0; s < 2; ++s) out[s].t3 = tr_frag(HP, L, s);
-        asm volatile("" ::: "memory");
-      };
-
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp) {
         // 0. this tile's dY values -> split terms (the lane's step-2 B fragments); start the next tile-unit's loads
@@ -1077,21 +1058,47 @@ mlp_bwd_x3p_k(const BwdArgs a) {
           g[r] = acc3[r] * dd.x;  // G = dHpre^T
           g[r + 1] = acc3[r + 1] * dd.y;
         }
-        // 4. dB^T[j][o] += Hpost^T[j][tok] dY[tok][o] : both operands by transposed reads
+        // 4. dB^T[j][o] += Hpost^T[j][tok] dY[tok][o]        (both operands by transposed reads)
+        // 5. dA[j][e] += G[j][tok] X[tok][e],  da[j] += G[j][tok] 1
+        // 6. dX^T[e][tok] += A_u^T[e][j] G[j][tok]              (A^T by transposed reads of the image, G from registers)
+        // The six terms of Hpost^T and G go through the two scratch planes in three rounds (LDS operations of one wave
+        // execute in order, so a plane is rewritten as soon as its reads are issued). G is split while round 1 is in
+        // flight; step 6, which needs no transposed activation, covers round 2, and step 4 covers round 3.
         PSF_TRACE(5 + 8 * tp);
-        {
-          const Split16 ys = split16(y);
-          Frag3 ha[2];
-          transposed(ys, ha);
+        Frag3 ha[2], ga[2];
+        const Split16 ys = split16(y);
+        store_acc_plane(HP, L, ys, 0);
+        store_acc_plane(YP, L, ys, 1);
+        asm volatile("" ::: "memory");
+        const Split16 gs = split16(g);
 #pragma unroll
-          for (int s = 0; s < 2; ++s) dBT = mfma6(ha[s], yb[s], dBT);
+        for (int s = 0; s < 2; ++s) ha[s].t1 = tr_frag(HP, L, s), ha[s].t2 = tr_frag(YP, L, s);
+        asm volatile("" ::: "memory");
+        store_acc_plane(HP, L, ys, 2);
+        store_acc_plane(YP, L, gs, 0);
+        asm volatile("" ::: "memory");
+        if (a.dX) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const Frag3 at{tr_frag_acc(img, L, s), tr_frag_acc(img + kPlaneBytes, L, s), tr_frag_acc(img + 2 * kPlaneBytes, L, s)};
+            const Frag3 gb{acc_frag(gs, 0, s), acc_frag(gs, 1, s), acc_frag(gs, 2, s)};
+            dxa[tp] = mfma6(at, gb, dxa[tp]);
+          }
         }
-        // 5. dA[j][e] += G[j][tok] X[tok][e], da[j] += G[j][tok] 1   and   6. dX^T[e][tok] += A_u^T[e][j] G[j][tok]
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 2; ++s) ha[s].t3 = tr_frag(HP, L, s), ga[s].t1 = tr_frag(YP, L, s);
+        asm volatile("" ::: "memory");
+        store_acc_plane(HP, L, gs, 1);
+        store_acc_plane(YP, L, gs, 2);
+        asm volatile("" ::: "memory");
         PSF_TRACE(6 + 8 * tp);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) dBT = mfma6(ha[s], yb[s], dBT);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) ga[s].t2 = tr_frag(HP, L, s), ga[s].t3 = tr_frag(YP, L, s);
+        asm volatile("" ::: "memory");
         {
-          const Split16 gs = split16(g);
-          Frag3 ga[2];
-          transposed(gs, ga);
           const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
@@ -1100,14 +1107,6 @@ mlp_bwd_x3p_k(const BwdArgs a) {
             dav = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[s].t3, ones, dav, 0, 0, 0);
             dav = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[s].t2, ones, dav, 0, 0, 0);
             dav = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[s].t1, ones, dav, 0, 0, 0);
-          }
-          if (a.dX) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              const Frag3 at{tr_frag_acc(img, L, s), tr_frag_acc(img + kPlaneBytes, L, s), tr_frag_acc(img + 2 * kPlaneBytes, L, s)};
-              const Frag3 gb{acc_frag(gs, 0, s), acc_frag(gs, 1, s), acc_frag(gs, 2, s)};
-              dxa[tp] = mfma6(at, gb, dxa[tp]);
-            }
           }
         }
       }
@@ -1242,7 +1241,11 @@ bool make_plan(int64_t T, int32_t E, int32_t K, const int32_t* h, const int32_t*
   p->tpw = (tiles + 7) / 8 >= 512 ? 2 : 1;
   // one workgroup (= one partial slot) per waves*TPW tiles: 4 waves (f32 kernel) or 8 (split-bf16 kernel)
   p->G = (tiles + 4 * p->tpw - 1) / (4 * p->tpw);
-  p->tpw8 = p->tpw;
+  int max_o = 1;
+  for (int k = 0; k < K; ++k) max_o = O[k] > max_o ? O[k] : max_o;
+  // 512-thread kernels: outputs wider than 16 double the dY registers of a lane and two tiles per wave no longer fit 256
+  // registers (70 spilled, 0.417 ms at 4 x O = 32, T = 655 k); one tile per wave fits: 0.397 ms.
+  p->tpw8 = max_o > 16 ? 1 : p->tpw;
   p->G8 = (tiles + 8 * p->tpw8 - 1) / (8 * p->tpw8);
   return true;
 }
@@ -1288,7 +1291,7 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   const int variant = psf_g_mlp_bwd_variant.load();
   const bool x3 = variant != 1;         // split-bf16 kernels unless the f32 one is forced
   const bool four_waves = variant == 4;  // split-bf16 kernel on 256-thread workgroups, two per CU
-  const bool planes = variant == 5;      // split-bf16 kernel on dual-use LDS planes
+  const bool planes = variant == 0 || variant >= 5;  // split-bf16 kernel on dual-use LDS planes (the default)
   if (planes && dX && (reinterpret_cast<uintptr_t>(dX) & 15) != 0)
     return psf_internal_fail(PSF_E_ALIGN, "psf_mlp_bwd: dX must be 16-byte aligned");
   float* ws = reinterpret_cast<float*>(workspace);
@@ -1319,19 +1322,18 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
     e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * waves), lds_bytes, s, args);
   };
-  auto launch_planes = [&](auto kernel, int) {  // static LDS: 2 images + 8 x (tpw x 3 planes + scratch) = 160,000 B at tpw = 2
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(512), 0, s, args);
+  auto launch_planes = [&](auto kernel, int waves) {  // static LDS: 2 images + 8 x (tpw x 3 planes + scratch) = 160,000 B at tpw = 2
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * waves), 0, s, args);
   };
   if (planes) {
     if (max_o <= 16) {
-      if (p.tpw8 == 2) launch_planes(mlp_bwd_x3p_k<2, 8>, 2);
-      else launch_planes(mlp_bwd_x3p_k<1, 8>, 1);
+      if (p.tpw8 == 2) launch_planes(mlp_bwd_x3p_k<2, 8>, 8);
+      else launch_planes(mlp_bwd_x3p_k<1, 8>, 8);
     } else {
-      if (p.tpw8 == 2) launch_planes(mlp_bwd_x3p_k<2, 16>, 2);
-      else launch_planes(mlp_bwd_x3p_k<1, 16>, 1);
+      launch_planes(mlp_bwd_x3p_k<1, 16>, 8);  // make_plan: one tile per wave when an output is wider than 16
     }
   } else if (x3) {
-    const bool full = psf_g_mlp_bwd_variant.load() == 2 || (psf_g_mlp_bwd_variant.load() == 0 && p.tpw8 == 1);
+    const bool full = variant == 2;
     if (four_waves) {
       if (max_o <= 16) {
         if (p.tpw == 2) launch(mlp_bwd_x3_k<2, 8, false, 4>, 4, kXImgBytes, 2, 17, 1);

@@ -183,7 +183,7 @@ MLP_TRAIN_CASES = [  # (T, E, [(h, out), ...])
 ]
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 5], ids=["bwd_auto", "bwd_f32_mfma", "bwd_bf16x3_all", "bwd_bf16x3_steps126", "bwd_bf16x3_planes"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["bwd_auto_planes", "bwd_f32_mfma", "bwd_bf16x3_resplit", "bwd_bf16x3_steps126", "bwd_bf16x3_steps126_4waves"])
 def mlp_bwd_variant(request):
     """Every kernel of psf_mlp_bwd_f32 (csrc/mlp_bwd.hip): the all-f32-MFMA one and the exact split-bf16 ones."""
     import sparsefactorization_amd as sfa
