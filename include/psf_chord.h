@@ -303,10 +303,10 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
  *   key "mlp_variant": psf_mlp_fwd_f32: 0 = auto (default: the split-bf16 kernel for E <= 32, else the f32-MFMA
  *                      kernel), 1 = f32 MFMA with streamed weights, 2 = f32 MFMA with LDS-resident weights,
  *                      3 = split-bf16 (each f32 operand as three exact bf16 terms, six product terms: f32 accuracy)
- *   key "mlp_bwd_variant": psf_mlp_bwd_f32: 0 = auto (default) = 5 = split-bf16 on dual-use LDS planes: all five GEMMs
+ *   key "mlp_bwd_variant": psf_mlp_bwd_f32: 0 = auto (default) = 3 = split-bf16 on dual-use LDS planes: all five GEMMs
  *                      on the bf16 matrix pipe, every operand split once, transposed operands by ds_read_b64_tr_b16;
- *                      1 = all-f32-MFMA kernel; 2 / 3 = the round-2 split-bf16 kernel with all five / only steps 1, 2, 6
- *                      on bf16 (operands re-split per orientation); 4 = 3 on 256-thread workgroups (two per CU)
+ *                      1 = all-f32-MFMA kernel; 2 = the first split-bf16 kernel (steps 1, 2, 6 on bf16, the token
+ *                      contractions on the f32 instruction)
  *   key "xcd_remap"  : 1 = keep a batch element's tiles on one XCD group (default), 0 = linear
  * psf_get_tuning returns the value (>= 0) or PSF_E_TUNING.
  */

@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # Counter passes on the fused MLP backward kernels (mlp_bwd_k / mlp_bwd_x3_k) at the Temporal-Order training shape.
-#     [VARIANTS="1 3 5"] bash profiles/collect_mlp_bwd.sh <tag>   -> gpurun_out/prof_<tag>/v<variant>/<pass>/
+#     [VARIANTS="1 2 0"] bash profiles/collect_mlp_bwd.sh <tag>   -> gpurun_out/prof_<tag>/v<variant>/<pass>/
 # then, here:  python profiles/summarize_mlp_bwd.py <tag>   -> profiles/<tag>_mlp_bwd_pmc.json
 set -u
 TAG=${1:-r02_mlp_bwd}
@@ -16,7 +16,7 @@ run() {  # variant, pass-name, rocprofv3 args...
   echo "rc=$rc" | tee -a "$OUT/collect.log"
   return $rc
 }
-for v in ${VARIANTS:-1 3 5}; do
+for v in ${VARIANTS:-1 2 0}; do
   run $v stats --kernel-trace --stats &&
   run $v pmc_time --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE &&
   run $v pmc_inst --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE || exit 1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fused producer-MLP backward (csrc/mlp_bwd.hip): the all-f32-MFMA kernel (mlp_bwd_variant=1) vs the split-bf16 kernels
-(3: steps 1, 2, 6 on the bf16 matrix pipe; 5: all steps, operands on dual-use LDS planes), interleaved in one process, at the Temporal-Order training shape
+(2: steps 1, 2, 6 on the bf16 matrix pipe; 3 = auto: all steps, operands on dual-use LDS planes), interleaved in one process, at the Temporal-Order training shape
 (E = h = 32, g with 8 outputs + 14 link MLPs with 15, T = B*N tokens) and at the Pathfinder shape (E = 32, h = 128).
 Gradients of both variants are compared with float64 autograd through nn modules on a slice of the tokens.
 
@@ -19,8 +19,7 @@ import sparsefactorization_amd as sfa  # noqa: E402
 from sparsefactorization_amd import fused_mlp  # noqa: E402
 
 
-LABELS = {0: "auto", 1: "f32-MFMA", 2: "split-bf16 all steps (re-split)", 3: "split-bf16 steps 1,2,6",
-          4: "split-bf16 steps 1,2,6, 4 waves x 2 workgroups/CU", 5: "split-bf16 on dual-use planes"}
+LABELS = {0: "auto", 1: "f32-MFMA", 2: "split-bf16 steps 1,2,6", 3: "split-bf16 on dual-use planes"}
 
 
 def make(E, h, outs, dev, seed=0):
@@ -54,7 +53,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=40 * 16384)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--variants", type=int, nargs="+", default=[1, 3, 5, 0],
+    ap.add_argument("--variants", type=int, nargs="+", default=[1, 2, 0],
                     help="mlp_bwd_variant values to interleave; speed-ups are relative to the first")
     args = ap.parse_args()
     dev = torch.device("cuda:0")

@@ -6,7 +6,7 @@
 #include <cstdio>
 #include <vector>
 
-std::atomic<int> psf_g_mlp_bwd_variant{5};
+std::atomic<int> psf_g_mlp_bwd_variant{3};
 extern "C" int psf_internal_fail(int code, const char* message) {
   std::printf("psf_internal_fail(%d): %s\n", code, message);
   return code;
@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int variant : {5, 3, 5}) {
+  for (int variant : {3, 2, 3}) {
     psf_g_mlp_bwd_variant.store(variant);
     for (int it = 0; it < 3; ++it)
       if (psf_mlp_bwd_f32(X, T, E, K, A.data(), a.data(), B.data(), h.data(), O.data(), dY.data(), dX, dA.data(), da.data(),

@@ -31,14 +31,14 @@
 //
 // Limits: E <= 32 (multiple of 4), h <= 128, O <= 32, K <= 32; anything else stays on autograd.
 //
-// Three kernels share that structure (knob mlp_bwd_variant; 0 = auto -> the third):
-//   mlp_bwd_k      (1) all five GEMMs on v_mfma_f32_32x32x2_f32. That instruction occupies the vector ALU's datapath
+// Three kernels share that structure (knob mlp_bwd_variant = 1, 2, 3; 0 = auto -> 3):
+//   mlp_bwd_k      all five GEMMs on v_mfma_f32_32x32x2_f32. That instruction occupies the vector ALU's datapath
 //                  (profiles/r01_mfmalab.log: MFMA cycles and VALU cycles add), so a tile-unit costs 72 x 64 MFMA
 //                  cycles PLUS ~2400 VALU cycles: 1.17 ms at Order N=16384, B=40.
-//   mlp_bwd_x3_k   (2, 3, 4) steps 1, 2, 6 (optionally all) on v_mfma_f32_32x32x16_bf16 with the exact three-way bf16 split
-//                  of mlp_x3_common.h; operands of the token contractions are re-laid through f32 LDS tiles and split again
-//                  per orientation — or stay on the f32 instruction: 1.03 ms.
-//   mlp_bwd_x3p_k  (5, default) all five GEMMs on the bf16 pipe, every operand split ONCE into bf16 planes in LDS that serve
+//   mlp_bwd_x3_k   steps 1, 2, 6 on v_mfma_f32_32x32x16_bf16 with the exact three-way bf16 split
+//                  of mlp_x3_common.h; the token contractions (steps 4, 5) stay on the f32 instruction, their operands
+//                  re-laid through f32 LDS tiles: 1.03 ms.
+//   mlp_bwd_x3p_k  (default) all five GEMMs on the bf16 pipe, every operand split ONCE into bf16 planes in LDS that serve
 //                  both orientations (row reads and ds_read_b64_tr_b16, mlp_planes.h): 0.86 ms. See the comment above it.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -483,18 +483,18 @@ __device__ __forceinline__ Frag3 load_frag3(const unsigned char* p, int term_str
 }
 
 // 512 threads: eight waves share one unit image. launch_bounds(512, 1): one workgroup (two waves per SIMD) per CU,
-// <= 256 registers per lane.
-// FULL: steps 4 and 5 (the contractions over tokens) on the bf16 pipe as well; otherwise they stay on the f32 instruction.
-// NW: waves per workgroup. 8 = one workgroup per CU, two image buffers; 4 = two workgroups per CU (their phases drift
-// apart, unlike the two waves of one workgroup that meet at every barrier) with ONE image buffer each.
-template <int TPW, int NDY, bool FULL, int NW>
-__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2)
+// <= 256 registers per lane. Steps 4 and 5 (the contractions over tokens) stay on the f32 instruction. (Builds with those
+// two steps on bf16 through a second split per orientation, and with four waves per workgroup and two workgroups per CU,
+// were measured and removed: 1.90 ms spilled / no gain)
+template <int TPW, int NDY>
+__global__ void __launch_bounds__(512, 1)
 mlp_bwd_x3_k(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int c = lane & 31, half = lane >> 5;
   constexpr int SD = NDY == 8 ? 17 : 33;      // odd strides: conflict-free by row and by column
-  constexpr int kImgBufs = (NDY == 8 && NW == 8) ? 2 : 1;  // O > 16 (wider dY tiles) or 4 waves: one image buffer (LDS)
+  constexpr int NW = 8;
+  constexpr int kImgBufs = NDY == 8 ? 2 : 1;  // O > 16 (wider dY tiles): one image buffer (LDS)
   constexpr int NS2 = NDY == 8 ? 1 : 2;       // k-steps of step 2 (16 outputs each)
   constexpr int kWaveLds = TPW * 32 * 33 + 32 * SD + 32 * 33;
   float* lds_f = reinterpret_cast<float*>(lds_raw + kImgBufs * kXImgBytes);
@@ -633,47 +633,7 @@ mlp_bwd_x3_k(const BwdArgs a) {
           g[r] = acc3[r] * dy.x;  // G = dHpre^T
           g[r + 1] = acc3[r + 1] * dy.y;
         }
-        if constexpr (FULL) {
-          // 4. dB^T[j][o] += Hpost^T[j][tok] · dY[tok][o]: contraction over the tile's 32 tokens, on the bf16 pipe.
-          //    A operand = 8 consecutive tokens of hidden row j = c from S2 [j][tok]; B operand = the same tokens of output
-          //    column o = c from the dY tile; both split here. All 32 LDS reads of the step are issued together (the f32
-          //    form read two operands per MFMA and waited for them: one exposed LDS round trip per instruction).
-          {
-            float dbs = 0.f;
-  #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              float hv[8], yv[8];
-  #pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                const int tok = 16 * s + 8 * half + i;
-                hv[i] = S2[c * 33 + tok];
-                yv[i] = c < O ? S1[tok * SD + c] : 0.f;
-                dbs += yv[i];
-              }
-              dBT = mfma6(split_pack8_pk(hv), split_pack8_pk(yv), dBT);
-            }
-            db += dbs;
-          }
-          // 5. dA[j][e] += G[j][tok] · X[tok][e]   (G re-laid through S2; X^T fragments split from the wave's X tile)
-  #pragma unroll
-          for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 33 + c] = g[r];
-          {
-            float das = 0.f;
-  #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              float gv[8], xv[8];
-  #pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                const int tok = 16 * s + 8 * half + i;
-                gv[i] = S2[c * 33 + tok];
-                xv[i] = SX[tp * 32 * 33 + tok * 33 + c];
-                das += gv[i];
-              }
-              dA = mfma6(split_pack8_pk(gv), split_pack8_pk(xv), dA);
-            }
-            da += das;
-          }
-        } else {
+        {
           // 4. dB^T += Hpost^T[j = c][tok = 2kk+half] · dY[tok = 2kk+half][o = c] on the f32 instruction. (Reading the
           //    operands of four MFMAs ahead of them was tried: at two tiles per wave the 16 extra live registers go to
           //    scratch, 1.05 -> 1.52 ms.)
@@ -1289,9 +1249,8 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
     args.unit[u] = u < p.U ? ((uint32_t)p.unit_k[u] | ((uint32_t)p.unit_hb[u] << 8)) : 0u;
   }
   const int variant = psf_g_mlp_bwd_variant.load();
-  const bool x3 = variant != 1;         // split-bf16 kernels unless the f32 one is forced
-  const bool four_waves = variant == 4;  // split-bf16 kernel on 256-thread workgroups, two per CU
-  const bool planes = variant == 0 || variant >= 5;  // split-bf16 kernel on dual-use LDS planes (the default)
+  const bool x3 = variant == 2;                      // the first split-bf16 form (steps 1, 2, 6 on bf16)
+  const bool planes = variant == 0 || variant == 3;  // split-bf16 on dual-use LDS planes (the default)
   if (planes && dX && (reinterpret_cast<uintptr_t>(dX) & 15) != 0)
     return psf_internal_fail(PSF_E_ALIGN, "psf_mlp_bwd: dX must be 16-byte aligned");
   float* ws = reinterpret_cast<float*>(workspace);
@@ -1301,7 +1260,7 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   args.partials = ws + (int64_t)p.U * kImgFloatsMax;
   args.stage1 = args.partials + (p.G > p.G8 ? p.G : p.G8) * p.U * kPart;
   args.T = T;
-  args.G = (x3 && !four_waves) ? p.G8 : p.G;
+  args.G = (x3 || planes) ? p.G8 : p.G;
   args.E = E;
   args.K = K;
   args.U = p.U;
@@ -1333,23 +1292,11 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
       launch_planes(mlp_bwd_x3p_k<1, 16>, 8);  // make_plan: one tile per wave when an output is wider than 16
     }
   } else if (x3) {
-    const bool full = variant == 2;
-    if (four_waves) {
-      if (max_o <= 16) {
-        if (p.tpw == 2) launch(mlp_bwd_x3_k<2, 8, false, 4>, 4, kXImgBytes, 2, 17, 1);
-        else launch(mlp_bwd_x3_k<1, 8, false, 4>, 4, kXImgBytes, 1, 17, 1);
-      } else {
-        if (p.tpw == 2) launch(mlp_bwd_x3_k<2, 16, false, 4>, 4, kXImgBytes, 2, 33, 1);
-        else launch(mlp_bwd_x3_k<1, 16, false, 4>, 4, kXImgBytes, 1, 33, 1);
-      }
-    } else if (max_o <= 16) {
-      if (p.tpw8 == 2) launch(mlp_bwd_x3_k<2, 8, false, 8>, 8, kXImgBytes, 2, 17, 2);
-      else if (full) launch(mlp_bwd_x3_k<1, 8, true, 8>, 8, kXImgBytes, 1, 17, 2);
-      else launch(mlp_bwd_x3_k<1, 8, false, 8>, 8, kXImgBytes, 1, 17, 2);
+    if (max_o <= 16) {
+      if (p.tpw8 == 2) launch(mlp_bwd_x3_k<2, 8>, 8, kXImgBytes, 2, 17, 2);
+      else launch(mlp_bwd_x3_k<1, 8>, 8, kXImgBytes, 1, 17, 2);
     } else {
-      if (p.tpw8 == 2) launch(mlp_bwd_x3_k<2, 16, false, 8>, 8, kXImgBytes, 2, 33, 1);
-      else if (full) launch(mlp_bwd_x3_k<1, 16, true, 8>, 8, kXImgBytes, 1, 33, 1);
-      else launch(mlp_bwd_x3_k<1, 16, false, 8>, 8, kXImgBytes, 1, 33, 1);
+      launch(mlp_bwd_x3_k<1, 16>, 8, kXImgBytes, 1, 33, 1);  // make_plan: one tile per wave when an output is wider than 16
     }
   } else if (max_o <= 16) {
     if (p.tpw == 2) launch(mlp_bwd_k<2, 8>, 4, kImg * sizeof(float), 2, 17, 2);

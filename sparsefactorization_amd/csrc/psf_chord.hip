@@ -66,8 +66,8 @@ thread_local bool t_walk_backwards = false;  // set by chain_impl around the lau
 // Fused producer MLPs: 0 = auto (split-bf16 kernel of mlp_fwd_x3.hip where it applies, else the f32-MFMA kernel of
 // mlp_fwd.hip with all images LDS-resident when they fit), 1 = f32 MFMA streaming, 2 = f32 MFMA resident, 3 = split-bf16
 std::atomic<int> psf_g_mlp_variant{0};
-// Fused producer MLP backward: 0 = auto, 1 = all-f32-MFMA kernel, 2 = split-bf16 kernel with all five GEMMs on the bf16
-// matrix pipe, 3 = split-bf16 kernel with steps 4 and 5 left on the f32 instruction
+// Fused producer MLP backward: 0 = auto (= 3), 1 = all-f32-MFMA kernel, 2 = split-bf16 kernel with steps 4 and 5 left on
+// the f32 instruction, 3 = split-bf16 kernel on dual-use LDS planes (all five GEMMs on the bf16 matrix pipe)
 std::atomic<int> psf_g_mlp_bwd_variant{0};
 namespace {
 
@@ -88,7 +88,7 @@ Knob g_knobs[] = {
     {"chain_fused", &g_chain_fused, 0, 1},
     {"chain_cc", &g_chain_cc, 0, 1},
     {"mlp_variant", &psf_g_mlp_variant, 0, 3},
-    {"mlp_bwd_variant", &psf_g_mlp_bwd_variant, 0, 5},
+    {"mlp_bwd_variant", &psf_g_mlp_bwd_variant, 0, 3},
 };
 
 int ceil_log2(int64_t x) {

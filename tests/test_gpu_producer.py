@@ -183,16 +183,20 @@ MLP_TRAIN_CASES = [  # (T, E, [(h, out), ...])
 ]
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["bwd_auto_planes", "bwd_f32_mfma", "bwd_bf16x3_resplit", "bwd_bf16x3_steps126", "bwd_bf16x3_steps126_4waves"])
+@pytest.fixture(params=[0, 1, 2], ids=["bwd_auto_bf16x3_planes", "bwd_f32_mfma", "bwd_bf16x3_steps126"])
 def mlp_bwd_variant(request):
-    """Every kernel of psf_mlp_bwd_f32 (csrc/mlp_bwd.hip): the all-f32-MFMA one and the exact split-bf16 ones."""
+    """Every kernel of psf_mlp_bwd_f32 (csrc/mlp_bwd.hip): the exact split-bf16 ones (on dual-use LDS planes = the default; the
+    first form with the token contractions on f32) and the all-f32-MFMA one."""
     import sparsefactorization_amd as sfa
     sfa.set_tuning("mlp_bwd_variant", request.param)
     yield request.param
     sfa.set_tuning("mlp_bwd_variant", 0)
 
 
-@pytest.mark.parametrize("T,E,layers", MLP_TRAIN_CASES + [(131072 + 37, 32, [(32, 8), (32, 15), (32, 15)])])  # last: two tiles per wave
+@pytest.mark.parametrize("T,E,layers", MLP_TRAIN_CASES + [
+    (131072 + 37, 32, [(32, 8), (32, 15), (32, 15)]),  # long input: two tiles per wave
+    (131072 + 5, 32, [(32, 32), (64, 17)]),            # long input, outputs wider than 16: one tile per wave
+])
 def test_fused_mlp_backward_matches_float64_autograd(gpu, T, E, layers, mlp_bwd_variant):
     """psf_mlp_fwd_f32 + psf_mlp_bwd_f32 under autograd vs float64 autograd through the nn modules they replace.
     Tolerance 2e-5 of max|ref| per tensor: f32 sums over up to T products plus a 1.5e-7 erf approximation."""
