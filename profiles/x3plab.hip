@@ -1,6 +1,6 @@
 // x3plab.hip — phase timing of mlp_bwd_x3p_k (csrc/mlp_bwd.hip built with PSF_X3P_TRACE): shader-clock timestamps that
 // every wave of one workgroup takes at the phase boundaries of one unit, at the Temporal-Order training shape.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o /tmp/x3plab profiles/x3plab.hip && /tmp/x3plab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -o /tmp/x3plab profiles/x3plab.hip && /tmp/x3plab
 #define PSF_X3P_TRACE 1
 #include <atomic>
 #include <cstdio>
@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     std::printf("variant %d: %.3f ms per call\n", variant, ms / 10);
   }
-  unsigned long long tr[12][32];
+  unsigned long long tr[8][32];
   CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(psf_x3p_trace), sizeof(tr)));
   const char* names[25] = {"unit top", "after B0", "t0 start", "t0 dY split+prefetch issued", "t0 steps 1,2 issued", "t0 GELU done",
                            "t0 step 4 issued", "", "", "", "t1 start", "t1 dY split+prefetch issued", "t1 steps 1,2 issued",

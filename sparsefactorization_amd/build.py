@@ -68,7 +68,9 @@ def _units():
              (os.path.join(OBJ_DIR, "adam.o"), os.path.join(CSRC, "adam.hip"), []),
              (os.path.join(OBJ_DIR, "mlp_fwd.o"), os.path.join(CSRC, "mlp_fwd.hip"), []),
              (os.path.join(OBJ_DIR, "mlp_fwd_x3.o"), os.path.join(CSRC, "mlp_fwd_x3.hip"), []),
-             (os.path.join(OBJ_DIR, "mlp_bwd.o"), os.path.join(CSRC, "mlp_bwd.hip"), [])]
+             # -fno-slp-vectorize: keeps hipcc from re-packing the scalar f32 arithmetic of the bf16-pipe kernel into
+             # v_pk_* instructions, which are slow beside MFMAs (mlp_bwd.hip, gelu_and_grad1)
+             (os.path.join(OBJ_DIR, "mlp_bwd.o"), os.path.join(CSRC, "mlp_bwd.hip"), ["-fno-slp-vectorize"])]
     for t in WIN_TGS:
         units.append((os.path.join(OBJ_DIR, f"fwd_window_tgs{t}.o"), os.path.join(CSRC, "fwd_window_inst.hip"),
                       [f"-DPSF_TGS={t}"]))

@@ -130,6 +130,19 @@ __global__ void __launch_bounds__(256) x3_pack_k(const X3Args a) {
   }
 }
 
+#ifdef PSF_X3F_TRACE  // profiles/x3flab.hip: shader-clock timestamps of one unit of one workgroup, per wave
+__device__ unsigned long long psf_x3f_trace[4][16];
+#define PSF_FTRACE(slot)                                                       \
+  do {                                                                         \
+    if (trace_on) {                                                            \
+      const unsigned long long t_ = clock64();                                 \
+      if (lane == 0) psf_x3f_trace[wv][(slot)] = t_;                           \
+    }                                                                          \
+  } while (0)
+#else
+#define PSF_FTRACE(slot) do { } while (0)
+#endif
+
 template <int TPW>
 __global__ void __launch_bounds__(256, 2)  // <= 256 registers: two workgroups (two waves per SIMD) per CU
 x3_fwd_k(const X3Args a) {
@@ -190,9 +203,12 @@ x3_fwd_k(const X3Args a) {
     // LDS tile buffer and its global stores are issued at the START of the next unit, a whole unit of arithmetic
     // ahead of the next barrier.
     int pend = -1;  // MLP whose Y tiles are parked in sw (wave-uniform)
-    // Element e = lane + 64 i of a tile's burst sits at sw[tok * 33 + o], (tok, o) = divmod(e, O). The offsets depend
-    // on O only (two values per block in PSFNet: g, then the link MLPs), so they are kept in registers: stepping
-    // them per element cost ~200 integer instructions per tile in a kernel that is VALU-issue-bound.
+    // A tile's burst is 32 O contiguous floats, 16-byte aligned when Y is; lane l stores elements 4 (l + 64 j) .. + 3 as ONE
+    // dwordx4 (j = 0, 1; O > 16: up to 4). Sixteen dword stores per flush made the flush a fifth of a unit (1,950 of 9,200
+    // clocks, profiles/r02ai_x3flab.log): a vector store costs the same issue time whatever its width. Element e sits at
+    // sw[tok * 33 + o], (tok, o) = divmod(e, O); the offsets depend on O only (two values per block in PSFNet: g, then the
+    // link MLPs), so the eight of j = 0, 1 are kept in registers (stepping them per element cost ~200 integer instructions
+    // per tile in a kernel that is VALU-issue-bound).
     int yoff[8], yoff_O = -1;
     auto flush = [&]() {
       const X3Mlp& dp = a.m[pend];
@@ -200,11 +216,12 @@ x3_fwd_k(const X3Args a) {
       if (O != yoff_O) {  // wave-uniform
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const int e = lane + 64 * i, tok = e / O;
+          const int e = 4 * (lane + 64 * (i >> 2)) + (i & 3), tok = e / O;
           yoff[i] = (tok < 32 ? tok : 31) * 33 + (e - tok * O);  // clamped: lanes past the tile read a valid address
         }
         yoff_O = O;
       }
+      const bool vec_ok = (reinterpret_cast<uintptr_t>(dp.Y) & 15) == 0;  // wave-uniform
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp) {
         if (t0[tp] >= a.T) continue;  // wave-uniform
@@ -212,26 +229,45 @@ x3_fwd_k(const X3Args a) {
         const int64_t rem = a.T - t0[tp];
         const int n_el = (int)(rem < 32 ? rem : 32) * O;  // one contiguous burst of rows*O floats
         float* __restrict__ yt = dp.Y + t0[tp] * O;
-        // all LDS reads of a batch of 8 are issued before its first store (a rolled loop paid one LDS round trip per
-        // element)
-        float v[8];
+        if (vec_ok && rem >= 32) {
+          // all LDS reads are issued before the first store
+          float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = st[yoff[i]];
+          for (int i = 0; i < 8; ++i) v[i] = st[yoff[i]];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (lane + 64 * i < n_el) yt[lane + 64 * i] = v[i];
-        for (int e = lane + 512; e < n_el; e += 64) {  // O > 16 only
-          const int tok = e / O;
-          yt[e] = st[tok * 33 + (e - tok * O)];
+          for (int j = 0; j < 2; ++j)
+            if (4 * (lane + 64 * j) < n_el)
+              *reinterpret_cast<float4*>(yt + 4 * (lane + 64 * j)) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+          for (int e = 4 * (lane + 128); e < n_el; e += 256) {  // O > 16 only
+            float w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int tok = (e + i) / O;
+              w[i] = st[tok * 33 + (e + i - tok * O)];
+            }
+            *reinterpret_cast<float4*>(yt + e) = make_float4(w[0], w[1], w[2], w[3]);
+          }
+        } else {  // the partial tile, or an unaligned Y: element by element
+          for (int e = lane; e < n_el; e += 64) {
+            const int tok = e / O;
+            yt[e] = st[tok * 33 + (e - tok * O)];
+          }
         }
       }
       pend = -1;
     };
 
     for (int u = 0; u < U; ++u) {
+#ifdef PSF_X3F_TRACE
+      const bool trace_on = blockIdx.x == 700 && u == 5;
+#endif
+      PSF_FTRACE(0);
       __syncthreads();  // image u has landed (hipcc drains vmcnt before the barrier); unit u-1 is finished
+      PSF_FTRACE(1);
       if (u + 1 < U) stage(u + 1);
+      PSF_FTRACE(6);
       if (pend >= 0) flush();
+      PSF_FTRACE(2);
       const unsigned char* img = lds_raw + (u & 1) * kImgBytes;
       const float* sa = reinterpret_cast<const float*>(img + kOffSa);
       const float* sb = reinterpret_cast<const float*>(img + kOffSb);
@@ -257,10 +293,11 @@ x3_fwd_k(const X3Args a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc2[tp][r] = sb[cd_row(r, half)];
       }
+      PSF_FTRACE(3);
       auto half_gelu = [&](const f32x16& acc1, int s) {  // GELU + split of registers 8s..8s+7: one B fragment
         float g[8];
 #pragma unroll
-        for (int i = 0; i < 8; i += 2) {
+        for (int i = 0; i < 8; i += 2) {  // (scalar f32 instead of packed: no gain here, profiles/r02ai_x3flab.log)
           const f32x2 y = gelu2(f32x2{acc1[8 * s + i], acc1[8 * s + i + 1]});
           g[i] = y.x;
           g[i + 1] = y.y;
@@ -316,6 +353,7 @@ x3_fwd_k(const X3Args a) {
         }
       }
 
+      PSF_FTRACE(4);
       if (last) {  // park the Y^T tiles as [tok][o] (stride 33); stored at the start of the next unit
 #pragma unroll
         for (int tp = 0; tp < TPW; ++tp)
@@ -323,6 +361,7 @@ x3_fwd_k(const X3Args a) {
           for (int r = 0; r < 16; ++r) sw[tp * kScr + c * 33 + cd_row(r, half)] = acc2[tp][r];
         pend = (int)(a.unit[u] & 0xff);
       }
+      PSF_FTRACE(5);
     }
     if (pend >= 0) flush();
   }

@@ -90,9 +90,10 @@ __device__ __forceinline__ Split16 split16(const float (&v)[16]) {
 #pragma unroll
   for (int i = 0; i < 16; i += 2) {
     const uint32_t a0 = __float_as_uint(v[i]) & 0xffff0000u, a1 = __float_as_uint(v[i + 1]) & 0xffff0000u;
-    const f32x2 r1 = f32x2{v[i], v[i + 1]} - f32x2{__uint_as_float(a0), __uint_as_float(a1)};
-    const uint32_t b0 = __float_as_uint(r1.x) & 0xffff0000u, b1 = __float_as_uint(r1.y) & 0xffff0000u;
-    const f32x2 r2 = r1 - f32x2{__uint_as_float(b0), __uint_as_float(b1)};
+    // scalar subtractions: packed f32 VALU is slow beside the sibling wave's MFMAs (see gelu_and_grad1 in mlp_bwd.hip)
+    const float r1x = v[i] - __uint_as_float(a0), r1y = v[i + 1] - __uint_as_float(a1);
+    const uint32_t b0 = __float_as_uint(r1x) & 0xffff0000u, b1 = __float_as_uint(r1y) & 0xffff0000u;
+    const f32x2 r2 = {r1x - __uint_as_float(b0), r1y - __uint_as_float(b1)};
     r.d[0][i >> 1] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
     r.d[1][i >> 1] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
     r.d[2][i >> 1] = __builtin_amdgcn_perm(__float_as_uint(r2.y), __float_as_uint(r2.x), 0x07060302u);
