@@ -6,6 +6,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -26,7 +27,8 @@ def main():
         for f in glob.glob(os.path.join(vdir, "stats", "**", "*kernel_stats.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 if main_kernel(row["Name"]):
-                    entry["kernel"] = row["Name"].split("(")[0][-60:]
+                    m = re.search(r"mlp_bwd\w*(<[^>]*>)?", row["Name"])
+                    entry["kernel"] = m.group(0) if m else row["Name"][:80]
                     entry["avg_us"] = float(row["AverageNs"]) / 1e3
                     entry["calls"] = int(row["Calls"])
         for f in glob.glob(os.path.join(vdir, "pmc_*", "**", "*counter_collection.csv"), recursive=True):

@@ -246,6 +246,40 @@ def test_fused_mlp_backward_partial_outputs_and_frozen_input(gpu):
         assert all(float(p.grad.abs().max()) == 0.0 for p in b.parameters())
 
 
+def test_fused_mlp_backward_refuses_unaligned_dx(gpu):
+    """The default backward kernel stores dX as 16-byte vectors: a misaligned dX is an error, not a slow path."""
+    import ctypes
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import _lib, fused_mlp
+    T, E, h, O = 256, 32, 32, 15
+    x = torch.randn(T, E, device=gpu)
+    params = [torch.randn(h, E, device=gpu), torch.randn(h, device=gpu), torch.randn(O, h, device=gpu), torch.randn(O, device=gpu)]
+    gy = torch.randn(T, O, device=gpu)
+    dX_ok, grads_ok = fused_mlp._backward_raw(x, params, [gy], True)
+    lib = _lib.load()
+    hs, Os = (ctypes.c_int32 * 1)(h), (ctypes.c_int32 * 1)(O)
+    ws_bytes = lib.psf_mlp_bwd_workspace(T, E, 1, hs, Os)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=gpu)
+    grads = [torch.empty_like(p) for p in params]
+    buf = torch.empty(T * E + 1, device=gpu)
+    dX = buf[1:]  # 4 bytes past a 16-byte boundary
+    assert dX.data_ptr() % 16 == 4
+    P = fused_mlp._ptrs
+    rc = lib.psf_mlp_bwd_f32(x.data_ptr(), T, E, 1, P([params[0]]), P([params[1]]), P([params[2]]), hs, Os, P([gy]), dX.data_ptr(),
+                             P([grads[0]]), P([grads[1]]), P([grads[2]]), P([grads[3]]), ws.data_ptr(), ws_bytes,
+                             torch.cuda.current_stream(gpu).cuda_stream)
+    assert rc != 0 and b"dX must be 16-byte aligned" in lib.psf_last_error()
+    sfa.set_tuning("mlp_bwd_variant", 1)  # the f32-MFMA kernel stores dX element-wise: same call, same numbers
+    try:
+        rc = lib.psf_mlp_bwd_f32(x.data_ptr(), T, E, 1, P([params[0]]), P([params[1]]), P([params[2]]), hs, Os, P([gy]), dX.data_ptr(),
+                                 P([grads[0]]), P([grads[1]]), P([grads[2]]), P([grads[3]]), ws.data_ptr(), ws_bytes,
+                                 torch.cuda.current_stream(gpu).cuda_stream)
+        assert rc == 0
+    finally:
+        sfa.set_tuning("mlp_bwd_variant", 0)
+    assert rel_inf(dX.reshape(T, E).cpu().numpy(), dX_ok.cpu().numpy()) <= 2e-5
+
+
 def test_stacked_first_layer_matches_per_module_path(gpu):
     """ListOps widths (E = 512, out = 128: outside the fused kernels): stacking the first layers into one Linear
     is the same function and has the same gradients as calling the modules one by one."""
