@@ -598,10 +598,10 @@ def test_errors(gpu):
         sfa.spmm(idx, W.reshape(2, 64), 16, 8, V)
 
 
-@pytest.mark.parametrize("count", [1, 2, 7, 8, 9, 15, 16, 23, 32])
+@pytest.mark.parametrize("count", [1, 2, 7, 8, 9, 15, 16, 17, 23, 31, 32])
 def test_sum_tensors_is_the_left_to_right_sum(gpu, count):
     """psf_sum_tensors_f32 (csrc/sum_tensors.hip): ((t0 + t1) + t2) + ... bit for bit, for every pass structure
-    (8 sources in the first pass, 7 per later pass) — the residual gradient of the chain is summed with it."""
+    (16 sources in the first pass, 15 per later pass) — the residual gradient of the chain is summed with it."""
     from sparsefactorization_amd.chord import _sum_tensors
     g = torch.Generator(device=gpu).manual_seed(count)
     terms = [torch.randn(3, 1001, 8, device=gpu, generator=g) * (10.0 ** (i % 5 - 2)) for i in range(count)]
