@@ -69,6 +69,7 @@ constexpr int kOffSa = 32 * 33;
 constexpr int kOffSb = kOffSa + 32;
 constexpr int kPart = 1024 + 1024 + 64 + 64;  // per (group, unit): dA [j][e] | dB^T [j][o] | da [half][j] | db [half][o]
 constexpr int kSlices = 64;                   // stage-1 reduction slices
+static_assert(kPart % 4 == 0, "the stage-1 reduction reads the partial sums as float4");
 
 // split-bf16 unit image (bytes), every part already in MFMA operand order:
 //   A terms   3 x [32 j][80 B: 32 e bf16 + pad]            step 1, A operand (8 consecutive e of row j per ds_read_b128)
@@ -1151,17 +1152,46 @@ mlp_bwd_x3p_k(const BwdArgs a) {
   }
 }
 
-// stage 1: R1[s][i] = sum over the groups of slice s of P[g][i]   (i < U*kPart; fixed order)
+// stage 1: R1[s][i] = sum over the groups of slice s of P[g][i]   (i < U*kPart; fixed order: four interleaved running sums
+// g = g0 + 0, 1, 2, 3 (mod 4), then ((s0 + s1) + s2) + s3). float4 per thread and four loads in flight per running sum: the
+// rolled scalar loop it replaces had one dependent load in flight per thread (49 us for 167 MB at Order N=16384, B=40).
 __global__ void __launch_bounds__(256) mlp_bwd_reduce1_k(const BwdArgs a) {
-  const int64_t n = (int64_t)a.U * kPart;
+  const int64_t n4 = (int64_t)a.U * kPart / 4;  // kPart % 4 == 0
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n4) return;
   const int s = blockIdx.y;
   const int64_t per = (a.G + kSlices - 1) / kSlices;
   const int64_t g0 = s * per, g1 = g0 + per < a.G ? g0 + per : a.G;
-  float acc = 0.f;
-  for (int64_t g = g0; g < g1; ++g) acc += a.partials[g * n + i];
-  a.stage1[s * n + i] = acc;
+  const float4* __restrict__ P = reinterpret_cast<const float4*>(a.partials);
+  float4 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int64_t g = g0;
+  for (; g + 4 <= g1; g += 4) {
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = P[(g + q) * n4 + i];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[q].x += v[q].x;
+      acc[q].y += v[q].y;
+      acc[q].z += v[q].z;
+      acc[q].w += v[q].w;
+    }
+  }
+  for (int q = 0; g < g1; ++g, ++q) {
+    const float4 v = P[g * n4 + i];
+    acc[q].x += v.x;
+    acc[q].y += v.y;
+    acc[q].z += v.z;
+    acc[q].w += v.w;
+  }
+  float4 r;
+  r.x = ((acc[0].x + acc[1].x) + acc[2].x) + acc[3].x;
+  r.y = ((acc[0].y + acc[1].y) + acc[2].y) + acc[3].y;
+  r.z = ((acc[0].z + acc[1].z) + acc[2].z) + acc[3].z;
+  r.w = ((acc[0].w + acc[1].w) + acc[2].w) + acc[3].w;
+  reinterpret_cast<float4*>(a.stage1)[s * n4 + i] = r;
 }
 
 // stage 2: sum the slices and scatter into the unpadded gradient tensors
@@ -1321,7 +1351,7 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   }
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
   const int64_t n = (int64_t)p.U * kPart;
-  hipLaunchKernelGGL(mlp_bwd_reduce1_k, dim3((unsigned)((n + 255) / 256), kSlices), dim3(256), 0, s, args);
+  hipLaunchKernelGGL(mlp_bwd_reduce1_k, dim3((unsigned)((n / 4 + 255) / 256), kSlices), dim3(256), 0, s, args);
   hipLaunchKernelGGL(mlp_bwd_reduce2_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, args);
   e = hipGetLastError();
   return e == hipSuccess ? PSF_OK : psf_internal_fail((int)e, hipGetErrorString(e));
