@@ -761,9 +761,9 @@ mlp_bwd_x3_k(const BwdArgs a) {
 //               transposed read = step-4 / step-5 A operand. G's packed terms ARE the step-6 B fragments.
 //   A_u         one [j][e] plane per term: row read = step-1 A operand, transposed read in accumulator order = step-6 A
 //               operand (the A^T copy of the x3 image is gone: 12.4 KB per unit image instead of 20 KB).
-// The scratch planes are used one term at a time (write term t, read it back transposed into registers, write term t+1
-// over it: LDS operations of one wave execute in order), so a wave needs 2 x 2 KB of scratch next to its X planes and two
-// tiles per wave x eight waves x two image buffers fit 160 KB.
+// A wave has TWO 2 KB scratch planes next to its X planes; the terms go through them two at a time and are read back
+// transposed into registers (a plane is rewritten as soon as its reads are issued: LDS operations of one wave execute in
+// order), so two tiles per wave x eight waves x two image buffers fit 160 KB.
 // da_u = G 1: three more MFMAs per k-step on G's transposed terms against a fragment of ones (every column of the result
 // is da_u; the matrix pipe has the slack, the VALU does not). db: per-lane sums of the dY registers, reduced over the 32
 // token lanes once per unit (DPP), in the ht = 0 unit only.
