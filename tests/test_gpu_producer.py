@@ -228,6 +228,44 @@ def test_fused_mlp_backward_matches_float64_autograd(gpu, T, E, layers, mlp_bwd_
     assert all(torch.equal(u, v) for u, v in zip(first, again))
 
 
+def _random_mlp_case(seed):
+    rng = np.random.default_rng(seed)
+    E = int(rng.choice([4, 8, 12, 16, 20, 24, 28, 32]))
+    K = int(rng.integers(1, 5))
+    layers = [(int(rng.choice([1, 7, 16, 31, 32, 33, 64, 65, 96, 127, 128])), int(rng.choice([1, 2, 8, 15, 16, 17, 24, 31, 32])))
+              for _ in range(K)]
+    T = int(rng.choice([1, 31, 32, 33, 255, 256, 257, 1000, 4096, 4097, 9999]))
+    return T, E, layers
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fused_mlp_forward_backward_random_shapes(gpu, seed):
+    """The default kernels (split-bf16 forward; backward on dual-use LDS planes) over seeded random widths: E in 4..32,
+    hidden widths around the 32-row unit boundaries, outputs around the 16-output boundary of the dY prefetch, token
+    counts around the 32-token tile boundary — every output and every gradient vs float64 autograd."""
+    import copy
+    from sparsefactorization_amd import fused_mlp
+    from sparsefactorization_amd.psfnet import MLPBlock
+    T, E, layers = _random_mlp_case(seed)
+    torch.manual_seed(seed)
+    blocks = [MLPBlock([h, 'GELU'], E, o).to(gpu) for h, o in layers]
+    ref_blocks = [copy.deepcopy(b).double() for b in blocks]
+    x = (torch.randn(T, E, device=gpu) * 1.5).requires_grad_(True)
+    xr = x.detach().double().requires_grad_(True)
+    gys = [torch.randn(T, o, device=gpu) for _, o in layers]
+    assert fused_mlp.trainable(x, blocks), (T, E, layers)
+    ys = fused_mlp.fused_mlp_apply(x, blocks)
+    refs = [b(xr) for b in ref_blocks]
+    for y, r in zip(ys, refs):
+        assert rel_inf(y.detach().cpu().numpy(), r.detach().cpu().numpy()) <= 1e-5, (T, E, layers)
+    torch.autograd.backward(ys, gys)
+    torch.autograd.backward(refs, [g.double() for g in gys])
+    assert rel_inf(x.grad.cpu().numpy(), xr.grad.cpu().numpy()) <= 2e-5, (T, E, layers)
+    for b, rb in zip(blocks, ref_blocks):
+        for (name, p), (_, rp) in zip(b.named_parameters(), rb.named_parameters()):
+            assert rel_inf(p.grad.cpu().numpy(), rp.grad.cpu().numpy()) <= 2e-5, (name, T, E, layers)
+
+
 def test_fused_mlp_backward_partial_outputs_and_frozen_input(gpu):
     """Outputs that receive no gradient count as zero; an input that needs no gradient gets none."""
     from sparsefactorization_amd import fused_mlp
