@@ -273,6 +273,34 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
                     int64_t workspace_bytes, void* stream);
 
 /*
+ * Producer side at the WIDE (LRA) sizes — the same K MLPs for E up to 1024 and outputs up to 128: reference ListOps
+ * E = 512, h = 128, outputs 12 (x 11 link MLPs) and 128 (LRA/psf_training_config.py:2-30; MLPBlock LRA/psf.py:35-60, call
+ * sites LRA/psf.py:214,227). The K first layers run as ONE stacked GEMM on the bf16 matrix pipe at f32 accuracy (every
+ * f32 operand split exactly into three bf16 terms, six product terms), forward, input gradient and weight gradient
+ * alike; the second layers, GELU and its derivative are fused around them.
+ *   psf_mlp_wide_fwd_f32  Y[k] as psf_mlp_fwd_f32. It also fills `saved` (caller-owned, 256-byte aligned, at least
+ *                         psf_mlp_wide_saved_bytes bytes): X as bf16 term planes and the pre-activations of the hidden
+ *                         layers — what the backward needs, so that nothing is recomputed (at these widths recomputing
+ *                         is a fourth 100-GFLOP GEMM; keeping is 4 x sum(h) bytes per token). Inference passes scratch.
+ *   psf_mlp_wide_bwd_f32  the gradients of psf_mlp_bwd_f32 from `saved` and dY[k]; dX may be NULL (not computed).
+ *   Layouts as psf_mlp_fwd_f32 / psf_mlp_bwd_f32. Limits: E a multiple of 16, 16 <= E <= 1024; 1 <= h[k] <= 128;
+ *   1 <= O[k] <= 128; 1 <= K <= 24; T * E and T * (sum of h[k] rounded up to 32) below 2^30; X and A[k] 16-byte aligned.
+ *   Workspaces: caller-owned, 256-byte aligned, at least psf_mlp_wide_{fwd,bwd}_workspace bytes (-1: unsupported sizes).
+ * Every reduction has a fixed order (no float atomics): results are bit-reproducible run to run.
+ */
+int64_t psf_mlp_wide_saved_bytes(int64_t T, int32_t E, int32_t K, const int32_t* h, const int32_t* O);
+int64_t psf_mlp_wide_fwd_workspace(int64_t T, int32_t E, int32_t K, const int32_t* h, const int32_t* O);
+int64_t psf_mlp_wide_bwd_workspace(int64_t T, int32_t E, int32_t K, const int32_t* h, const int32_t* O);
+int psf_mlp_wide_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float* const* A, const float* const* a,
+                         const float* const* B, const float* const* b, const int32_t* h, const int32_t* O,
+                         float* const* Y, void* saved, int64_t saved_bytes, void* workspace, int64_t workspace_bytes,
+                         void* stream);
+int psf_mlp_wide_bwd_f32(const void* saved, int64_t saved_bytes, int64_t T, int32_t E, int32_t K,
+                         const float* const* A, const float* const* B, const int32_t* h, const int32_t* O,
+                         const float* const* dY, float* dX, float* const* dA, float* const* da, float* const* dB,
+                         float* const* db, void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * Process-wide tuning knobs (benchmark / test use; defaults are the shipped configuration).
  *   key "fwd_variant": 0 = auto, 1 = generic direct-gather kernel, 2 = LDS-window kernel
  *   key "bwd_variant": 0 = auto (LDS-window dV / dW kernels where they apply), 1 = generic kernels

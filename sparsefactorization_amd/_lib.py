@@ -58,6 +58,15 @@ SIGNATURES = {
     "psf_mlp_bwd_f32": ([c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                          ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(c_vp),
                          ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp, c_i64, c_vp], ctypes.c_int),
+    "psf_mlp_wide_saved_bytes": ([c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)], c_i64),
+    "psf_mlp_wide_fwd_workspace": ([c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)], c_i64),
+    "psf_mlp_wide_bwd_workspace": ([c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)], c_i64),
+    "psf_mlp_wide_fwd_f32": ([c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+                              ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_vp), c_vp,
+                              c_i64, c_vp, c_i64, c_vp], ctypes.c_int),
+    "psf_mlp_wide_bwd_f32": ([c_vp, c_i64, c_i64, c_i32, c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+                              ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(c_vp),
+                              ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp, c_i64, c_vp], ctypes.c_int),
     "psf_set_tuning": ([ctypes.c_char_p, c_i32], ctypes.c_int),
     "psf_get_tuning": ([ctypes.c_char_p], ctypes.c_int),
     "psf_describe_fwd": ([c_i64, c_i64, c_i32, c_i64, c_i32, ctypes.c_char_p, c_i32], ctypes.c_int),

@@ -25,10 +25,10 @@ ARCH = "gfx950"
 WIN_TGS = list(range(7))
 
 HEADERS = ["psf_common.h", "fwd_kernels.h", "fwd_window.h", "fwd_window_launch.h", "bwd_kernels.h",
-           "bwd_window.h", "bwd_dw_chunk.h", "bwd_window_launch.h", "fwd_chain_lds.h", "fwd_chain_lds_launch.h", "mlp_fwd_x3.h", "mlp_x3_common.h", "mlp_planes.h",
+           "bwd_window.h", "bwd_dw_chunk.h", "bwd_window_launch.h", "fwd_chain_lds.h", "fwd_chain_lds_launch.h", "mlp_fwd_x3.h", "mlp_x3_common.h", "mlp_planes.h", "x3_gemm.h",
            os.path.join("..", "..", "include", "psf_chord.h")]
 SOURCES = ["psf_chord.hip", "fwd_window_inst.hip", "bwd_window_inst.hip", "linear_wgrad.hip",
-           "fwd_chain_lds_inst.hip", "embed.hip", "flat_head.hip", "sum_tensors.hip", "adam.hip", "mlp_fwd.hip", "mlp_fwd_x3.hip", "mlp_bwd.hip"]
+           "fwd_chain_lds_inst.hip", "embed.hip", "flat_head.hip", "sum_tensors.hip", "adam.hip", "mlp_fwd.hip", "mlp_fwd_x3.hip", "mlp_bwd.hip", "mlp_wide.hip"]
 
 # -ffp-contract=off: products and sums stay separate roundings (bitwise parity with the CPU oracle).
 HIPCC_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
@@ -70,7 +70,8 @@ def _units():
              (os.path.join(OBJ_DIR, "mlp_fwd_x3.o"), os.path.join(CSRC, "mlp_fwd_x3.hip"), []),
              # -fno-slp-vectorize: keeps hipcc from re-packing the scalar f32 arithmetic of the bf16-pipe kernel into
              # v_pk_* instructions, which are slow beside MFMAs (mlp_bwd.hip, gelu_and_grad1)
-             (os.path.join(OBJ_DIR, "mlp_bwd.o"), os.path.join(CSRC, "mlp_bwd.hip"), ["-fno-slp-vectorize"])]
+             (os.path.join(OBJ_DIR, "mlp_bwd.o"), os.path.join(CSRC, "mlp_bwd.hip"), ["-fno-slp-vectorize"]),
+             (os.path.join(OBJ_DIR, "mlp_wide.o"), os.path.join(CSRC, "mlp_wide.hip"), ["-fno-slp-vectorize"])]
     for t in WIN_TGS:
         units.append((os.path.join(OBJ_DIR, f"fwd_window_tgs{t}.o"), os.path.join(CSRC, "fwd_window_inst.hip"),
                       [f"-DPSF_TGS={t}"]))

@@ -12,8 +12,12 @@ M+1 of them to the same ``data`` (psf.py:165,175).
 ``eligible`` (no gradient needed) / ``trainable`` (gradient needed) say whether a call can take these kernels;
 MLPs of another form, fp64, E > 64 (E > 32 when training), h > 128, out > 32 or CPU tensors use the stock modules.
 
-``stackable`` / ``stacked_apply`` cover the widths the kernels do not (ListOps: E = 512, out = 128) with library
-GEMMs laid out for them: the M+1 first layers share their input, so they run as ONE Linear(E, sum h) — one GEMM
+``wide_ok`` / ``wide_apply`` (csrc/mlp_wide.hip) cover the LRA widths — E up to 1024, outputs up to 128; the reference
+ListOps network has E = 512, out = 12 and 128 (LRA/psf_training_config.py:2-30): the M+1 first layers are ONE stacked GEMM
+on the bf16 matrix pipe at f32 accuracy, forward, input gradient and weight gradient; the forward keeps the hidden
+pre-activations for the backward instead of recomputing them.
+
+``stackable`` / ``stacked_apply`` cover whatever is left (fp64, odd widths) with library GEMMs laid out for them: the M+1 first layers share their input, so they run as ONE Linear(E, sum h) — one GEMM
 forward, one GEMM for the input gradient (K = sum h, instead of M+1 GEMMs plus M accumulations of a [T, E]
 tensor) and one for the weight gradient; GELU and its backward are one kernel each.
 """
@@ -188,6 +192,114 @@ def fused_mlp_apply(x: torch.Tensor, blocks: Sequence[nn.Module]) -> List[torch.
     lead, E = x.shape[:-1], x.shape[-1]
     x2 = x.reshape(-1, E).contiguous()
     ys = _FusedMLPFn.apply(x2, *_params_of(blocks))
+    return [y.reshape(*lead, y.shape[1]) for y in ys]
+
+
+WIDE_MAX_E, WIDE_MAX_O, WIDE_MAX_K = 1024, 128, 24
+wide_enabled = True
+
+
+def wide_ok(x: torch.Tensor, blocks: Sequence[nn.Module]) -> bool:
+    """The wide kernels (psf_mlp_wide_*) can replace ``[b(x) for b in blocks]``, with or without autograd. Callers try
+    ``eligible`` / ``trainable`` (the narrow kernels, which never let a hidden activation reach memory) first."""
+    if not (enabled and wide_enabled) or not x.is_cuda or x.dtype != torch.float32 or x.dim() < 2 or not 1 <= len(blocks) <= WIDE_MAX_K:
+        return False
+    E = x.shape[-1]
+    if E < 16 or E > WIDE_MAX_E or E % 16:
+        return False
+    J = 0
+    for b in blocks:
+        pair = _two_layer(b)
+        if pair is None:
+            return False
+        l1, l2 = pair
+        if l1.in_features != E or l1.out_features > MAX_H or l2.out_features > WIDE_MAX_O or l1.weight.dtype != torch.float32:
+            return False
+        J += (l1.out_features + 31) // 32 * 32
+    T = x.numel() // E
+    return T * max(E, J) < 2 ** 30  # 32-bit lane offsets into a bf16 plane
+
+
+def _wide_sizes(x2: torch.Tensor, params: Sequence[torch.Tensor]):
+    K = len(params) // 4
+    h = (ctypes.c_int32 * K)(*[A.shape[0] for A in params[0::4]])
+    O = (ctypes.c_int32 * K)(*[B.shape[0] for B in params[2::4]])
+    return x2.shape[0], x2.shape[1], K, h, O
+
+
+def _scratch(nbytes: int, dev) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)  # the caching allocator aligns to 512 bytes
+
+
+def _wide_forward_raw(x2: torch.Tensor, params: Sequence[torch.Tensor]):
+    """(Y_0..Y_{K-1}, saved): ``saved`` holds X as bf16 term planes and the hidden pre-activations (mlp_wide.hip)."""
+    T, E, K, h, O = _wide_sizes(x2, params)
+    dev = x2.device
+    lib = _lib.load()
+    As, as_, Bs, bs = params[0::4], params[1::4], params[2::4], params[3::4]
+    n_saved, n_ws = lib.psf_mlp_wide_saved_bytes(T, E, K, h, O), lib.psf_mlp_wide_fwd_workspace(T, E, K, h, O)
+    if n_saved < 0 or n_ws < 0:
+        raise ValueError("psf_mlp_wide_fwd does not support these layer sizes")
+    saved, ws = _scratch(n_saved, dev), _scratch(n_ws, dev)
+    ys = [torch.empty((T, B.shape[0]), dtype=torch.float32, device=dev) for B in Bs]
+    with torch.cuda.device(dev):
+        rc = lib.psf_mlp_wide_fwd_f32(x2.data_ptr(), T, E, K, _ptrs(As), _ptrs(as_), _ptrs(Bs), _ptrs(bs), h, O, _ptrs(ys),
+                                      saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(),
+                                      torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "psf_mlp_wide_fwd_f32")
+    return ys, saved
+
+
+def _wide_backward_raw(saved: torch.Tensor, T: int, E: int, params: Sequence[torch.Tensor], gys: Sequence[torch.Tensor], need_dx: bool):
+    dev = saved.device
+    lib = _lib.load()
+    K = len(params) // 4
+    As, Bs = params[0::4], params[2::4]
+    h = (ctypes.c_int32 * K)(*[A.shape[0] for A in As])
+    O = (ctypes.c_int32 * K)(*[B.shape[0] for B in Bs])
+    grads = [torch.empty_like(p) for p in params]
+    dX = torch.empty((T, E), dtype=torch.float32, device=dev) if need_dx else None
+    n_ws = lib.psf_mlp_wide_bwd_workspace(T, E, K, h, O)
+    if n_ws < 0:
+        raise ValueError("psf_mlp_wide_bwd does not support these layer sizes")
+    ws = _scratch(n_ws, dev)
+    with torch.cuda.device(dev):
+        rc = lib.psf_mlp_wide_bwd_f32(saved.data_ptr(), saved.numel(), T, E, K, _ptrs(As), _ptrs(Bs), h, O, _ptrs(gys),
+                                      dX.data_ptr() if need_dx else None, _ptrs(grads[0::4]), _ptrs(grads[1::4]),
+                                      _ptrs(grads[2::4]), _ptrs(grads[3::4]), ws.data_ptr(), ws.numel(),
+                                      torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "psf_mlp_wide_bwd_f32")
+    return dX, grads
+
+
+class _WideMLPFn(torch.autograd.Function):
+    """(Y_0, ..., Y_{K-1}) = MLPs(x2) on the wide kernels; saves the kernels' own record of X and the hidden layer."""
+
+    @staticmethod
+    def forward(ctx, x2, *params):
+        params = tuple(p.detach().contiguous() for p in params)
+        ys, saved = _wide_forward_raw(x2, params)
+        ctx.save_for_backward(saved, *params)
+        ctx.x_shape = tuple(x2.shape)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        saved, *params = ctx.saved_tensors
+        T, E = ctx.x_shape
+        gys = [torch.zeros((T, B.shape[0]), dtype=torch.float32, device=saved.device) if g is None else g.contiguous()
+               for g, B in zip(gys, params[2::4])]
+        dX, grads = _wide_backward_raw(saved, T, E, params, gys, ctx.needs_input_grad[0])
+        return (dX, *grads)
+
+
+def wide_apply(x: torch.Tensor, blocks: Sequence[nn.Module]) -> List[torch.Tensor]:
+    """[block(x) for block in blocks] on the wide kernels (autograd-aware). Caller checks ``wide_ok`` first."""
+    lead, E = x.shape[:-1], x.shape[-1]
+    if _needs_grad(x, blocks):
+        ys = _WideMLPFn.apply(x.reshape(-1, E).contiguous(), *_params_of(blocks))
+    else:
+        ys, _ = _wide_forward_raw(x.detach().reshape(-1, E).contiguous(), [p.detach().contiguous() for p in _params_of(blocks)])
     return [y.reshape(*lead, y.shape[1]) for y in ys]
 
 

@@ -142,6 +142,8 @@ class _ChordMixer(nn.Module):
             return fused_mlp.fused_mlp_forward(data, fs)
         if fused_mlp.trainable(data, fs):
             return fused_mlp.fused_mlp_apply(data, fs)
+        if fused_mlp.wide_ok(data, fs):
+            return fused_mlp.wide_apply(data, fs)
         if fused_mlp.stackable(data, fs):
             return fused_mlp.stacked_apply(data, fs)
         return [f(data) for f in fs]
@@ -159,6 +161,9 @@ class _ChordMixer(nn.Module):
             return outs[0], outs[1:]
         if fused_mlp.trainable(data, blocks):
             outs = fused_mlp.fused_mlp_apply(data, blocks)
+            return outs[0], outs[1:]
+        if fused_mlp.wide_ok(data, blocks):
+            outs = fused_mlp.wide_apply(data, blocks)
             return outs[0], outs[1:]
         if fused_mlp.stackable(data, blocks):
             outs = fused_mlp.stacked_apply(data, blocks)
