@@ -47,6 +47,8 @@ constexpr int kOtMax = 4;              // output tiles of 32 per MLP (O <= 128)
 constexpr int kPack2Tile = 2048;       // one term of one (unit, output tile): [2 s][2 half][32 o][8] bf16
 constexpr int kPackBtStep = 1024;      // one term of one (unit, k-step of 16 outputs): [2 half][32 j][8] bf16
 constexpr int kSplitsMax = 64;
+constexpr int kSlotClass = 4 * 96;           // work-item table of wide_mid_k: three classes x (<= 4 sub-items per unit)
+constexpr int kSlotBytes = 3 * kSlotClass * 4;
 
 // ---- y = GELU(x) = x Phi(x), dy/dx = Phi(x) + x phi(x); Phi by Abramowitz & Stegun 26.2.17 (|error| <= 7.5e-8), on
 // scalar f32 instructions (packed f32 VALU is slow beside the sibling wave's MFMAs: mlp_bwd.hip, gelu_and_grad1).
@@ -129,9 +131,20 @@ struct WideBwdArgs {
   const float* HF;
   float* part;             // [workgroups][rec_total] partial sums of dB^T, da, db
   const float* dapart;     // [splits][J_pad][E_pad] partial dAcat
-  uint32_t rec_off[kMaxWideUnits];  // float offset of a unit's record: [ot][1024] dB^T | [32] da | [ot][32] db (first unit of its MLP)
-  int32_t rec_total, groups, splits;
+  // float offset of a unit's first record in a group's slab; a unit has nsub(unit) records of rec_size(unit) floats:
+  // [ot][1024] dB^T | [32] da | [ot][32] db (first unit of its MLP)
+  uint32_t rec_off[kMaxWideUnits];
+  // work items of wide_mid_k by unit class (0: O <= 16, 1: O <= 32, 2: wider), each class kSlotClass entries:
+  // unit | sub << 8 | nsub << 16 (written by the pack kernel)
+  uint32_t* slots;
+  int32_t rec_total, groups, splits, n_slots[3];
 };
+__host__ __device__ inline int wide_class(int O) { return O <= 16 ? 0 : O <= 32 ? 1 : 2; }
+
+// A unit of a wide-output MLP (more than 32 outputs: 2-4 output tiles) costs 2-3 x a narrow one per token tile in
+// wide_mid_k; it is cut into nsub work items of 8 / nsub token tiles so that items cost about the same.
+__host__ __device__ inline int wide_nsub(int ot) { return ot <= 1 ? 1 : ot == 2 ? 2 : 4; }
+__host__ __device__ inline int wide_rec_size(int ot, bool first) { return ot * 1024 + 32 + (first ? ot * 32 : 0); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // packing (once per call; all of it a few MB)
@@ -209,6 +222,15 @@ __global__ void __launch_bounds__(256) wide_pack_fwd_k(const WideFwdArgs a) {
 __global__ void __launch_bounds__(256) wide_pack_bwd_k(const WideBwdArgs a) {
   const WideGeom& g = a.g;
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
+  if (gid < 3) {  // (0) the work items of wide_mid_k of class gid, in unit order
+    int n = 0;
+    for (int unit = 0; unit < g.J / 32; ++unit) {
+      const WideBwdMlp& d = a.m[g.unit_k[unit]];
+      if (wide_class(d.O) != (int)gid) continue;
+      const int nsub = wide_nsub(d.ot);
+      for (int sub = 0; sub < nsub; ++sub) a.slots[gid * kSlotClass + n++] = (uint32_t)unit | ((uint32_t)sub << 8) | ((uint32_t)nsub << 16);
+    }
+  }
   // (1) Wcat^T planes: rows e (E_pad), column blocks jb (J / 16): element (e, j) = Wcat[j][e]
   const int jb_n = g.J / 16;
   for (int64_t i = gid; i < (int64_t)g.E_pad * jb_n; i += gsz) {
@@ -333,12 +355,14 @@ __global__ void __launch_bounds__(256) wide_out_k(const WideFwdArgs a) {
 //   dB^T[j][o] += Hpost^T[j][tok] dY[tok][o]             (contraction over tokens: Hpost^T transposed through two LDS
 //                                                          planes + ds_read_b64_tr_b16; dY columns straight from memory)
 //   da[j] += sum_tok G,  db[o] += sum_tok dY
-// 512 threads, one 32-token tile per wave (8 tiles = one 256-token GEMM tile per workgroup); per unit the eight waves'
-// sums are combined through LDS in a fixed order and flushed to the workgroup's record (one barrier per unit and
-// output tile: two combine buffers alternate).
+// Work item = (group of kMidTiles token tiles, hidden unit), owned by ONE wave: it walks the group's token tiles with the
+// unit's dB^T / da / db sums in registers and writes the item's record once — no workgroup barrier, no cross-wave
+// combine (a first version combined eight waves through LDS after every unit: 96 barriers per workgroup kept the waves
+// in lockstep and every Hpre load exposed, 410 us at ListOps sizes). Items are dealt round-robin over all waves of the
+// launch (unit fastest, so the four units of an MLP, which read the same dY tile, run side by side); the next token
+// tile's Hpre registers are requested before the current tile is processed.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kMidScr = 1024 + 32 + 32;   // floats: dB^T tile [32 j][32 o] | da [32] | db [32]
-constexpr int kMidWaveBytes = 2 * kPlaneBytes + 2 * kMidScr * 4;
+constexpr int kMidTiles = 8;  // token tiles per item = one 256-token GEMM tile
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -352,90 +376,133 @@ __device__ __forceinline__ float half_sum(float v) {  // sum over the 32 lanes o
   return v + __shfl_xor(v, 16, 64);
 }
 
-__global__ void __launch_bounds__(512, 1) wide_mid_k(const WideBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char wave_lds[8 * kMidWaveBytes];
+// OT: output tiles of 32 a unit may have (dB^T accumulators); NDY: dY tile elements per lane (8: O <= 16). Three
+// instances — <1, 8>, <1, 16>, <4, 16> — each launched on its own class of units (WideBwdArgs::n_slots): with the widest
+// shape's 64 accumulator registers in every instance the common narrow case spilled 100+ registers.
+template <int OT, int NDY>
+__global__ void __launch_bounds__(512, 1) wide_mid_k(const WideBwdArgs a, const int cls) {
+  constexpr int kWaveLds = 2 * kPlaneBytes + 32 * 33 * 4 + 128;  // two transposition planes + the dY tile (<= [32 tok][33])
+  __shared__ __attribute__((aligned(16))) unsigned char wave_lds[8 * kWaveLds];
   const WideGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, half = lane >> 5;
-  unsigned char* HP = wave_lds + wv * kMidWaveBytes;
+  unsigned char* HP = wave_lds + wv * kWaveLds;
   unsigned char* YP = HP + kPlaneBytes;
+  float* YT = reinterpret_cast<float*>(YP + kPlaneBytes);
   const PlaneLane L = plane_lane(lane);
-  const int64_t ttile = (int64_t)blockIdx.x * 8 + wv;  // < T_pad / 32 by construction of the grid
-  const int64_t tok = ttile * 32 + c;
-  const bool tok_ok = tok < g.T;
-  float* part = a.part + (int64_t)blockIdx.x * a.rec_total;
-  int par = 0;  // combine buffer parity (block-uniform: every wave runs the same sequence)
+  const int n_slots = a.n_slots[cls];
+  const uint32_t* slots = a.slots + cls * kSlotClass;
+  const int64_t items = (int64_t)a.groups * n_slots;
+  const int64_t waves = (int64_t)gridDim.x * 8;
 
-  auto scr_of = [&](int w, int p) -> float* {
-    return reinterpret_cast<float*>(wave_lds + w * kMidWaveBytes + 2 * kPlaneBytes) + p * kMidScr;
-  };
-  auto sum8 = [&](int p, int off) {  // float4 at float offset `off` of the combine buffers, waves in order
-    float4 acc = *reinterpret_cast<const float4*>(scr_of(0, p) + off);
+  for (int64_t item = (int64_t)blockIdx.x * 8 + wv; item < items; item += waves) {
+    const int64_t grp = item / n_slots;
+    const uint32_t slot = slots[item - grp * n_slots];
+    const int unit = (int)(slot & 0xff), sub = (int)((slot >> 8) & 0xff), nsub = (int)(slot >> 16);
+    const WideBwdMlp& d = a.m[g.unit_k[unit]];
+    const int O = d.O, ot_n = d.ot, ns2 = (O + 15) >> 4;
+    const bool first = 32 * unit == d.joff;
+    const unsigned char* btp = a.packbt + ((int64_t)unit * 8 * 3) * kPackBtStep + (half * 32 + c) * 16;
+    const int n_tiles = kMidTiles / nsub;
+    const int64_t tt0 = grp * kMidTiles + (int64_t)sub * n_tiles;
+
+    f32x16 dbt[OT];
+    float dasum[16], dbs[OT];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) {
-      const float4 v = *reinterpret_cast<const float4*>(scr_of(w, p) + off);
-      acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+    for (int ot = 0; ot < OT; ++ot) {
+      dbs[ot] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dbt[ot][r] = 0.f;
     }
-    return acc;
-  };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dasum[r] = 0.f;
 
-  for (int k = 0; k < g.K; ++k) {
-    const WideBwdMlp& d = a.m[k];
-    const int O = d.O, ot_n = d.ot, ns2 = (O + 15) >> 4, unit0 = d.joff >> 5, nu = (d.h + 31) >> 5;
-    // B operand of dB^T: dY[tok = 16 s + 8 half + i][o = 32 ot + c] (k = token). Rows past T and outputs past O are zero.
-    auto load_yb = [&](int ot, int s) {
-      float v[8];
-      const int o = 32 * ot + c;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int64_t t2 = ttile * 32 + 16 * s + 8 * half + i;
-        v[i] = (t2 < g.T && o < O) ? d.dY[t2 * O + o] : 0.f;
-      }
-      return split_pack8(v);
-    };
-    Frag3 yb0[2];  // output tile 0, kept for all units of the MLP
-    float dbs[kOtMax];
-#pragma unroll
-    for (int ot = 0; ot < kOtMax; ++ot) dbs[ot] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) yb0[s] = load_yb(0, s);
-    // db[o = 32 ot + c]: the lane's half sums 16 tokens, the two halves are added below
-#pragma unroll
-    for (int ot = 0; ot < kOtMax; ++ot) {
-      if (ot < ot_n) {
-        const int o = 32 * ot + c;
-        float sacc = 0.f;
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int64_t t2 = ttile * 32 + 16 * s + 8 * half + i;
-            sacc += (t2 < g.T && o < O) ? d.dY[t2 * O + o] : 0.f;
-          }
-        dbs[ot] = sacc + __shfl_xor(sacc, 32, 64);
-      }
-    }
-
-    for (int u = 0; u < nu; ++u) {
-      const int unit = unit0 + u;
+    // Everything a token tile reads first is requested one tile ahead: its Hpre registers and the first 32 outputs of its
+    // dY tile (for O <= 32 the whole tile: one contiguous burst of 32 O floats, element lane + 64 i). Loads only, no use
+    // here (a use would wait for them). The tile goes through LDS and is read back in both orientations: the lane's
+    // token row (B operand of dHpost^T) and the lane's output column (B operand of dB^T). A first version read those
+    // straight from memory: 24 scattered dword loads per tile and unit kept the CU's address unit busy, not the ALUs.
+    // Lane l takes elements l + 64 i of the tile. O < 32: the tile is 32 O contiguous floats and keeps that order in LDS
+    // (row stride O). O > 32: element (row (l >> 5) + 2 i, output l & 31), LDS row stride 33. Either way memory and LDS
+    // addresses are a per-lane base + i x a constant.
+    const int W = O < 32 ? O : 32;
+    constexpr bool two_d = OT > 1;  // the class of units with more than 32 outputs
+    const int g_off = two_d ? (lane >> 5) * O + (lane & 31) : lane, g_step = two_d ? 2 * O : 64;
+    const int l_off = two_d ? lane + (lane >> 5) : lane, l_step = two_d ? 66 : 64, l_row = two_d ? 33 : O;
+    const int nel = two_d ? 16 : (32 * O + 63) >> 6;  // elements per lane (the last may be partial when O < 32)
+    float hnext[16], dyt[NDY];
+    auto prefetch = [&](int64_t ttile) {
       const float* hfp = a.HF + (((ttile * g.U + unit) * 16) << 6) + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hnext[r] = hfp[r * 64];
+      const float* tile = d.dY + ttile * 32 * O;
+      const int64_t rows = g.T - ttile * 32;  // valid rows of this tile (may be <= 0 past the end)
+      if (rows >= 32) {  // wave-uniform
+        const float* p0 = tile + g_off;
+#pragma unroll
+        for (int i = 0; i < NDY; ++i)
+          if (i < nel) dyt[i] = p0[(two_d || lane + 64 * i < 32 * O) ? i * g_step : 0];
+      } else {  // the partial tile: rows past T read element 0 of the array and are zeroed when consumed
+#pragma unroll
+        for (int i = 0; i < NDY; ++i)
+          if (i < nel) {
+            const int e = g_off + i * g_step;
+            const bool ok = two_d ? (lane >> 5) + 2 * i < rows : e < rows * O;
+            dyt[i] = ok ? tile[e] : d.dY[0];
+          }
+      }
+    };
+    prefetch(tt0);
+    for (int it = 0; it < n_tiles; ++it) {
+      const int64_t ttile = tt0 + it;
+      const int64_t tok = ttile * 32 + c;
+      const bool tok_ok = tok < g.T;
       float hpre[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hpre[r] = hfp[r * 64];
-      // dHpost^T
+      for (int r = 0; r < 16; ++r) hpre[r] = hnext[r];
+      {
+        const int64_t rows = g.T - ttile * 32;
+#pragma unroll
+        for (int i = 0; i < NDY; ++i)
+          if (i < nel) {
+            const bool ok = rows >= 32 || (two_d ? (lane >> 5) + 2 * i < rows : g_off + i * g_step < rows * O);
+            if (two_d || lane + 64 * i < 32 * O) YT[l_off + i * l_step] = ok ? dyt[i] : 0.f;
+          }
+      }
+      // "consume the old values, THEN issue the next loads" (hipcc would hoist the loads above their predecessors' uses)
+#pragma unroll
+      for (int r = 0; r < 16; r += 4) asm volatile("" : "+v"(hpre[r]), "+v"(hpre[r + 1]), "+v"(hpre[r + 2]), "+v"(hpre[r + 3]) : : "memory");
+      if (it + 1 < n_tiles) prefetch(ttile + 1);
+      float dy0[8], yb0[16];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dy0[i] = 8 * half + i < W ? YT[c * l_row + 8 * half + i] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) yb0[i] = c < W ? YT[(8 * half + (i & 7) + 16 * (i >> 3)) * l_row + c] : 0.f;
+      // dHpost^T: B operand = the lane's own dY row, 8 outputs per k-step
       f32x16 acc3;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
-      for (int s2 = 0; s2 < ns2; ++s2) {
+      acc3 = mfma6(load_frag3(btp, kPackBtStep), split_pack8(dy0), acc3);
+      if (NDY > 8 && ns2 > 1) {  // outputs 16 .. 31: still inside the LDS tile
         float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int o = 16 * s2 + 8 * half + i;
-          v[i] = (tok_ok && o < O) ? d.dY[tok * O + o] : 0.f;
+        for (int i = 0; i < 8; ++i) v[i] = 16 + 8 * half + i < W ? YT[c * l_row + 16 + 8 * half + i] : 0.f;
+        acc3 = mfma6(load_frag3(btp + (int64_t)3 * kPackBtStep, kPackBtStep), split_pack8(v), acc3);
+      }
+      const bool row4 = (O & 3) == 0 && (reinterpret_cast<uintptr_t>(d.dY) & 15) == 0;  // the lane's row in 16-byte pieces
+      for (int s2 = 2; s2 < (OT > 1 ? ns2 : 2); ++s2) {
+        float v[8];
+        const int o0 = 16 * s2 + 8 * half;
+        if (row4) {
+          float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+          if (tok_ok && o0 < O) lo = *reinterpret_cast<const float4*>(d.dY + tok * O + o0);
+          if (tok_ok && o0 + 4 < O) hi = *reinterpret_cast<const float4*>(d.dY + tok * O + o0 + 4);
+          v[0] = lo.x, v[1] = lo.y, v[2] = lo.z, v[3] = lo.w, v[4] = hi.x, v[5] = hi.y, v[6] = hi.z, v[7] = hi.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = (tok_ok && o0 + i < O) ? d.dY[tok * O + o0 + i] : 0.f;
         }
-        const Frag3 dy3 = split_pack8(v);
-        const Frag3 bt = load_frag3(a.packbt + ((int64_t)(unit * 8 + s2) * 3) * kPackBtStep + (half * 32 + c) * 16, kPackBtStep);
-        acc3 = mfma6(bt, dy3, acc3);
+        acc3 = mfma6(load_frag3(btp + (int64_t)s2 * 3 * kPackBtStep, kPackBtStep), split_pack8(v), acc3);
       }
       float y[16], gg[16];
 #pragma unroll
@@ -443,71 +510,87 @@ __global__ void __launch_bounds__(512, 1) wide_mid_k(const WideBwdArgs a) {
         float dd;
         gelu_and_grad(hpre[r], y[r], dd);
         gg[r] = acc3[r] * dd;
+        dasum[r] += gg[r];
       }
-      // G planes: registers 4 q .. 4 q + 3 are rows j = 32 unit + 8 q + 4 half + (0..3) of token c: 8 bytes of the token's
-      // 32-byte row in column block 2 unit + (q >> 1)
-      const Split16 gs = split16(gg);
+      // G planes: registers 4 q .. 4 q + 3 of lane (c, half) are rows j = 32 unit + 8 q + 4 half + (0..3) of token c, i.e. 8 of
+      // the 32 bytes of the token's row in column block 2 unit + (q >> 1). v_permlane32_swap pairs the two halves of
+      // the wave so that lane (c, half) ends up with rows 16 p + 8 half .. + 7 (p = 0, 1): 16 contiguous bytes, and the
+      // wave stores each (term, block) as ONE fully coalesced 1 KB dwordx4 burst instead of four scattered 8-byte stores.
+      {
+        const Split16 gs = split16(gg);
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          unsigned char* dst = a.gp[t] + ((int64_t)(2 * unit + (q >> 1)) * g.T_pad + tok) * 32 + (8 * (q & 1) + 4 * half) * 2;
-          *reinterpret_cast<uint2*>(dst) = uint2{gs.d[t][2 * q], gs.d[t][2 * q + 1]};
-        }
+          for (int pq = 0; pq < 2; ++pq) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(gs.d[t][4 * pq], gs.d[t][4 * pq + 2], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(gs.d[t][4 * pq + 1], gs.d[t][4 * pq + 3], false, false);
+            unsigned char* dst = a.gp[t] + ((int64_t)(2 * unit + pq) * g.T_pad + tok) * 32 + 16 * half;
+            *reinterpret_cast<uint4*>(dst) = uint4{s0[0], s1[0], s0[1], s1[1]};
+          }
+      }
       // Hpost^T transposed: accumulator layout -> [tok][j] planes -> A operand with the token as k
-      const Split16 ys = split16(y);
       Frag3 ha[2];
-      store_acc_plane(HP, L, ys, 0);
-      store_acc_plane(YP, L, ys, 1);
-      asm volatile("" ::: "memory");
+      {
+        const Split16 ys = split16(y);
+        store_acc_plane(HP, L, ys, 0);
+        store_acc_plane(YP, L, ys, 1);
+        asm volatile("" ::: "memory");
 #pragma unroll
-      for (int s = 0; s < 2; ++s) ha[s].t1 = tr_frag(HP, L, s), ha[s].t2 = tr_frag(YP, L, s);
-      asm volatile("" ::: "memory");
-      store_acc_plane(HP, L, ys, 2);
-      asm volatile("" ::: "memory");
+        for (int s = 0; s < 2; ++s) ha[s].t1 = tr_frag(HP, L, s), ha[s].t2 = tr_frag(YP, L, s);
+        asm volatile("" ::: "memory");
+        store_acc_plane(HP, L, ys, 2);
+        asm volatile("" ::: "memory");
 #pragma unroll
-      for (int s = 0; s < 2; ++s) ha[s].t3 = tr_frag(HP, L, s);
-      asm volatile("" ::: "memory");
-      // da
-      float das[16];
+        for (int s = 0; s < 2; ++s) ha[s].t3 = tr_frag(HP, L, s);
+        asm volatile("" ::: "memory");
+      }
+      // dB^T: B operand = dY[tok = 16 s + 8 half + i][o = 32 ot + c] (k = token); rows past T, outputs past O are zero
 #pragma unroll
-      for (int r = 0; r < 16; ++r) das[r] = half_sum(gg[r]);
-
-      const uint32_t rec = a.rec_off[unit];
-      for (int ot = 0; ot < ot_n; ++ot) {
-        f32x16 dbt;
+      for (int s = 0; s < 2; ++s) {
+        const float v[8] = {yb0[8 * s], yb0[8 * s + 1], yb0[8 * s + 2], yb0[8 * s + 3], yb0[8 * s + 4], yb0[8 * s + 5], yb0[8 * s + 6], yb0[8 * s + 7]};
+        if (first) dbs[0] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        dbt[0] = mfma6(ha[s], split_pack8(v), dbt[0]);
+      }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dbt[r] = 0.f;
-        if (ot == 0) {
+      for (int ot = 1; ot < OT; ++ot) {
+        if (ot < ot_n) {
+          const int o = 32 * ot + c;
 #pragma unroll
-          for (int s = 0; s < 2; ++s) dbt = mfma6(ha[s], yb0[s], dbt);
-        } else {
+          for (int s = 0; s < 2; ++s) {
+            float v[8];
 #pragma unroll
-          for (int s = 0; s < 2; ++s) dbt = mfma6(ha[s], load_yb(ot, s), dbt);
-        }
-        float* scr = scr_of(wv, par);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) scr[cd_row(r, half) * 32 + c] = dbt[r];
-        if (ot == 0) {
-          if (c == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) scr[1024 + cd_row(r, half)] = das[r];
+            for (int i = 0; i < 8; ++i) {
+              const int64_t t2 = ttile * 32 + 16 * s + 8 * half + i;
+              v[i] = (t2 < g.T && o < O) ? d.dY[t2 * O + o] : 0.f;
+            }
+            if (first) dbs[ot] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            dbt[ot] = mfma6(ha[s], split_pack8(v), dbt[ot]);
           }
         }
-        // db of output tile ot travels with the dB^T tile of the MLP's first unit
-        if (u == 0 && half == 0) scr[1056 + c] = ot == 0 ? dbs[0] : ot == 1 ? dbs[1] : ot == 2 ? dbs[2] : dbs[3];
-        __syncthreads();
-        if (wv < 4) *reinterpret_cast<float4*>(part + rec + ot * 1024 + wv * 256 + 4 * lane) = sum8(par, wv * 256 + 4 * lane);
-        if (wv == 4 && ot == 0 && lane < 8) *reinterpret_cast<float4*>(part + rec + ot_n * 1024 + 4 * lane) = sum8(par, 1024 + 4 * lane);
-        if (wv == 5 && u == 0 && lane < 8)
-          *reinterpret_cast<float4*>(part + rec + ot_n * 1024 + 32 + ot * 32 + 4 * lane) = sum8(par, 1056 + 4 * lane);
-        par ^= 1;
       }
+    }
+    // the item's record: [ot][32 j][32 o] dB^T | [32] da | [ot][32] db (first unit of its MLP)
+    float* rec = a.part + grp * a.rec_total + a.rec_off[unit] + sub * wide_rec_size(ot_n, first);
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      if (ot < ot_n) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rec[ot * 1024 + cd_row(r, half) * 32 + c] = dbt[ot][r];
+        if (first) {
+          const float tot = dbs[ot] + __shfl_xor(dbs[ot], 32, 64);
+          if (half == 0) rec[ot_n * 1024 + 32 + ot * 32 + c] = tot;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float tot = half_sum(dasum[r]);
+      if (c == 0) rec[ot_n * 1024 + cd_row(r, half)] = tot;
     }
   }
 }
 
-// dB, da, db: sum the workgroups' records in a fixed order (four interleaved running sums) and scatter.
+// dB, da, db: sum the items' records in a fixed order and scatter.
 __global__ void __launch_bounds__(256) wide_reduce_small_k(const WideBwdArgs a) {
   const WideGeom& g = a.g;
   const int unit = blockIdx.y;
@@ -516,21 +599,25 @@ __global__ void __launch_bounds__(256) wide_reduce_small_k(const WideBwdArgs a) 
   const WideBwdMlp& d = a.m[k];
   const int hb = 32 * unit - d.joff;
   const bool first = hb == 0;
-  const int rec_size = d.ot * 1024 + 32 + (first ? d.ot * 32 : 0);
+  const int rec_size = wide_rec_size(d.ot, first), nsub = wide_nsub(d.ot);
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= rec_size) return;
   const float* p = a.part + a.rec_off[unit] + i;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // fixed order: eight interleaved running sums over the records v = group * nsub + sub (eight independent loads in
+  // flight per thread: the loop is bound by load latency; nsub is 1, 2 or 4)
+  const int sh = nsub == 4 ? 2 : nsub == 2 ? 1 : 0, n = a.groups << sh;
+  auto at = [&](int v) { return p[(int64_t)(v >> sh) * a.rec_total + (v & (nsub - 1)) * rec_size]; };
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int w = 0;
-  for (; w + 4 <= a.groups; w += 4) {
-    float v[4];
+  for (; w + 8 <= n; w += 8) {
+    float v[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = p[(int64_t)(w + q) * a.rec_total];
+    for (int q = 0; q < 8; ++q) v[q] = at(w + q);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] += v[q];
+    for (int q = 0; q < 8; ++q) acc[q] += v[q];
   }
-  for (int q = 0; w < a.groups; ++w, ++q) acc[q] += p[(int64_t)w * a.rec_total];
-  const float total = ((acc[0] + acc[1]) + acc[2]) + acc[3];
+  for (int q = 0; w < n; ++w, ++q) acc[q] += at(w);
+  const float total = (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])));
   if (i < d.ot * 1024) {
     const int ot = i >> 10, j = (i >> 5) & 31, o = 32 * ot + (i & 31);
     if (hb + j < d.h && o < d.O) d.dB[(int64_t)o * d.h + hb + j] = total;
@@ -577,7 +664,7 @@ struct WidePlan {
   int64_t xp_plane, hf_bytes;                 // saved: [3 x XP plane | HF]
   int64_t w1p_plane, w1tp_plane, gp_plane;
   int64_t pack2_bytes, packbt_bytes;
-  int32_t splits, groups, rec_total;
+  int32_t splits, groups, rec_total, n_slots[3];
   uint32_t rec_off[kMaxWideUnits];
 };
 
@@ -585,6 +672,7 @@ bool make_wide_plan(int64_t T, int32_t E, int32_t K, const int32_t* h, const int
   if (T < 1 || E < 16 || E > 1024 || (E & 15) || K < 1 || K > kMaxWideMlps || !h || !O) return false;
   WideGeom& g = p->g;
   int j = 0, rec = 0;
+  p->n_slots[0] = p->n_slots[1] = p->n_slots[2] = 0;
   for (int u = 0; u < kMaxWideUnits; ++u) g.unit_k[u] = -1, p->rec_off[u] = 0;
   for (int k = 0; k < K; ++k) {
     if (h[k] < 1 || h[k] > 128 || O[k] < 1 || O[k] > 32 * kOtMax) return false;
@@ -594,7 +682,8 @@ bool make_wide_plan(int64_t T, int32_t E, int32_t K, const int32_t* h, const int
     for (int u = 0; u < nu; ++u) {
       g.unit_k[j / 32 + u] = k;
       p->rec_off[j / 32 + u] = (uint32_t)rec;
-      rec += p->ot[k] * 1024 + 32 + (u == 0 ? p->ot[k] * 32 : 0);
+      rec += wide_nsub(p->ot[k]) * wide_rec_size(p->ot[k], u == 0);
+      p->n_slots[wide_class(O[k])] += wide_nsub(p->ot[k]);
     }
     j += 32 * nu;
   }
@@ -612,10 +701,11 @@ bool make_wide_plan(int64_t T, int32_t E, int32_t K, const int32_t* h, const int
   p->pack2_bytes = (int64_t)(g.J / 32) * kOtMax * 3 * kPack2Tile;
   p->packbt_bytes = (int64_t)(g.J / 32) * 8 * 3 * kPackBtStep;
   p->groups = (int32_t)(g.T_pad / 256);
-  // split-K of the weight-gradient GEMM: enough workgroups for every CU, at least 32 k-chunks (512 tokens) each
+  // split-K of the weight-gradient GEMM: ONE round of workgroups (one per CU, never 256 + a few: the few would run a
+  // second round alone), at least 32 k-chunks (512 tokens) each
   const int tiles = (g.J_pad / 256) * (g.E_pad / 256);
   const int64_t chunks = g.T_pad / 16;
-  int s = (256 + tiles - 1) / tiles;
+  int s = 256 / tiles;
   if (s > chunks / 32) s = (int)(chunks / 32);
   if (s > kSplitsMax) s = kSplitsMax;
   if (s < 1) s = 1;
@@ -628,7 +718,7 @@ int64_t fwd_ws_bytes(const WidePlan& p) {
   return 3 * p.w1p_plane + up((int64_t)p.g.J_pad * 4, 256) + p.pack2_bytes + up((int64_t)p.g.K * kOtMax * 32 * 4, 256);
 }
 int64_t bwd_ws_bytes(const WidePlan& p) {
-  return 3 * p.w1tp_plane + p.packbt_bytes + 3 * p.gp_plane + up((int64_t)p.groups * p.rec_total * 4, 256) +
+  return 3 * p.w1tp_plane + p.packbt_bytes + kSlotBytes + 3 * p.gp_plane + up((int64_t)p.groups * p.rec_total * 4, 256) +
          (int64_t)p.splits * p.g.J_pad * p.g.E_pad * 4;
 }
 
@@ -731,17 +821,27 @@ int psf_mlp_wide_bwd_f32(const void* saved, int64_t saved_bytes_given, int64_t T
   unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
   for (int t = 0; t < 3; ++t) ba.w1tp[t] = ws + t * p.w1tp_plane;
   ba.packbt = ws + 3 * p.w1tp_plane;
-  for (int t = 0; t < 3; ++t) ba.gp[t] = ba.packbt + p.packbt_bytes + t * p.gp_plane;
+  ba.slots = reinterpret_cast<uint32_t*>(ba.packbt + p.packbt_bytes);
+  for (int t = 0; t < 3; ++t) ba.gp[t] = ba.packbt + p.packbt_bytes + kSlotBytes + t * p.gp_plane;
   ba.part = reinterpret_cast<float*>(ba.gp[0] + 3 * p.gp_plane);
   float* dapart = ba.part + up((int64_t)p.groups * p.rec_total * 4, 256) / 4;
   ba.dapart = dapart;
   ba.HF = reinterpret_cast<const float*>(sv + 3 * p.xp_plane);
   for (int u = 0; u < kMaxWideUnits; ++u) ba.rec_off[u] = p.rec_off[u];
   ba.rec_total = p.rec_total, ba.groups = p.groups, ba.splits = p.splits;
+  for (int c3 = 0; c3 < 3; ++c3) ba.n_slots[c3] = p.n_slots[c3];
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
   hipLaunchKernelGGL(wide_pack_bwd_k, dim3(512), dim3(256), 0, s, ba);
-  hipLaunchKernelGGL(wide_mid_k, dim3((unsigned)p.groups), dim3(512), 0, s, ba);
+  for (int cls = 0; cls < 3; ++cls) {  // (256-token group, hidden unit [, part of the group]): one wave per item
+    const int64_t items = (int64_t)p.groups * p.n_slots[cls];
+    if (!items) continue;
+    const int64_t wgs = (items + 7) / 8;
+    const dim3 grid((unsigned)(wgs < 256 ? wgs : 256));
+    if (cls == 0) hipLaunchKernelGGL((wide_mid_k<1, 8>), grid, dim3(512), 0, s, ba, cls);
+    else if (cls == 1) hipLaunchKernelGGL((wide_mid_k<1, 16>), grid, dim3(512), 0, s, ba, cls);
+    else hipLaunchKernelGGL((wide_mid_k<kOtMax, 16>), grid, dim3(512), 0, s, ba, cls);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
   if (dX) {  // dX[tok][e] = sum_j G[tok][j] Wcat[j][e]
