@@ -108,8 +108,25 @@ def load() -> ctypes.CDLL:
         v = lib.psf_version()
         if v != ABI_VERSION:
             raise PSFLibraryError(f"{LIB_PATH} has ABI version {v}, this package needs {ABI_VERSION}; rebuild it")
+        _warn_if_stale(lib)
         _lib = lib
     return _lib
+
+
+def _warn_if_stale(lib) -> None:
+    """A library built from other kernel sources than the ones in csrc/ (an edit without a rebuild) is loaded, but loudly."""
+    import re
+    import warnings
+    csrc = os.path.join(PKG_DIR, "csrc")
+    if not os.path.isdir(csrc):
+        return  # a binary-only installation: nothing to compare with
+    m = re.search(r"csrc=([0-9a-f]{64})", lib.psf_build_info().decode("utf-8", "replace"))
+    from .build import csrc_hash
+    want = csrc_hash()
+    if m is None or m.group(1) != want:
+        warnings.warn(f"{LIB_PATH} was built from other sources than sparsefactorization_amd/csrc "
+                      f"(library {m.group(1)[:12] if m else 'unstamped'}, tree {want[:12]}): run "
+                      "`python -m sparsefactorization_amd.build`", RuntimeWarning, stacklevel=3)
 
 
 def last_error() -> str:

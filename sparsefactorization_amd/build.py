@@ -59,7 +59,7 @@ def hipcc() -> str:
 
 def _units():
     """(object path, source, extra flags) for every translation unit."""
-    units = [(os.path.join(OBJ_DIR, "psf_chord.o"), os.path.join(CSRC, "psf_chord.hip"), []),
+    units = [(os.path.join(OBJ_DIR, "psf_chord.o"), os.path.join(CSRC, "psf_chord.hip"), [f'-DPSF_CSRC_HASH="{csrc_hash()}"']),
              (os.path.join(OBJ_DIR, "linear_wgrad.o"), os.path.join(CSRC, "linear_wgrad.hip"), []),
              (os.path.join(OBJ_DIR, "fwd_chain_lds.o"), os.path.join(CSRC, "fwd_chain_lds_inst.hip"), []),
              (os.path.join(OBJ_DIR, "embed.o"), os.path.join(CSRC, "embed.hip"), []),
@@ -88,12 +88,21 @@ def _units():
     return units
 
 
+def built_hash(path: str = LIB_PATH):
+    """The ``csrc=<sha256>`` a library carries in its psf_build_info string (read from the file: no dlopen), or None."""
+    import re
+    try:
+        with open(path, "rb") as fh:
+            m = re.search(rb"csrc=([0-9a-f]{64})", fh.read())
+    except OSError:
+        return None
+    return m.group(1).decode() if m else None
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
-        return True
-    lib_m = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > lib_m for d in deps)
+    """True when the library is missing or was built from other sources than the ones in csrc/ now (content hash, not
+    timestamps: an edited header that no list names, or a checkout that restores old mtimes, cannot leave a stale .so)."""
+    return not os.path.exists(LIB_PATH) or built_hash() != csrc_hash()
 
 
 def _compile(unit, cc, verbose):

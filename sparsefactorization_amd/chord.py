@@ -233,7 +233,9 @@ def spmm(index: torch.Tensor, value: torch.Tensor, m: int, n: int, matrix: torch
 def _sum_tensors(terms: Sequence[torch.Tensor]) -> torch.Tensor:
     """((t0 + t1) + t2) + ... in one pass (csrc/sum_tensors.hip); all terms fp32, same shape, on one HIP device."""
     dev = _require_hip(*terms)
+    # the kernel reads 16-byte vectors: a contiguous VIEW at a storage offset (an upstream gradient) may be misaligned
     terms = [t.contiguous() for t in terms]
+    terms = [t if t.data_ptr() % 16 == 0 else t.clone() for t in terms]
     out = torch.empty_like(terms[0])
     tab = (ctypes.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
     with torch.cuda.device(dev):

@@ -600,7 +600,12 @@ const char* psf_build_info(void) {
          " | bwd: generic dV/dW<f32,f64> + LDS-window dV/dW<f32>"
          " | producers: fused MLP fwd (split-bf16 MFMA at f32 accuracy, f32 MFMA) + fused MLP bwd (split-bf16 MFMA on dual-use LDS planes, f32 MFMA),"
          " tall-skinny weight gradients (f32 MFMA), token embedding + positional add"
-         " | arithmetic of the chord path: uncontracted mul+add, links ascending";
+         " wide producer MLPs (E <= 1024: stacked first layers as split-bf16 GEMMs from bf16 term planes, LDS-DMA ring)"
+         " | arithmetic of the chord path: uncontracted mul+add, links ascending"
+#ifdef PSF_CSRC_HASH
+         " | csrc=" PSF_CSRC_HASH  // build.csrc_hash() of the sources this library was built from (_lib.load compares)
+#endif
+      ;
 }
 
 int psf_chord_offsets(int64_t N, int32_t L, int64_t* offsets_out) {

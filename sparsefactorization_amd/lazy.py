@@ -34,8 +34,13 @@ from .chord import chord_chain, chord_spmm, offsets_from_index
 
 __all__ = ["spmm", "LazyChordChain"]
 
-_ADD_FUNCS = {torch.add, torch.Tensor.add, torch.Tensor.__add__, torch.Tensor.__radd__, torch.Tensor.__iadd__,
-              torch.Tensor.add_}
+# only the out-of-place adds are fused (they return a NEW lazy chain); V.add_(res) / V += res materialize and add in place,
+# so that every alias of V sees the residual
+_ADD_FUNCS = {torch.add, torch.Tensor.add, torch.Tensor.__add__, torch.Tensor.__radd__}
+# attribute reads answered from the wrapper without running the chain; every other property (requires_grad, grad_fn,
+# is_leaf, data, T, mT, grad ...) is read from the materialized tensor
+_METADATA_PROPS = {"shape", "dtype", "device", "ndim", "layout", "is_cuda", "is_cpu", "is_sparse", "is_quantized", "is_meta",
+                   "names", "itemsize", "nbytes"}
 _METADATA_METHODS = {"size", "dim", "ndimension", "numel", "nelement", "is_floating_point", "is_complex", "element_size",
                      "stride", "is_contiguous", "get_device", "type"}
 
@@ -94,8 +99,8 @@ class LazyChordChain(torch.Tensor):
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         name = getattr(func, "__name__", "")
-        if name == "__get__" or name in _METADATA_METHODS:  # shape, dtype, device, requires_grad, size(), dim(), ...
-            with torch._C.DisableTorchFunctionSubclass():
+        if name in _METADATA_METHODS or (name == "__get__" and getattr(getattr(func, "__self__", None), "__name__", "") in _METADATA_PROPS):
+            with torch._C.DisableTorchFunctionSubclass():  # shape, dtype, device, size(), dim(), ...
                 return func(*args, **kwargs)
         if func in _ADD_FUNCS and len(args) == 2 and not kwargs:  # V + res_conn: fuse into the last step
             a, b = args

@@ -84,12 +84,48 @@ class ChunkedAdam(torch.optim.Optimizer):
     Adam gives a workgroup 65 536 elements, which runs the two 524 288-element parameters of a PSFNet at N = 16384
     (``pos_embedding``, ``final``) on 16 workgroups: 2 x 43 us per step against ~2 x 5 here.
 
-    State per parameter under torch's Adam's names (``step``, ``exp_avg``, ``exp_avg_sq``; ``step`` is a host float, or with
-    ``capturable`` the shared device scalar). ``capturable``: ONE device scalar counts the steps for all parameters (advanced by a one-element kernel, read by the update kernel), so a
-    captured step can be replayed; parameters whose ``.grad`` is None are skipped, as in torch."""
+    State per parameter under torch's Adam's names (``step``, ``exp_avg``, ``exp_avg_sq``); ``state_dict`` /
+    ``load_state_dict`` / ``torch.save`` work as for any optimizer (the host-side launch plan — ctypes pointer tables —
+    lives outside ``param_groups`` and is rebuilt whenever a parameter, a gradient set or a state tensor changes address).
+
+    ``capturable``: ``step`` is ONE device scalar shared by all parameters of a group (advanced by a one-element kernel,
+    read by the update kernel), so a captured step can be replayed. That is torch's Adam as long as every parameter that
+    ever gets a gradient gets one on EVERY step (PSFNet: parameters the forward does not use never get one and are simply
+    skipped); a parameter that joins or leaves the set of updated parameters later would take another parameter's bias
+    correction, so that raises instead. A non-capturable instance raises when stepped under stream capture (the host step
+    count would be baked into the graph), like torch's Adam."""
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, capturable: bool = False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, capturable=capturable))
+        self._plans: Dict[int, tuple] = {}       # group index -> (key, pointer tables..., states)
+        self._step_devs: Dict[int, torch.Tensor] = {}  # group index -> the shared device step counter (capturable)
+        self._cap_live: Dict[int, tuple] = {}    # group index -> ids of the parameters the shared counter counts for
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plans.clear()
+        self._step_devs.clear()
+        self._cap_live.clear()
+        for gi, group in enumerate(self.param_groups):  # re-link the loaded per-parameter counters to ONE device scalar
+            if not group["capturable"]:
+                for p in group["params"]:
+                    st = self.state.get(p)
+                    if st and torch.is_tensor(st.get("step")):
+                        st["step"] = float(st["step"])
+                continue
+            steps = [self.state[p]["step"] for p in group["params"] if self.state.get(p)]
+            if not steps:
+                continue
+            vals = {float(t) for t in steps}
+            if len(vals) != 1:
+                raise RuntimeError("ChunkedAdam(capturable=True) shares one step counter per group; the loaded state has "
+                                   f"different counts {sorted(vals)}")
+            p0 = next(p for p in group["params"] if self.state.get(p))
+            dev_step = torch.full((), vals.pop(), dtype=torch.float32, device=p0.device)
+            self._step_devs[gi] = dev_step
+            for p in group["params"]:
+                if self.state.get(p):
+                    self.state[p]["step"] = dev_step
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -100,41 +136,50 @@ class ChunkedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             live = [p for p in group["params"] if p.grad is not None]
             if not live:
                 continue
             dev = live[0].device
             cap = group["capturable"]
-            if cap and "_step_dev" not in group:
-                group["_step_dev"] = torch.zeros((), dtype=torch.float32, device=dev)
-            # host-side plan (pointer tables of the parameters and their moments), rebuilt only when the set of
-            # parameters with a gradient changes: the small LRA models are launch-bound, every microsecond here counts
-            key = tuple(map(id, live))
-            plan = group.get("_plan")
+            if not cap and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("ChunkedAdam: stepping under stream capture needs capturable=True (the host step count "
+                                   "would be baked into the captured kernel arguments)")
+            if cap:
+                if gi not in self._step_devs:
+                    self._step_devs[gi] = torch.zeros((), dtype=torch.float32, device=dev)
+                ids = tuple(map(id, live))
+                if self._cap_live.setdefault(gi, ids) != ids:
+                    raise RuntimeError("ChunkedAdam(capturable=True): the set of parameters with a gradient changed between "
+                                       "steps; the shared step counter would give the newcomers another parameter's bias "
+                                       "correction. Use capturable=False (per-parameter counts) for such a model.")
+            for p in live:
+                st = self.state[p]
+                if not st:
+                    st["step"] = self._step_devs[gi] if cap else 0.0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            # host-side plan (pointer tables of the parameters and their moments), rebuilt only when a tensor of it
+            # moved: the small LRA models are launch-bound, every microsecond here counts
+            states = [self.state[p] for p in live]
+            key = tuple((p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) for p, st in zip(live, states))
+            plan = self._plans.get(gi)
             if plan is None or plan[0] != key:
-                for p in live:
-                    st = self.state[p]
-                    if not st:
-                        st["step"] = group["_step_dev"] if cap else 0.0
-                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 n = len(live)
                 tab = lambda ts: (ctypes.c_void_p * n)(*[x.data_ptr() for x in ts])  # noqa: E731
-                plan = (key, tab(live), tab([self.state[p]["exp_avg"] for p in live]),
-                        tab([self.state[p]["exp_avg_sq"] for p in live]), (ctypes.c_int64 * n)(*[p.numel() for p in live]),
-                        [self.state[p] for p in live])
-                group["_plan"] = plan
-            _, ptab, mtab, vtab, sizes, states = plan
+                plan = (key, tab(live), tab([st["exp_avg"] for st in states]), tab([st["exp_avg_sq"] for st in states]),
+                        (ctypes.c_int64 * n)(*[p.numel() for p in live]))
+                self._plans[gi] = plan
+            _, ptab, mtab, vtab, sizes = plan
             n = len(live)
             gtab = (ctypes.c_void_p * n)(*[(p.grad if p.grad.is_contiguous() else p.grad.contiguous()).data_ptr() for p in live])
             b1, b2 = group["betas"]
             stream = torch.cuda.current_stream(dev).cuda_stream
             with torch.cuda.device(dev):
                 if cap:
-                    group["_step_dev"].add_(1.0)
+                    self._step_devs[gi].add_(1.0)
                     rc = lib.psf_adam_step_f32(ptab, gtab, mtab, vtab, sizes, n, group["lr"], b1, b2, group["eps"], 1.0,
-                                               group["_step_dev"].data_ptr(), stream)
+                                               self._step_devs[gi].data_ptr(), stream)
                 else:
                     t0 = states[0]["step"] + 1.0
                     uniform = True
@@ -235,6 +280,9 @@ class GraphedStep:
         if not X.is_cuda:
             raise RuntimeError("GraphedStep needs GPU tensors")
         check_capturable(net)
+        if reducer is None and not optimizer.defaults.get("capturable", False):
+            raise RuntimeError("GraphedStep captures optimizer.step(): build the optimizer with capturable=True "
+                               "(make_adam(..., capturable=True)); a host-side step count would be frozen into the graph")
         self.net, self.optimizer, self.loss, self.reducer = net, optimizer, loss, reducer
         self.X, self.Y = X.clone(), Y.clone()
         # a plain nn.Embedding that is actually looked up (not just a parameter holder like pos_embedding, whose
@@ -245,12 +293,15 @@ class GraphedStep:
                 hooks.append(m.register_forward_hook(lambda _m, _i, _o, _n=name: called.append(_n)))
         # the warm-up steps are real optimisation steps; they are undone after the capture (parameters, buffers and
         # optimizer state restored IN PLACE — the graph holds their addresses), so a graphed run starts from the same
-        # state, and follows the same trajectory, as an eager one (tests/test_reference_pins.py)
+        # state, and follows the same trajectory, as an eager one (tests/test_reference_pins.py; with dropout too: the
+        # generator states are put back, and a replay advances the philox offset by what an eager step draws)
         with torch.no_grad():
             tensors = list(net.parameters()) + list(net.buffers())
             snapshot = [t.detach().clone() for t in tensors]
         opt_before = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in optimizer.state[p].items()}
                       for p in optimizer.state}
+        # warm-up and capture draw random numbers (dropout): the generator states are restored below too
+        rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(X.device)
         side = torch.cuda.Stream(device=X.device)
         side.wait_stream(torch.cuda.current_stream(X.device))
         with torch.cuda.stream(side):  # eager warm-up on a side stream (allocator, lazy initialisations, autotuning)
@@ -278,6 +329,8 @@ class GraphedStep:
                         v.copy_(before[k]) if k in before else v.zero_()
                     elif k == "step":  # a host-side step count (ChunkedAdam, not capturable)
                         st[k] = before.get(k, 0.0)
+        torch.set_rng_state(rng_cpu)
+        torch.cuda.set_rng_state(rng_dev, X.device)
 
     def _step(self, zero: bool = True, eager_tail: bool = True):
         if zero:

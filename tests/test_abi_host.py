@@ -290,3 +290,20 @@ def test_genome_surface(lib):
     cfg.update(n_vec=64, n_W=6)
     net = PSFNet(**cfg)
     assert net.embedding.padding_idx is None
+
+
+def test_library_carries_the_hash_of_its_sources_and_a_stale_one_is_reported(monkeypatch):
+    """psf_build_info ends in csrc=<sha256 of csrc/ + the header>; build.needs_build and _lib.load compare it with the
+    tree, so an edited kernel source cannot silently run on an old binary."""
+    import warnings
+    from sparsefactorization_amd import _lib, build
+    lib = _lib.load()
+    assert ("csrc=" + build.csrc_hash()).encode() in lib.psf_build_info()
+    assert build.built_hash() == build.csrc_hash() and not build.needs_build()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _lib._warn_if_stale(lib)  # fresh: silent
+    monkeypatch.setattr(build, "csrc_hash", lambda: "0" * 64)
+    assert build.needs_build()
+    with pytest.warns(RuntimeWarning, match="built from other sources"):
+        _lib._warn_if_stale(lib)

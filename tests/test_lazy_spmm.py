@@ -143,3 +143,27 @@ def test_lazy_loop_on_the_gpu_matches_chord_chain(gpu, B, N, M, C, res):
     with torch.no_grad():  # evaluation mode: recorded and run without autograd
         ev = _reference_loop(lazy.spmm, idx, Wa, Va, N, res)
         assert torch.equal(ev[:, 0, :], want[:, 0, :]) and not ev.materialize().requires_grad
+
+
+def test_in_place_adds_reach_every_alias_and_properties_come_from_the_value(cpu_chain):
+    """``V.add_(res)`` / ``V += res`` are not recorded (a recorded add returns a NEW chain and would leave aliases of V
+    without the residual): the chain runs and the add happens in place on its value. Properties other than the
+    shape / dtype / device family are read from the evaluated tensor (requires_grad, T, data ...)."""
+    from sparsefactorization_amd import lazy
+    idx, Ws, V0 = _inputs(M=2)
+    reshape = lambda W: W.reshape(W.size(0), -1)  # noqa: E731
+    want = oc.torch_spmm_port(idx, reshape(Ws[0]), 64, 64, V0) + V0
+    V = lazy.spmm(idx, reshape(Ws[0]), 64, 64, V0)
+    alias = V
+    V.add_(V0)                                    # statement form: V itself must now hold the sum
+    assert torch.equal(alias * 1.0, want) and torch.equal(V * 1.0, want)
+    V = lazy.spmm(idx, reshape(Ws[0]), 64, 64, V0)
+    alias = V
+    V += V0
+    assert torch.equal(V * 1.0, want) and torch.equal(alias * 1.0, want)
+    Wg = Ws[0].clone().requires_grad_(True)
+    with torch.enable_grad():
+        Vg = lazy.spmm(idx, reshape(Wg), 64, 64, V0)
+        assert Vg.shape == (3, 64, 8) and cpu_chain["step"] + cpu_chain["chain"] == 2  # shape: still nothing new ran
+        assert Vg.requires_grad and Vg.grad_fn is not None and not Vg.is_leaf     # read from the evaluated chain
+    assert torch.equal(Vg.mT, Vg.materialize().mT) and torch.equal(Vg.data, Vg.materialize().data)
