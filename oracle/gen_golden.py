@@ -24,6 +24,7 @@ structure, W's memory layout and the residual semantics against real reference c
 against that restatement (cross-checked in tests against spmul/spmul_cuda.cu's formulas and a dense matmul).
 
     python oracle/gen_golden.py            # rewrites every fixture
+    python oracle/gen_golden.py cfg3       # only train_lra_listops_cfg3_n2048.npz
 """
 from __future__ import annotations
 
@@ -427,6 +428,69 @@ def gen_training_lra(lra, utils):
         torch.Tensor.cuda = real_cuda
 
 
+CFG3_MODEL = dict(vocab_size=17, embedding_size=64, n_vec=2048, n_W=11, Ws=[128, 'GELU'], V=[128, 'GELU'], n_channels_V=64,
+                  n_class=10, pooling_type="CLS", head=['linear'], use_cuda=False, use_residuals=False, dropout1_p=0,
+                  dropout2_p=0, dropout3_p=0, init_embedding_weights=False, use_pos_embedding=True, problem="listops")
+
+
+def gen_training_lra_cfg3(lra, utils):
+    """BASELINE.json configs[2] at its own size — "LRA ListOps N=2048, dim=64, full PSF model training loop": the
+    reference's TrainPSF (LRA/psf_utils.py:48-128) on its LRA PSFNet with the ListOps configuration
+    (LRA/psf_training_config.py:2-30: 11 factors, hidden 128, CLS pooling, padding_idx embedding, positional embedding, no
+    residual) at embedding_size = n_channels_V = 64 and N = 1 + 2047 (the CLS token prepended as listops_training.py:65-72
+    does). 1 epoch x 4 fixed batches of 4, evaluation on 1 + 1 batches, CrossEntropyLoss, Adam(1e-3), seed_everything(42).
+    The initial state is pinned by hash (seed_everything(42) + construction reproduces it), the end state by its small tensors."""
+    import contextlib
+    import io
+    import re
+    from torch.utils.data import DataLoader
+    cfg = CFG3_MODEL
+    BATCH, NB, NE = 4, 4, 1
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        utils.seed_everything(42)
+        net = lra.PSFNet(**cfg)
+        sd0 = state_arrays(net)
+        optimizer = torch.optim.Adam(net.parameters(), lr=0.001)
+        loss = RecordingLoss(torch.nn.CrossEntropyLoss())
+        g = torch.Generator().manual_seed(2026)
+
+        def split(n):
+            data = torch.randint(0, 15, (n, cfg["n_vec"] - 1), generator=g)
+            labels = torch.randint(0, 10, (n,), generator=g)
+            cls_token = torch.tensor([[cfg['vocab_size'] - 1] * data.size(0)]).T  # listops_training.py:65-72
+            return data, torch.cat([cls_token, data], -1), labels
+
+        (raw_tr, Xtr, Ytr), (raw_va, Xva, Yva), (raw_te, Xte, Yte) = split(BATCH * NB), split(BATCH * NE), split(BATCH * NE)
+        mk = lambda X, Y: DataLoader(utils.DatasetCreator(X, Y), batch_size=BATCH, shuffle=False, drop_last=True,  # noqa: E731
+                                     num_workers=0)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+            utils.TrainPSF(net=net, trainloader=mk(Xtr, Ytr), valloader=mk(Xva, Yva), testloader=mk(Xte, Yte),
+                           n_epochs=1, test_freq=1, optimizer=optimizer, loss=loss, problem="listops", saving_criteria=1e9)
+        text = buf.getvalue()
+        num = r"([-+0-9.eE]+)"
+        printed = {key: [float(x) for x in re.findall(pat + num, text)]
+                   for key, pat in (("train_loss", r"Training loss:\s+"), ("val_loss", r"Val  loss: "),
+                                    ("test_loss", r"Test loss: "), ("val_acc", r"Val  accuracy: "),
+                                    ("test_acc", r"Test accuracy: "))}
+        assert len(loss.values) == NB + 2 * NE and all(len(v) == 1 for v in printed.values())
+        vals = np.asarray(loss.values, dtype=np.float64)
+        u8 = lambda t: t.numpy().astype(np.uint8)  # noqa: E731
+        end = state_arrays(net)
+        small = {"final::" + k[4:]: v for k, v in end.items() if v.size <= 2048}  # biases, second layers of the link MLPs, head
+        save("train_lra_listops_cfg3_n2048.npz", raw_tr=u8(raw_tr), Ytr=u8(Ytr), raw_va=u8(raw_va), Yva=u8(Yva), raw_te=u8(raw_te),
+             Yte=u8(Yte), step_loss=vals[:NB].copy(), val_batch_loss=vals[NB:NB + NE].copy(), test_batch_loss=vals[NB + NE:].copy(),
+             **{"printed_" + k: np.asarray(v) for k, v in printed.items()},
+             sd0_names=np.asarray([k[4:] for k in sorted(sd0)]), sd0_sha256=np.asarray([sha256(sd0[k]) for k in sorted(sd0)]),
+             end_names=np.asarray([k[4:] for k in sorted(end)]), end_absmax=np.asarray([float(np.abs(end[k]).max()) for k in sorted(end)]),
+             end_sum=np.asarray([float(end[k].astype(np.float64).sum()) for k in sorted(end)]), **small)
+        print(f"  cfg3 (N = 2048, E = C = 64): step losses {vals[:NB]}; printed {printed}")
+    finally:
+        torch.Tensor.cuda = real_cuda
+
+
 # ---------------------------------------------------------------------------------------------------
 # 4. attention_block.py
 # ---------------------------------------------------------------------------------------------------
@@ -493,13 +557,20 @@ def gen_synth_data(gen):
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # deterministic CPU reductions
+    only = sys.argv[1] if len(sys.argv) > 1 else None  # "cfg3": only that fixture
     se = import_reference("ref_se_psf", "SyntheticExperiments/psf.py")
     lra = import_reference("ref_lra_psf", "LRA/psf.py")
-    gen_indices(se)
-    gen_synthetic(se)
-    gen_lra(lra)
-    gen_training(se, import_reference("ref_se_psf_utils", "SyntheticExperiments/psf_utils.py"))
-    gen_training_lra(lra, import_reference("ref_lra_psf_utils", "LRA/psf_utils.py"))
+    if only is None:
+        gen_indices(se)
+        gen_synthetic(se)
+        gen_lra(lra)
+        gen_training(se, import_reference("ref_se_psf_utils", "SyntheticExperiments/psf_utils.py"))
+    lra_utils = import_reference("ref_lra_psf_utils", "LRA/psf_utils.py")
+    if only in (None, "cfg3"):
+        gen_training_lra_cfg3(lra, lra_utils)
+    if only is not None:
+        return
+    gen_training_lra(lra, lra_utils)
     gen_attention_block()
     gen_synth_data(import_reference("ref_synth_data_generation", "SyntheticExperiments/synth_data_generation.py"))
     gen_genome(import_reference("ref_genome_psf", "Genome_Clf/psf.py"))

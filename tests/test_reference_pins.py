@@ -488,3 +488,82 @@ def test_lra_train_harness_follows_the_reference_trajectory(gpu, mode):
     for e in range(2):
         assert abs(hist[e]["train"]["loss"] - g["printed_train_loss"][e]) <= 1e-4 * g["printed_train_loss"][e]
         assert abs(hist[e]["test"]["accuracy"] - g["printed_test_acc"][e]) <= 100.0 / 64 + 1e-6  # one borderline sample
+
+
+CFG3 = dict(vocab_size=17, embedding_size=64, n_vec=2048, n_W=11, Ws=[128, 'GELU'], V=[128, 'GELU'], n_channels_V=64,
+            n_class=10, pooling_type="CLS", head=['linear'], use_residuals=False, dropout1_p=0, dropout2_p=0, dropout3_p=0,
+            init_embedding_weights=False, use_pos_embedding=True, problem="listops")
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_cfg3_seed_42_draws_the_reference_initial_weights():
+    """BASELINE.json configs[2] at its own size (ListOps, N = 2048, dim = 64): the fixture holds the SHA-256 of every tensor
+    of the reference network's initial state_dict; the same seed and constructor here reproduce them bit for bit."""
+    from sparsefactorization_amd.lra_psf import PSFNet
+    from sparsefactorization_amd.train import seed_everything
+    g = load_golden("train_lra_listops_cfg3_n2048.npz")
+    seed_everything(42)
+    sd = PSFNet(**CFG3, use_cuda=False).state_dict()
+    assert sorted(sd.keys()) == [str(n) for n in g["sd0_names"]]
+    for name, want in zip(g["sd0_names"], g["sd0_sha256"]):
+        assert _sha(sd[str(name)].numpy()) == str(want), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_cfg3_listops_training_follows_the_reference_at_full_size(gpu, mode):
+    """cfg3 at BASELINE size — N = 1 + 2047 (CLS prepended, listops_training.py:65-72), E = C = 64, 11 factors, B = 4: the
+    four step losses, the evaluation losses and the end state of the reference's own TrainPSF run (LRA/psf_utils.py:48-128,
+    executed by oracle/gen_golden.py) are reproduced to 1e-4 by train.TrainPSF on the HIP path — embedding kernel, the
+    WIDE producer-MLP kernels (E = 64, 64 channels), the LDS-resident chain and its backward kernels, fused Adam —
+    eagerly and replaying one captured HIP graph."""
+    from sparsefactorization_amd import fused_mlp
+    from sparsefactorization_amd.lra_psf import PSFNet
+    from sparsefactorization_amd.lra_training import add_cls_token
+    from sparsefactorization_amd.train import DeviceBatches, GraphedStep, TrainPSF, make_adam, seed_everything
+    g = load_golden("train_lra_listops_cfg3_n2048.npz")
+    seed_everything(42)
+    net = PSFNet(**CFG3, use_cuda=True).to(gpu)
+    i64 = lambda k: torch.from_numpy(g[k].astype(np.int64)).to(gpu)  # noqa: E731
+    data = {s: (add_cls_token(i64("raw_" + s), 17), i64("Y" + s)) for s in ("tr", "va", "te")}
+    assert data["tr"][0].shape == (16, 2048) and bool((data["tr"][0][:, 0] == 16).all())
+    mk = lambda s: DeviceBatches(*data[s], 4, shuffle=False, drop_last=True)  # noqa: E731
+    loss = _Recording(torch.nn.CrossEntropyLoss())
+    optimizer = make_adam(net.parameters(), 0.001, capturable=mode == "graph")
+    wide_calls = []
+    orig = fused_mlp.wide_apply
+    fused_mlp.wide_apply = lambda x, b: (wide_calls.append(len(b)), orig(x, b))[1]
+    try:
+        tap, steps = None, []
+        if mode == "graph":
+            graphed = GraphedStep(net, optimizer, loss.inner, data["tr"][0][:4], data["tr"][1][:4])
+
+            def tap(X, Y):
+                out = graphed(X, Y)
+                steps.append(out.detach().clone())
+                return out
+        hist = TrainPSF(net=net, trainloader=mk("tr"), valloader=mk("va"), testloader=mk("te"), n_epochs=1, test_freq=1,
+                        optimizer=optimizer, loss=loss, problem="listops", saving_criteria=1e9, log=lambda s: None, graphed=tap)
+    finally:
+        fused_mlp.wide_apply = orig
+    assert wide_calls and all(n == 12 for n in wide_calls)  # g + 11 link MLPs through psf_mlp_wide_*
+    vals = np.asarray([float(v) for v in loss.values])
+    got_steps = np.asarray([float(v) for v in steps]) if mode == "graph" else vals[:4]
+    got_eval = vals[-2:]
+    assert np.all(np.isfinite(got_steps))
+    assert np.max(np.abs(got_steps - g["step_loss"]) / np.abs(g["step_loss"])) <= 1e-4, (got_steps, g["step_loss"])
+    assert abs(got_eval[0] - g["val_batch_loss"][0]) <= 2e-4 * g["val_batch_loss"][0]
+    assert abs(got_eval[1] - g["test_batch_loss"][0]) <= 2e-4 * g["test_batch_loss"][0]
+    assert abs(hist[0]["train"]["loss"] - g["printed_train_loss"][0]) <= 1e-4 * g["printed_train_loss"][0]
+    assert hist[0]["val"]["accuracy"] == g["printed_val_acc"][0] and hist[0]["test"]["accuracy"] == g["printed_test_acc"][0]
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    for name, absmax, total in zip(g["end_names"], g["end_absmax"], g["end_sum"]):
+        v = sd[str(name)]
+        assert abs(float(np.abs(v).max()) - absmax) <= 1e-3 * absmax + 1e-7, name
+    for key in g.files:
+        if key.startswith("final::"):
+            assert rel_inf(sd[key[7:]], g[key]) <= 2e-3, key  # four Adam steps of lr 1e-3 on top of 1e-4-accurate gradients

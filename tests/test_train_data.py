@@ -130,9 +130,15 @@ def test_lra_driver_host_logic():
 @pytest.mark.gpu
 def test_lra_training_driver_runs_on_gpu(gpu, capsys):
     from sparsefactorization_amd import lra_training
+    import json
+    import math
     lra_training.main(["--task", "listops", "--train-seqs", "160", "--eval-seqs", "32", "--json", "--max-steps", "3"])
     out = capsys.readouterr().out
-    assert '"task": "listops"' in out and '"n_vec": 2000' in out
+    rec = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    # the reference configuration at full size (N = 2000, E = 512, 128 channels, batch 32): numbers, not substrings
+    assert rec["task"] == "listops" and rec["n_vec"] == 2000 and rec["batch_per_gpu"] == 32 and rec["steps"] == 3
+    assert math.isfinite(rec["loss"]) and 0.5 < rec["loss"] < 20.0  # ten classes, random labels: around ln 10 = 2.3
+    assert rec["ms_per_step"] > 0 and math.isfinite(rec["value"]) and rec["value"] > 0
     lra_training.main(["--task", "pathfinder", "--train-seqs", "128", "--eval-seqs", "64", "--epochs", "1"])
     out = capsys.readouterr().out
     assert "Training loss" in out and "Test accuracy" in out
