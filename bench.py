@@ -24,9 +24,14 @@ cpu_baseline = the reference's CPU op sequence (index_select -> mul -> scatter_a
   torch_sparse.spmm executes on CPU tensors) restated in torch CPU ops (oracle/), timed on this host's cores on a
   bounded sample of the same workload, best of a thread-count sweep; cpu_baseline_cfg1 = the same at BASELINE.json
   configs[0] (Adding N = 128, M = 7, B = 40 — the reference's own CPU-runnable case). Reported, not targeted.
+roofline.peak_measured / frac_of_measured = the same achieved rate against what a plain triad sustains on this box
+  (measured in this run, outside the timed region) — the spec peak is a datasheet figure.
 train = the data-parallel leg (BASELINE.json configs[4]): Temporal Order N = 16384, B = 40 per
   GPU, full training step of the reference loop (psf_utils.py:62-71) with ONE flat RCCL gradient all-reduce;
   tokens/s over all ranks and the mean device time of the all-reduce. Not part of the headline's timed region.
+  With several ranks the step is replayed from a HIP graph by default (--no-train-graph: eager).
+train_listops = BASELINE.json configs[2] (one GPU only): the ListOps training step at the reference's configuration
+  and at BASELINE's wording (N = 2048, dim = 64).
 """
 from __future__ import annotations
 
@@ -43,7 +48,8 @@ if ROOT not in sys.path:
 
 N_SEQ, M_FACTORS, C_CH, B_PER_GPU = 16384, 14, 8, 64
 L_LINKS = M_FACTORS + 1
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy rate
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the rate this box sustains is measured below
+PREHEAT_S = 0.3        # seconds of untimed chains before the warm-up steps (brings the clocks up; printed in the line)
 TRAIN_PROBLEM, TRAIN_N, TRAIN_B = "order", 16384, 40  # SyntheticExperiments/synthetic_training_config.py:72-86
 
 
@@ -57,8 +63,11 @@ def parse_args(argv=None):
                     help="also time the data-parallel training leg (default)")
     ap.add_argument("--no-train", dest="train", action="store_false")
     ap.add_argument("--train-steps", type=int, default=20)
-    ap.add_argument("--train-graph", action="store_true",
-                    help="training leg: replay forward+backward from a HIP graph (all-reduce + Adam stay eager)")
+    ap.add_argument("--train-graph", dest="train_graph", action="store_true", default=None,
+                    help="training leg: replay the step from a HIP graph (with several ranks: forward+backward; all-reduce + "
+                         "Adam stay eager). Default: on when --gpus > 1 — ~150 launches per step from each of N host "
+                         "processes is where the scaling of a 2.4 ms step is decided — off on one GPU")
+    ap.add_argument("--no-train-graph", dest="train_graph", action="store_false")
     return ap.parse_args(argv)
 
 
@@ -87,7 +96,10 @@ def self_launch(args) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    # The GPU pool's own requirement for multi-process GPU work (its host driver only supports dmabuf IPC; the pool
+    # exports this variable on every box). Kept as a default so that a child started from a stripped environment still
+    # has it. No run of ours has shown it matter: no box with more than one GPU was available.
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
     line = None
@@ -193,6 +205,36 @@ def gpu_cfg1(device):
     return B * N * 200 / (e0.elapsed_time(e1) * 1e-3)
 
 
+def measured_bandwidth(device):
+    """What this GPU sustains on plain streaming kernels, outside the headline's timed region: a triad a = b + s*c over
+    three 384 MiB fp32 arrays (1.2 GB per pass, far beyond the 256 MiB Infinity Cache) and a copy of 512 MiB (1.07 GB read +
+    written), HIP events over 20 passes each. GB/s of bytes read + written."""
+    import torch
+    n = 96 * 1024 * 1024
+    a, b, c = (torch.empty(n, dtype=torch.float32, device=device) for _ in range(3))
+    b.fill_(1.0), c.fill_(2.0)
+    src, dst = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device=device).fill_(3.0), None
+    dst = torch.empty_like(src)
+
+    def timed(fn, nbytes, reps=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(device)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(device)
+        return nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    triad = timed(lambda: torch.add(b, c, alpha=0.5, out=a), 3 * 4 * n)
+    copy = timed(lambda: dst.copy_(src), 2 * 4 * src.numel())
+    del a, b, c, src, dst
+    torch.cuda.empty_cache()
+    return {"triad": triad, "copy": copy}
+
+
 def pmc_traffic():
     """(bytes per launch, source) from the newest committed forward-kernel PMC summary (profiles/*_pmc.json with
     ``hbm_bytes_per_launch``). The summary records the hash of the kernel sources it was collected on
@@ -268,7 +310,7 @@ def run_rank(args) -> int:
     with torch.no_grad():
         # bring the clocks up before the W warm-up steps (a cold process measured ~10 % low): ~0.3 s of chains
         t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < 0.3:
+        while time.perf_counter() - t_pre < PREHEAT_S:
             for _ in range(8):
                 step()
             torch.cuda.synchronize(device)
@@ -297,9 +339,20 @@ def run_rank(args) -> int:
     del Ws, V0, out
     torch.cuda.empty_cache()
 
+    bw = None
+    if rank == 0:
+        try:
+            bw = measured_bandwidth(device)
+        except Exception as exc:  # bookkeeping must not lose the headline
+            bw = {"error": repr(exc)}
+    if args.train_graph is None:
+        args.train_graph = world > 1
     train = None
+    train_listops = None
     if args.train:
         train = train_leg(args, device, rank, world, dist)
+        if world == 1:
+            train_listops = listops_leg(args, device)
 
     if rank == 0:
         tokens = world * B_PER_GPU * N_SEQ * args.steps
@@ -340,13 +393,22 @@ def run_rank(args) -> int:
                 "launch_us": launch_s * 1e6,
                 "launches": launches,
                 "frac_per_gpu": [bytes_per_launch / (ms * 1e-3 / launches) / 1e9 / HBM_PEAK_GBS for ms in per_rank_ms],
+                # the second denominator: what plain streaming kernels sustain on THIS box
+                "peak_measured": bw.get("triad") if bw else None,
+                "peak_measured_copy": bw.get("copy") if bw else None,
+                "peak_measured_how": "torch triad a = b + s*c over 3 x 384 MiB fp32 / copy of 512 MiB; bytes read + written "
+                                     "per second, HIP events over 20 passes, rank 0, outside the timed region",
+                "frac_of_measured": (achieved / bw["triad"]) if bw and bw.get("triad") else None,
             },
+            "preheat_s": PREHEAT_S,
             "rank_ms_per_step": {"min": min(per_rank_ms) / args.steps, "max": max(per_rank_ms) / args.steps},
         }
         if rehearsal():
             line["rehearsal"] = "ranks share GPUs over gloo: plumbing check only, the numbers are meaningless"
         if train is not None:
             line["train"] = train
+        if train_listops is not None:
+            line["train_listops"] = train_listops
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             cfg1 = cpu_baseline_cfg1()
@@ -398,6 +460,25 @@ def train_leg(args, device, rank, world, dist):
         }
     except Exception as exc:  # the headline line must survive a failure of the secondary leg
         return {"error": repr(exc)}
+
+
+def listops_leg(args, device):
+    """BASELINE.json configs[2], "LRA ListOps — full PSF model training loop on 1 x MI355X", twice: the reference's own
+    configuration (LRA/psf_training_config.py:2-30: N = 1 + 1999, E = 512, 128 channels, batch 32) and BASELINE's wording
+    (N = 2048, dim = 64). Eager steps, one GPU; outside the headline's timed region."""
+    out = {}
+    try:
+        from sparsefactorization_amd.lra_training import train_benchmark
+        for tag, over in (("reference_config", {}), ("baseline_wording", dict(n_vec=2048, embedding_size=64, n_channels_V=64))):
+            r = train_benchmark("listops", steps=args.train_steps, warmup=5, device=device, graph=False, **over)
+            out[tag] = {"metric": f"PSF train tokens/sec, ListOps N={r['n_vec']}, E={r['embedding_size']}, "
+                                  f"C={r['n_channels_V']}, B={r['batch']}, Adam",
+                        "value": r["batch"] * r["n_vec"] * r["steps"] / r["seconds"], "unit": "tokens/s",
+                        "ms_per_step": r["seconds"] * 1e3 / r["steps"], "device_ms_per_step": r["event_ms"] / r["steps"],
+                        "steps": r["steps"], "loss": r["loss"], "hip_graph": r["hip_graph"]}
+    except Exception as exc:
+        out["error"] = repr(exc)
+    return out
 
 
 def main() -> int:

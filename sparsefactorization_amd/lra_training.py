@@ -93,6 +93,66 @@ def load_split(task: str, split: str, data_dir: str, device):
     return data, labels
 
 
+def train_benchmark(task: str, steps: int, warmup: int, device, rank: int = 0, world: int = 1, graph: bool = False,
+                    batch: int = None, n_batches: int = 4, **model_overrides) -> dict:
+    """Time ``steps`` optimisation steps of the LRA loop body (LRA/psf_utils.py:60-74: zero_grad, forward, loss, backward,
+    [gradient all-reduce,] Adam) on synthetic token batches of the task's shape (CLS prepended where the task pools on
+    it). Per-rank numbers, as ``psf_training.train_benchmark``; ``model_overrides`` change configuration entries
+    (BASELINE.json's ListOps wording: n_vec=2048, embedding_size=64, n_channels_V=64)."""
+    import torch.distributed as dist
+    cfg_model, cfg_training = dict(config[task]["model"], **model_overrides), config[task]["training"]
+    batch = batch or cfg_training["batch_size"]
+    seed_everything(42)
+    net = PSFNet(**cfg_model).to(device)
+    dp.broadcast_parameters(net)
+    optimizer = make_adam(net.parameters(), cfg_training["learning_rate"], capturable=graph and world == 1)
+    loss = nn.CrossEntropyLoss()
+    reducer = dp.FlatGradAllReduce(net.parameters(), timing=True) if world > 1 else None
+    cls = cfg_model["pooling_type"] == "CLS"
+    g = torch.Generator(device=device).manual_seed(1000 + rank)
+    n_tokens = cfg_model["vocab_size"] - (2 if task in ("listops", "imdb") else 0)
+    X = torch.randint(0, n_tokens, (batch * n_batches, cfg_model["n_vec"] - (1 if cls else 0)), device=device, generator=g)
+    Y = torch.randint(0, cfg_model["n_class"], (batch * n_batches,), device=device, generator=g)
+    if cls:
+        X = add_cls_token(X, cfg_model["vocab_size"])
+    batches = [(X[i * batch:(i + 1) * batch], Y[i * batch:(i + 1) * batch]) for i in range(n_batches)]
+    graphed = GraphedStep(net, optimizer, loss, *batches[0], reducer=reducer) if graph else None
+
+    def one(i):
+        x, y = batches[i % n_batches]
+        if graphed is not None:
+            return graphed(x, y)
+        optimizer.zero_grad(set_to_none=True)
+        out = loss(net(x).squeeze(), y)
+        out.backward()
+        if reducer is not None:
+            reducer()
+        optimizer.step()
+        return out.detach()
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for i in range(warmup):
+        one(i)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync()
+    t0 = time.perf_counter()
+    e0.record()
+    last = None
+    for i in range(steps):
+        last = one(i)
+    e1.record()
+    sync()
+    dt = time.perf_counter() - t0
+    return {"seconds": dt, "event_ms": e0.elapsed_time(e1), "steps": steps, "loss": float(last), "batch": batch,
+            "n_vec": cfg_model["n_vec"], "embedding_size": cfg_model["embedding_size"], "n_channels_V": cfg_model["n_channels_V"],
+            "hip_graph": bool(graph)}
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--task", choices=sorted(config), default="listops")

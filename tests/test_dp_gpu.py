@@ -70,3 +70,23 @@ def test_two_rank_training_of_the_real_model_equals_single_process(gpu, tmp_path
     _train(net, _batches(gpu), None, 0, 1)
     for k, v in net.state_dict().items():
         assert torch.allclose(sd0[k], v.cpu(), rtol=2e-4, atol=2e-6), k
+
+
+def test_bench_two_rank_rehearsal_replays_the_step_from_a_graph(gpu):
+    """bench.py --gpus 2 on this one-GPU box in rehearsal mode (two ranks share the GPU over gloo: plumbing only, the
+    numbers mean nothing): the self-launch, the barriers and gathers, and — the default with several ranks — the training
+    leg replaying forward + backward from a HIP graph with the flat gradient all-reduce and Adam eager behind it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PSF_BENCH_REHEARSAL="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--train-steps", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "rehearsal" in line
+    tr = line["train"]
+    assert "error" not in tr, tr
+    assert tr["hip_graph"] == "fwd+bwd" and tr["global_batch"] == 80 and tr["allreduce_us"] is not None
+    assert tr["allreduce_bytes"] > 4_000_000 and tr["loss"] == tr["loss"]  # ~1.07 M fp32 gradients, finite loss

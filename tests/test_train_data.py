@@ -242,3 +242,17 @@ def test_generators_match_the_reference_samples_in_distribution(request, where):
     assert torch.all((c_ref - c_mine).abs() < 0.04)
     first = lambda x: (x >= 4).float().argmax(1).float().mean()  # noqa: E731
     assert abs(float(first(ref_o)) - float(first(mine_o))) < 1.0
+
+
+def test_ranks_draw_different_training_data_from_the_same_model_seed():
+    """Data parallel: every rank builds the SAME model (seed_everything(42), then rank 0's weights are broadcast) and
+    draws ITS OWN data (seed 1000 + rank in psf_training.train_benchmark / 100 + rank in the drivers)."""
+    from sparsefactorization_amd.psf_training import make_split
+    x0, y0 = make_split("order", 8, 64, "cpu", 1000 + 0)
+    x1, y1 = make_split("order", 8, 64, "cpu", 1000 + 1)
+    x0b, _ = make_split("order", 8, 64, "cpu", 1000 + 0)
+    assert torch.equal(x0, x0b) and not torch.equal(x0, x1)
+    from sparsefactorization_amd import lra_training
+    a, _ = lra_training.synthetic_split("listops", 4, "cpu", 100 + 0)
+    b, _ = lra_training.synthetic_split("listops", 4, "cpu", 100 + 1)
+    assert not torch.equal(a, b)
