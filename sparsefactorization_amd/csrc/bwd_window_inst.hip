@@ -10,6 +10,7 @@
 #include <atomic>
 
 #include "bwd_dw_chunk.h"
+#include "bwd_fused.h"
 #include "bwd_window.h"
 #include "bwd_window_launch.h"
 
@@ -121,5 +122,35 @@ hipError_t launch_dv_win(int rows, int L, const BwdWinArgs& a) {
   return hipErrorInvalidValue;
 }
 template hipError_t launch_dv_win<PSF_TGS, PSF_NT>(int rows, int L, const BwdWinArgs& a);
+
+#if PSF_NT == 512
+namespace {
+template <int L, int TGS, int NT>
+hipError_t launch_fused(const BwdWinArgs& a) {
+  using Cfg = BwdFusedCfg<L, TGS, NT>;
+  auto kern = chord_bwd_fused_k<L, TGS, NT>;
+  static std::atomic<int> done{0};
+  if (hipError_t e = raise_lds_limit(kern, Cfg::lds_bytes, done); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(NT), Cfg::lds_bytes, a.stream, a.dZ, a.WV, a.V2, a.out2, a.out,
+                     a.gm, a.offs, a.w_total, a.wfar, a.far_k0);
+  return hipGetLastError();
+}
+}  // namespace
+template <int TGS>
+hipError_t launch_bwd_fused(int L, const BwdWinArgs& a, int nt) {
+  switch (L) {
+#define PSF_CASE(LL) \
+  case LL:           \
+    return nt == 256 ? launch_fused<LL, TGS, 256>(a) : launch_fused<LL, TGS, kFusedThreads>(a);
+    PSF_CASE(4) PSF_CASE(5) PSF_CASE(6) PSF_CASE(7) PSF_CASE(8) PSF_CASE(9) PSF_CASE(10) PSF_CASE(11)
+    PSF_CASE(12) PSF_CASE(13) PSF_CASE(14) PSF_CASE(15) PSF_CASE(16) PSF_CASE(17) PSF_CASE(18)
+    PSF_CASE(19) PSF_CASE(20)
+#undef PSF_CASE
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+template hipError_t launch_bwd_fused<PSF_TGS>(int L, const BwdWinArgs& a, int nt);
+#endif
 
 }  // namespace psf

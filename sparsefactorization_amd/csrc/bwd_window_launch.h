@@ -19,6 +19,8 @@ struct BwdWinArgs {
   hipStream_t stream;
   const float* wfar = nullptr;  // dV: link-major side copy of W's columns >= far_k0 (include/psf_chord.h), or nullptr
   int far_k0 = 0;
+  const float* V2 = nullptr;    // fused step (bwd_fused.h): WV = W, V2 = V, out = dV, out2 = dW
+  float* out2 = nullptr;
 };
 
 template <int TGS>
@@ -39,5 +41,9 @@ constexpr bool dv_pair_compiled(int tgs, int nt) {
 }
 template <int TGS, int NT>
 hipError_t launch_dv_win(int rows, int L, const BwdWinArgs& a);
+// fused dV + dW step (bwd_fused.h): 512 threads x 1 row, rows of exactly 4 << TGS channels, TGS <= kDvMidTgsMax; compiled
+// in the 512-thread units
+template <int TGS>
+hipError_t launch_bwd_fused(int L, const BwdWinArgs& a, int nt);  // nt: 512 (tile = 512 >> TGS rows) or 256
 
 }  // namespace psf

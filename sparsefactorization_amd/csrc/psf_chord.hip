@@ -47,6 +47,8 @@ std::atomic<int> g_fwd_split{1};
 std::atomic<int> g_bwd_rows{0};     // 0 = default, else rows per thread (R) of the backward window kernels
 // dV workgroup: 0 = auto, 1 = 256 threads (rows per thread from bwd_rows), 2 = 512 threads x 1 row (TGS <= 3)
 std::atomic<int> g_dv_threads{0};
+std::atomic<int> g_bwd_fused_nt{1};  // 1 = 256 threads (default: tile = 256 >> tgs rows), 0 = 512 threads
+std::atomic<int> g_bwd_fused{1};  // 0 = never, 1 = auto, 2 = wherever the fused step kernel applies
 std::atomic<int> g_dw_variant{0};   // dW: 0 = auto (chunk-looping kernel for C >= 32), 1 = whole-row window kernel, 2 = chunk forced
 std::atomic<int> g_dw_tgs{0};       // chunk-looping dW: 0 = auto, 4 = 8 lanes per row chunk, 5 = 16 lanes
 std::atomic<int> g_chain_fused{1};  // 1 = short sequences run the whole chain in one LDS-resident launch
@@ -82,6 +84,8 @@ Knob g_knobs[] = {
     {"fwd_wide", &g_fwd_wide, 0, 2},
     {"dw_variant", &g_dw_variant, 0, 2},
     {"dv_threads", &g_dv_threads, 0, 2},
+    {"bwd_fused", &g_bwd_fused, 0, 2},
+    {"bwd_fused_nt", &g_bwd_fused_nt, 0, 1},
     {"dw_tgs", &g_dw_tgs, 0, 5},
     {"fwd_wg_limit", &g_fwd_wg_limit, 0, 4},
     {"chain_zigzag", &g_chain_zigzag, 0, 1},
@@ -207,6 +211,38 @@ hipError_t launch_dv(const WinPick& pk, int L, const BwdWinArgs& a) {
   PSF_TGS_SWITCH(launch_dv_win, (pk.rows, L, a))
 }
 #undef PSF_TGS_SWITCH
+
+hipError_t launch_fused_step(int tgs, int L, const BwdWinArgs& a, int nt) {
+  switch (tgs) {
+    case 0: return launch_bwd_fused<0>(L, a, nt);
+    case 1: return launch_bwd_fused<1>(L, a, nt);
+    case 2: return launch_bwd_fused<2>(L, a, nt);
+    case 3: return launch_bwd_fused<3>(L, a, nt);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// The fused dV + dW step (bwd_fused.h) applies to full tiles of narrow rows: C = 4 << tgs with tgs <= 3, N a multiple of
+// the tile (512 >> tgs rows) and at least two tiles, chord near offsets, everything 16-byte aligned and chunk-clean.
+bool pick_fused_step(const void* dZ, const void* W, const void* V, const void* dW, const void* dV, int64_t B, int64_t N,
+                     int32_t L, int64_t C, int64_t v_bstride, const Offsets& offs, WinPick* pk) {
+  const int knob = g_bwd_fused.load();
+  if (!knob || L < kWinLmin || L > kWinLmax || (C != 4 && C != 8 && C != 16 && C != 32)) return false;
+  const int tgs = C == 4 ? 0 : C == 8 ? 1 : C == 16 ? 2 : 3;
+  const int nt = g_bwd_fused_nt.load() ? 256 : kDvMidThreads;
+  const int TR = nt >> tgs;
+  if (N % TR != 0 || N < 2 * (int64_t)TR) return false;
+  if (!aligned_to(dZ, 16) || !aligned_to(W, 16) || !aligned_to(V, 16) || !aligned_to(dW, 16) || !aligned_to(dV, 16)) return false;
+  if ((B * N * (int64_t)L) % 4 != 0 || (v_bstride != 0 && v_bstride != N * C)) return false;
+  int KN = 2;
+  for (int t = TR; t > 1; t >>= 1) ++KN;
+  if (KN > L) KN = L;
+  for (int k = 0; k < KN; ++k)
+    if (offs.v[k] != chord_off(k)) return false;
+  pk->tgs = tgs, pk->rows = 1, pk->nt = nt, pk->TR = TR, pk->KN = KN;
+  pk->tiles_full = (int)(N / TR), pk->ragged = false, pk->all_edge = false;
+  return true;
+}
 
 // A ragged last tile per sequence (N % TR != 0) runs on the EDGE instance. In a second launch of its own it costs a
 // kernel boundary, ~2.7 us whatever the shape (r02d: IMDb N = 4097, C = 32: 15.3 us split vs 12.7 in one predicated
@@ -449,6 +485,20 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
       // dW before dV: dV's output is the next (earlier) step's dZ, read first thing by that step's kernels; writing
       // it last leaves it cache-hot (dV 27.4 -> 26.9 us, dW 20.5 -> 20.4 us in the Order training step)
       const int dwv = g_dw_variant.load();
+      if (dW && dV && pick_fused_step(dZ, W, V, dW, dV, B, N, L, C, v_batch_stride, offs, &pk)) {
+        BwdWinArgs a{dZ, W, dV, Geom{}, offs, w_total, false, s};
+        a.V2 = V;
+        a.out2 = dW;
+        if (wfar != nullptr && far_k0 >= 0 && far_k0 <= pk.KN && pk.KN < L) {
+          a.wfar = wfar;
+          a.far_k0 = far_k0;
+        }
+        if (int rc = make_geom(B, N, L, C, 4, pk.tgs, pk.TR, false, v_batch_stride, 0, pk.tiles_full, &a.gm)) return rc;
+        hipError_t e = launch_fused_step(pk.tgs, L, a, pk.nt);
+        if (e != hipSuccess) return fail_hip(e, "chord_bwd_fused");
+        dW = nullptr;
+        dV = nullptr;
+      }
       if (dW && dwv != 1 &&
           pick_dw_chunk(dW, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(V, 16), &pk)) {
         BwdWinArgs a{dZ, V, dW, Geom{}, offs, w_total, false, s};
@@ -673,8 +723,12 @@ int32_t psf_chord_bwd_far_first_link(int64_t B, int64_t N, int32_t L, int64_t C)
   Offsets offs;
   make_offsets(N, L, nullptr, &offs);
   WinPick pk;
-  if (!pick_dv(nullptr, B, N, L, C, offs, true, &pk)) return L;
-  return pk.KN < L ? pk.KN : L;
+  // a step that wants both gradients may run the fused kernel, whose tile (and first far link) can be shorter than the
+  // dV kernel's: the copy must cover the far links of either
+  int k0 = L;
+  if (pick_fused_step(nullptr, nullptr, nullptr, nullptr, nullptr, B, N, L, C, N * C, offs, &pk) && pk.KN < k0) k0 = pk.KN;
+  if (pick_dv(nullptr, B, N, L, C, offs, true, &pk) && pk.KN < k0) k0 = pk.KN;
+  return k0;
 }
 
 int psf_chord_chain_fwd_far_f32(const float* const* W_steps, const float* V0, float* const* out_steps,

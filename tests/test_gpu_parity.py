@@ -728,3 +728,49 @@ def test_random_shapes_forward_and_backward(gpu, seed):
         dF, dV = oc.spmul_bwd(dZ, W, V)
         assert np.array_equal(gV.cpu().numpy(), dV), tag
         assert rel_inf(gW.cpu().numpy(), dF) <= TOL, tag
+
+
+FUSED_SHAPES = [(3, 16384, 15, 8), (2, 1024, 12, 32), (2, 2048, 12, 16), (5, 512, 9, 4), (2, 256, 8, 8), (1, 1536, 20, 16),
+                (2, 128, 7, 32)]
+
+
+@pytest.mark.parametrize("nt", [0, 1])
+@pytest.mark.parametrize("B,N,L,C", FUSED_SHAPES)
+def test_fused_backward_step_kernel(gpu, B, N, L, C, nt):
+    """chord_bwd_fused_k (csrc/bwd_fused.h): dV and dW of a step from ONE kernel — what backward_host computes with two
+    (spmul/spmul_cuda.cu:114-159) — vs the oracle: dV bit-exact, dW <= 1e-5; 256- and 512-thread tiles, with and without
+    the link-major side copy of W's far columns, a broadcast V (v_batch_stride = 0), and the same numbers as the
+    two-kernel path (bwd_fused = 0). Shapes the fused kernel does not take fall back silently (smallest N here)."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import _lib
+    from sparsefactorization_amd.chord import _launch_bwd
+    W, V, dZ = _mk((B, N, L), 81), _mk((B, N, C), 82), _mk((B, N, C), 83)
+    Wt, Vt, dZt = _t(W, gpu), _t(V, gpu), _t(dZ, gpu)
+    dF, dV = oc.spmul_bwd(dZ, W, V)
+    k0 = _lib.load().psf_chord_bwd_far_first_link(B, N, L, C)
+    far = Wt[:, :, k0:].permute(0, 2, 1).contiguous() if 0 <= k0 < L else None
+    sfa.set_tuning("bwd_fused_nt", nt)
+    try:
+        results = []
+        for fused, use_far in ((1, False), (1, True), (0, False)):
+            if use_far and far is None:
+                continue
+            sfa.set_tuning("bwd_fused", fused)
+            gW = torch.full_like(Wt, float("nan"))
+            gV = torch.full_like(Vt, float("nan"))
+            _launch_bwd(dZt, Wt, Vt, gW, gV, B, N, L, C, N * C, None, far if use_far else None, k0 if use_far else 0)
+            assert np.array_equal(gV.cpu().numpy(), dV), (fused, use_far)
+            assert rel_inf(gW.cpu().numpy(), dF) <= TOL, (fused, use_far)
+            if fused:
+                results.append(gW)
+        assert all(torch.equal(results[0], r) for r in results[1:])  # the side copy changes no bit of dW either
+        # broadcast first operand (the attention-map chain's unbatched start, pathfinder_inference.py:57,75-81)
+        sfa.set_tuning("bwd_fused", 1)
+        dFb, dVb = oc.spmul_bwd(dZ, W, np.broadcast_to(V[:1], V.shape).copy())
+        gW = torch.full_like(Wt, float("nan"))
+        gV = torch.full_like(Vt, float("nan"))
+        _launch_bwd(dZt, Wt, Vt[0].contiguous(), gW, gV, B, N, L, C, 0, None)
+        assert np.array_equal(gV.cpu().numpy(), dVb) and rel_inf(gW.cpu().numpy(), dFb) <= TOL
+    finally:
+        sfa.set_tuning("bwd_fused", 1)
+        sfa.set_tuning("bwd_fused_nt", 1)
