@@ -324,8 +324,9 @@ int psf_mlp_wide_bwd_f32(const void* saved, int64_t saved_bytes, int64_t T, int3
  *   key "fwd_wide"   : rows of >= 64 channels: 0 = one workgroup spans the whole row (default, fastest measured);
  *                      1 = 32-channel chunks on 1024-thread workgroups (256-row tiles); 2 = 32-channel chunks
  *                      on 256-thread workgroups
- *   key "chain_fused": 1 = psf_chord_chain_fwd_f32 runs short sequences (N <= 2048, L <= 20, C % 4 == 0) as ONE
- *                      launch with the sequence resident in LDS (default); 0 = always M per-step launches
+ *   key "chain_fused": 1 = psf_chord_chain_fwd_f32 runs short sequences (N <= 2048, L <= 20, C % 4 == 0, rows of at most
+ *                      64 channels: at most 8 workgroups share a sequence) as ONE launch with the sequence resident in
+ *                      LDS (default); 0 = always M per-step launches; 2 = the single launch wherever it fits
  *   key "fwd_wg_limit": LDS-window forward kernel, workgroups per CU: 0 = auto (3 for rows of <= 8 channels on
  *                      launches of >= 4096 tiles, else unlimited), 1 = unlimited, 2..4 = that many
  *   key "chain_zigzag": per-step launches of psf_chord_chain_fwd_*: 1 = every XCD walks its tile range forwards on

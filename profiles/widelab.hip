@@ -4,6 +4,7 @@
 //   profiles/bin/widelab [T] [E] [J] [reps]
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -108,7 +109,7 @@ int main(int argc, char** argv) {
     g.tiles_m = (int)(J_pad / 256), g.tiles_n = (int)(T_pad / 256), g.splits = 1, g.chunks = (int)(E / 16);
     g.n_fast = 0, g.epilogue = kEpiRowMajor, g.out = dOut, g.bias = nullptr, g.ld = T_pad, g.rows_alloc = J_pad;
     g.rows_valid = J, g.cols_valid = T;
-    const unsigned grid = (unsigned)(g.tiles_m * g.tiles_n);
+    const unsigned grid = std::min(256u, (unsigned)(g.tiles_m * g.tiles_n));
     timeit([&] { hipLaunchKernelGGL(x3_gemm_k<false>, dim3(grid), dim3(512), 0, s, g); CK(hipGetLastError()); }, "NT fwd  (J x T, K = E)",
            2.0 * J * T * E);
     std::vector<float> hOut((size_t)J_pad * T_pad);
@@ -157,7 +158,7 @@ int main(int argc, char** argv) {
     g.tiles_m = (int)(T_pad / 256), g.tiles_n = (int)(E_pad / 256), g.splits = 1, g.chunks = (int)(J / 16);
     g.n_fast = 1, g.epilogue = kEpiRowMajor, g.out = dOut, g.ld = E, g.rows_alloc = T;
     g.rows_valid = T, g.cols_valid = E;
-    const unsigned grid = (unsigned)(g.tiles_m * g.tiles_n);
+    const unsigned grid = std::min(256u, (unsigned)(g.tiles_m * g.tiles_n));
     timeit([&] { hipLaunchKernelGGL(x3_gemm_k<false>, dim3(grid), dim3(512), 0, s, g); CK(hipGetLastError()); }, "NT dX   (T x E, K = J)",
            2.0 * J * T * E);
     std::vector<float> hOut((size_t)T * E);
@@ -175,7 +176,7 @@ int main(int argc, char** argv) {
     CK(hipFree(dOut));
   }
   // ---------------- TN dA: dA[j][e] = sum_tok G[tok][j] X[tok][e]
-  for (int splits : {8, 20, 40}) {
+  for (int splits : {8, 21, 42}) {
     float* dOut;
     CK(hipMalloc(&dOut, (size_t)splits * J_pad * E_pad * 4));
     GemmArgs g{};
@@ -183,7 +184,7 @@ int main(int argc, char** argv) {
     g.tiles_m = (int)(J_pad / 256), g.tiles_n = (int)(E_pad / 256), g.splits = splits, g.chunks = (int)(T_pad / 16);
     g.n_fast = 0, g.epilogue = kEpiRowMajor, g.out = dOut, g.ld = E_pad, g.rows_alloc = J_pad;
     g.rows_valid = J_pad, g.cols_valid = E_pad;
-    const unsigned grid = (unsigned)(g.tiles_m * g.tiles_n * splits);
+    const unsigned grid = std::min(256u, (unsigned)(g.tiles_m * g.tiles_n * splits));
     char name[64];
     snprintf(name, sizeof name, "TN dA   (J x E, K = T) /%d", splits);
     timeit([&] { hipLaunchKernelGGL(x3_gemm_k<true>, dim3(grid), dim3(512), 0, s, g); CK(hipGetLastError()); }, name, 2.0 * J * T * E);

@@ -723,7 +723,9 @@ int64_t bwd_ws_bytes(const WidePlan& p) {
 }
 
 hipError_t launch_gemm(bool tn, const GemmArgs& ga, hipStream_t s) {
-  const unsigned grid = (unsigned)(ga.tiles_m * ga.tiles_n * ga.splits);
+  if (ga.splits < 1 || ga.chunks < ga.splits) return hipErrorInvalidValue;  // every (tile, split) item needs a K range
+  const int64_t items = (int64_t)ga.tiles_m * ga.tiles_n * ga.splits;
+  const unsigned grid = (unsigned)(items < 256 ? items : 256);  // persistent: one workgroup per CU of the MI355X
   if (tn) hipLaunchKernelGGL(x3_gemm_k<true>, dim3(grid), dim3(kGemmThreads), 0, s, ga);
   else hipLaunchKernelGGL(x3_gemm_k<false>, dim3(grid), dim3(kGemmThreads), 0, s, ga);
   return hipGetLastError();

@@ -89,7 +89,7 @@ Knob g_knobs[] = {
     {"dw_tgs", &g_dw_tgs, 0, 5},
     {"fwd_wg_limit", &g_fwd_wg_limit, 0, 4},
     {"chain_zigzag", &g_chain_zigzag, 0, 1},
-    {"chain_fused", &g_chain_fused, 0, 1},
+    {"chain_fused", &g_chain_fused, 0, 2},
     {"chain_cc", &g_chain_cc, 0, 1},
     {"mlp_variant", &psf_g_mlp_variant, 0, 3},
     {"mlp_bwd_variant", &psf_g_mlp_bwd_variant, 0, 3},
@@ -581,7 +581,13 @@ int chain_impl(const T* const* W_steps, const T* V0, T* const* out_steps, int32_
     // Short sequences: the whole chain in ONE launch with the sequence's X slice resident in LDS.
     ChainLdsPlan plan;
     // (the single-launch LDS chain reads W rows straight into registers: it cannot emit the far-column side copy)
-    bool ok = g_chain_fused.load() && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, g_chain_cc.load()) &&
+    // Every workgroup of a sequence streams the sequence's whole W: with `chunks` workgroups per sequence W crosses
+    // L2 -> CU `chunks` times and every output row is stored in `chunks` pieces. Past ~8 the per-step kernels win
+    // (profiles/r03n_chain_train_sweep.log, us per chain one launch / per step: ListOps N = 2000, C = 128, 32 chunks:
+    // 361 / 223; N = 2048, C = 64, 16 chunks: 184 / 119; Pathfinder C = 32, 4 chunks: 72 / 78). chain_fused = 2 forces it.
+    const int cf = g_chain_fused.load();
+    bool ok = cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, g_chain_cc.load()) &&
+              (cf == 2 || plan.chunks <= 8) &&
               aligned_to(V0, 16) && B * (int64_t)plan.chunks <= 0x7fffffff;
     for (int m = 0; ok && m < M; ++m) ok = aligned_to(W_steps[m], 4) && aligned_to(out_steps[m], 16);
     if (ok) {

@@ -20,6 +20,7 @@
 // chunk being multiplied; per chunk ONE counted s_waitcnt vmcnt + ONE s_barrier:
 //     wait (own DMA of chunk i) -> barrier (everyone's DMA of chunk i landed, everyone done reading chunk i-1)
 //     -> issue DMA of chunk i+2 into the stage chunk i-1 used -> 18 fragment reads + 48 MFMAs on chunk i.
+// Workgroups are persistent (one per CU, items dealt round-robin) and the ring runs across item boundaries.
 // The six product terms of a fragment pair reuse the same six fragment registers, so LDS traffic per MFMA is half of a
 // plain bf16 GEMM's at the same tile.
 #pragma once
@@ -85,7 +86,10 @@ __global__ void __launch_bounds__(kGemmThreads, 1) x3_gemm_k(const GemmArgs g) {
   const int wm = wv >> 2, wn = wv & 3;  // wave grid 2 (m) x 4 (n)
   const int c = lane & 31, half = lane >> 5;
 
-  // ---- which tile: XCD-aware bijective remap (consecutive logical ids run on one XCD and share operand tiles in its L2)
+  // ---- work items = (tile, K split). Persistent workgroups: item = round * gridDim.x + XCD-aware bijective remap of the
+  // block id (consecutive logical ids run on one XCD at the same time and share operand tiles in its L2). The LDS ring is
+  // fed across item boundaries: the first two chunks of the NEXT item are in flight while this item's last chunks are
+  // multiplied and its tile is stored, so only a workgroup's first item pays the load latency of an empty pipeline.
   uint32_t lb;
   {
     const uint32_t nb = gridDim.x, bid = blockIdx.x;
@@ -93,56 +97,73 @@ __global__ void __launch_bounds__(kGemmThreads, 1) x3_gemm_k(const GemmArgs g) {
     lb = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + idx;
   }
   const uint32_t per_split = (uint32_t)(g.tiles_m * g.tiles_n);
-  const int sp = (int)(lb / per_split);
-  const uint32_t rem = lb - (uint32_t)sp * per_split;
-  int tm, tn;
-  if (g.n_fast) {
-    tm = (int)(rem / (uint32_t)g.tiles_n);
-    tn = (int)(rem - (uint32_t)tm * (uint32_t)g.tiles_n);
-  } else {
-    tn = (int)(rem / (uint32_t)g.tiles_m);
-    tm = (int)(rem - (uint32_t)tn * (uint32_t)g.tiles_m);
-  }
-  const int64_t m0 = (int64_t)tm * kTile, n0 = (int64_t)tn * kTile;
-  const int per = (g.chunks + g.splits - 1) / g.splits;
-  const int k_begin = sp * per;
-  const int k_end = k_begin + per < g.chunks ? k_begin + per : g.chunks;
-  const int nk = k_end > k_begin ? k_end - k_begin : 0;
+  const uint32_t items = per_split * (uint32_t)g.splits;
+  const int per = (g.chunks + g.splits - 1) / g.splits;  // host guarantees every split a non-empty K range
+  struct Item {
+    int64_t m0, n0;
+    int sp, k_begin, nk;
+  };
+  auto decode = [&](uint32_t item) {
+    Item it;
+    it.sp = (int)(item / per_split);
+    const uint32_t rem = item - (uint32_t)it.sp * per_split;
+    int tm, tn;
+    if (g.n_fast) {
+      tm = (int)(rem / (uint32_t)g.tiles_n);
+      tn = (int)(rem - (uint32_t)tm * (uint32_t)g.tiles_n);
+    } else {
+      tn = (int)(rem / (uint32_t)g.tiles_m);
+      tm = (int)(rem - (uint32_t)tn * (uint32_t)g.tiles_m);
+    }
+    it.m0 = (int64_t)tm * kTile, it.n0 = (int64_t)tn * kTile;
+    it.k_begin = it.sp * per;
+    const int k_end = it.k_begin + per < g.chunks ? it.k_begin + per : g.chunks;
+    it.nk = k_end - it.k_begin;
+    return it;
+  };
 
-  // ---- loader: per-lane offsets (constant over the chunks) and per-chunk scalar bases
+  // ---- loader: per-lane offsets (constant over an item's chunks) and per-chunk scalar bases of the ISSUE cursor
   uint32_t voff_a, voff_b;
   int64_t step_a, step_b;  // bytes from one chunk's base to the next
   const unsigned char* base_a[3];
   const unsigned char* base_b[3];
-  if constexpr (!TN) {
-    voff_a = voff_b = (uint32_t)tid * 16u;
-    step_a = g.A.rows_pad * 32;
-    step_b = g.B.rows_pad * 32;
+  uint32_t item_i = lb;  // the item whose chunks are being requested, and how many of them are left
+  int left_i = 0;
+  auto aim = [&](const Item& it) {  // point the issue cursor at the first chunk of an item
+    if constexpr (!TN) {
+      voff_a = voff_b = (uint32_t)tid * 16u;
+      step_a = g.A.rows_pad * 32;
+      step_b = g.B.rows_pad * 32;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      base_a[t] = g.A.p[t] + ((int64_t)k_begin * g.A.rows_pad + m0) * 32;
-      base_b[t] = g.B.p[t] + ((int64_t)k_begin * g.B.rows_pad + n0) * 32;
-    }
-  } else {
-    // LDS image of an operand plane: [16 column blocks][16 k rows][32 B]; the 128-byte groups of four k rows are swapped
-    // pairwise in odd blocks (source-side swizzle) so that the two blocks a transposed read touches in one LDS cycle
-    // fall on different banks.
-    const int b = tid >> 5, q = tid & 31, r_lin = q >> 1, h16 = q & 1;
-    const int r = ((((r_lin >> 2) ^ (b & 1)) << 2) | (r_lin & 3));
-    const int64_t blk_a = m0 / 16 + b < g.A.blocks ? m0 / 16 + b : g.A.blocks - 1;  // clamped: tiles past the array
-    const int64_t blk_b = n0 / 16 + b < g.B.blocks ? n0 / 16 + b : g.B.blocks - 1;  // re-read its last block
-    voff_a = (uint32_t)((blk_a * g.A.rows_pad + r) * 32 + h16 * 16);
-    voff_b = (uint32_t)((blk_b * g.B.rows_pad + r) * 32 + h16 * 16);
-    step_a = step_b = 16 * 32;
+      for (int t = 0; t < 3; ++t) {
+        base_a[t] = g.A.p[t] + ((int64_t)it.k_begin * g.A.rows_pad + it.m0) * 32;
+        base_b[t] = g.B.p[t] + ((int64_t)it.k_begin * g.B.rows_pad + it.n0) * 32;
+      }
+    } else {
+      // LDS image of an operand plane: [16 column blocks][16 k rows][32 B]; the 128-byte groups of four k rows are swapped
+      // pairwise in odd blocks (source-side swizzle) so that the two blocks a transposed read touches in one LDS cycle
+      // fall on different banks.
+      const int b = tid >> 5, q = tid & 31, r_lin = q >> 1, h16 = q & 1;
+      const int r = ((((r_lin >> 2) ^ (b & 1)) << 2) | (r_lin & 3));
+      const int64_t blk_a = it.m0 / 16 + b < g.A.blocks ? it.m0 / 16 + b : g.A.blocks - 1;  // clamped: tiles past the array
+      const int64_t blk_b = it.n0 / 16 + b < g.B.blocks ? it.n0 / 16 + b : g.B.blocks - 1;  // re-read its last block
+      voff_a = (uint32_t)((blk_a * g.A.rows_pad + r) * 32 + h16 * 16);
+      voff_b = (uint32_t)((blk_b * g.B.rows_pad + r) * 32 + h16 * 16);
+      step_a = step_b = 16 * 32;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      base_a[t] = g.A.p[t] + (int64_t)k_begin * 512;
-      base_b[t] = g.B.p[t] + (int64_t)k_begin * 512;
+      for (int t = 0; t < 3; ++t) {
+        base_a[t] = g.A.p[t] + (int64_t)it.k_begin * 512;
+        base_b[t] = g.B.p[t] + (int64_t)it.k_begin * 512;
+      }
     }
-  }
+    left_i = it.nk;
+  };
+  if (item_i < items) aim(decode(item_i));
   const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds);
   const uint32_t lds_wave = lds0 + (uint32_t)wv * 1024u;
-  auto issue = [&](int stage) {  // the next chunk (bases advance) into LDS stage `stage`
+  int in_flight = 0;  // chunks requested and not yet multiplied (0..2)
+  auto issue = [&](int stage) {  // the issue cursor's chunk into LDS stage `stage`; the cursor moves on (block-uniform)
+    if (left_i == 0) return;
     const uint32_t at = lds_wave + (uint32_t)stage * kStageBytes;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -150,6 +171,11 @@ __global__ void __launch_bounds__(kGemmThreads, 1) x3_gemm_k(const GemmArgs g) {
       glds16(at + (3 + t) * kPlaneStage, voff_b, base_b[t]);
       base_a[t] += step_a;
       base_b[t] += step_b;
+    }
+    ++in_flight;
+    if (--left_i == 0) {
+      item_i += gridDim.x;
+      if (item_i < items) aim(decode(item_i));
     }
   };
 
@@ -176,6 +202,13 @@ __global__ void __launch_bounds__(kGemmThreads, 1) x3_gemm_k(const GemmArgs g) {
     }
   };
 
+  issue(0);
+  issue(1);
+  int st = 0;
+  for (uint32_t item_c = lb; item_c < items; item_c += gridDim.x) {
+  const Item cur = decode(item_c);
+  const int64_t m0 = cur.m0, n0 = cur.n0;
+  const int sp = cur.sp;
   f32x16 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -184,16 +217,15 @@ __global__ void __launch_bounds__(kGemmThreads, 1) x3_gemm_k(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (nk > 0) issue(0);
-  if (nk > 1) issue(1);
-  int st = 0;
-  for (int i = 0; i < nk; ++i) {
-    // this wave's DMA of chunk i has landed (chunk i+1, six loads, may stay in flight)
-    if (i + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  for (int i = 0; i < cur.nk; ++i) {
+    // this wave's DMA of the chunk to multiply has landed; the chunk requested after it (six loads) may stay in flight.
+    // (After an item boundary the previous tile's stores are younger than both: the counted wait then covers them too.)
+    if (in_flight > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (i + 2 < nk) issue(st == 0 ? 2 : st - 1);  // stage (i + 2) % 3 = the one chunk i - 1 used
+    --in_flight;
+    issue(st == 0 ? 2 : st - 1);  // into the stage the previous chunk used
     const unsigned char* sA = lds + st * kStageBytes;
     const unsigned char* sB = sA + 3 * kPlaneStage;
     Frag3 bf[2];
@@ -244,6 +276,7 @@ __global__ void __launch_bounds__(kGemmThreads, 1) x3_gemm_k(const GemmArgs g) {
         }
       }
   }
+  }  // items
 }
 
 // f32 [rows][cols] (row stride ld floats) -> three col16 planes; rows in [rows, rows_pad) are written as zeros.

@@ -465,7 +465,7 @@ def test_fused_lds_chain_matches_oracle_and_per_step(gpu, B, N, M, L, C, residua
     want = oc.chain(np.stack([rows, cols]), W, V0, residual)  # [M, B, N, C]
     Ws = [_t(W[m], gpu) for m in range(M)]
     got = {}
-    for fused in (1, 0):
+    for fused in (2, 0):  # 2: the single launch wherever it fits (the default, 1, leaves rows of > 64 channels to the steps)
         sfa.set_tuning("chain_fused", fused)
         try:
             with torch.no_grad():
@@ -478,7 +478,7 @@ def test_fused_lds_chain_matches_oracle_and_per_step(gpu, B, N, M, L, C, residua
             assert np.array_equal(out.detach().cpu().numpy(), want[-1])
         finally:
             sfa.set_tuning("chain_fused", 1)
-    assert np.array_equal(got[1], want[-1])
+    assert np.array_equal(got[2], want[-1])
     assert np.array_equal(got[0], want[-1])
 
 
@@ -489,7 +489,11 @@ def test_fused_lds_chain_custom_offsets_and_broadcast(gpu):
     off = [0, 5, 255, 300, -1, 128]
     eye = np.eye(N, dtype=np.float32)
     Ws = [_t(W[m], gpu) for m in range(M)]
-    got = sfa.chord_chain(Ws, _t(eye, gpu), False, offsets=off).cpu().numpy()
+    sfa.set_tuning("chain_fused", 2)  # 64 workgroups per sequence: beyond the default's limit
+    try:
+        got = sfa.chord_chain(Ws, _t(eye, gpu), False, offsets=off).cpu().numpy()
+    finally:
+        sfa.set_tuning("chain_fused", 1)
     X = np.broadcast_to(eye, (B, N, N)).copy()
     for m in range(M):
         X = oc.spmul_fwd(W[m], X, off)
