@@ -665,6 +665,8 @@ struct WidePlan {
   int64_t w1p_plane, w1tp_plane, gp_plane;
   int64_t pack2_bytes, packbt_bytes;
   int32_t splits, groups, rec_total, n_slots[3];
+  int32_t tiles_e;   // column tiles of the two GEMMs whose columns are e (dX, dAcat)
+  bool narrow_e;     // ... on the 256 x 64 configuration (E <= 128) instead of 256 x 256
   uint32_t rec_off[kMaxWideUnits];
 };
 
@@ -703,7 +705,9 @@ bool make_wide_plan(int64_t T, int32_t E, int32_t K, const int32_t* h, const int
   p->groups = (int32_t)(g.T_pad / 256);
   // split-K of the weight-gradient GEMM: ONE round of workgroups (one per CU, never 256 + a few: the few would run a
   // second round alone), at least 32 k-chunks (512 tokens) each
-  const int tiles = (g.J_pad / 256) * (g.E_pad / 256);
+  p->narrow_e = E <= 128;
+  p->tiles_e = p->narrow_e ? (E + kTileNarrow - 1) / kTileNarrow : g.E_pad / 256;
+  const int tiles = (g.J_pad / 256) * p->tiles_e;
   const int64_t chunks = g.T_pad / 16;
   int s = 256 / tiles;
   if (s > chunks / 32) s = (int)(chunks / 32);
@@ -722,12 +726,14 @@ int64_t bwd_ws_bytes(const WidePlan& p) {
          (int64_t)p.splits * p.g.J_pad * p.g.E_pad * 4;
 }
 
-hipError_t launch_gemm(bool tn, const GemmArgs& ga, hipStream_t s) {
+hipError_t launch_gemm(bool tn, bool narrow, const GemmArgs& ga, hipStream_t s) {
   if (ga.splits < 1 || ga.chunks < ga.splits) return hipErrorInvalidValue;  // every (tile, split) item needs a K range
   const int64_t items = (int64_t)ga.tiles_m * ga.tiles_n * ga.splits;
-  const unsigned grid = (unsigned)(items < 256 ? items : 256);  // persistent: one workgroup per CU of the MI355X
-  if (tn) hipLaunchKernelGGL(x3_gemm_k<true>, dim3(grid), dim3(kGemmThreads), 0, s, ga);
-  else hipLaunchKernelGGL(x3_gemm_k<false>, dim3(grid), dim3(kGemmThreads), 0, s, ga);
+  const dim3 grid((unsigned)(items < 256 ? items : 256));  // persistent: one workgroup per CU of the MI355X
+  if (tn && narrow) hipLaunchKernelGGL((x3_gemm_k<true, GemmNarrow>), grid, dim3(kGemmThreads), 0, s, ga);
+  else if (tn) hipLaunchKernelGGL((x3_gemm_k<true, GemmSquare>), grid, dim3(kGemmThreads), 0, s, ga);
+  else if (narrow) hipLaunchKernelGGL((x3_gemm_k<false, GemmNarrow>), grid, dim3(kGemmThreads), 0, s, ga);
+  else hipLaunchKernelGGL((x3_gemm_k<false, GemmSquare>), grid, dim3(kGemmThreads), 0, s, ga);
   return hipGetLastError();
 }
 
@@ -793,7 +799,7 @@ int psf_mlp_wide_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const 
   ga.tiles_m = p.g.J_pad / 256, ga.tiles_n = (int32_t)(p.g.T_pad / 256), ga.splits = 1, ga.chunks = E / 16;
   ga.n_fast = 0, ga.epilogue = kEpiFragBias, ga.out = HF, ga.bias = fa.acat;
   ga.rows_valid = p.g.J_pad, ga.cols_valid = p.g.T_pad;
-  hipError_t e = launch_gemm(false, ga, s);
+  hipError_t e = launch_gemm(false, false, ga, s);
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
   hipLaunchKernelGGL(wide_out_k, dim3((unsigned)((T + 127) / 128)), dim3(256), 0, s, fa);
   e = hipGetLastError();
@@ -851,10 +857,10 @@ int psf_mlp_wide_bwd_f32(const void* saved, int64_t saved_bytes_given, int64_t T
     for (int t = 0; t < 3; ++t) ga.A.p[t] = ba.gp[t], ga.B.p[t] = ba.w1tp[t];
     ga.A.rows_pad = p.g.T_pad, ga.A.blocks = p.g.J / 16;
     ga.B.rows_pad = p.g.E_pad, ga.B.blocks = p.g.J / 16;
-    ga.tiles_m = (int32_t)(p.g.T_pad / 256), ga.tiles_n = p.g.E_pad / 256, ga.splits = 1, ga.chunks = p.g.J / 16;
+    ga.tiles_m = (int32_t)(p.g.T_pad / 256), ga.tiles_n = p.tiles_e, ga.splits = 1, ga.chunks = p.g.J / 16;
     ga.n_fast = 1, ga.epilogue = kEpiRowMajor, ga.out = dX, ga.ld = E, ga.rows_alloc = T;
     ga.rows_valid = T, ga.cols_valid = E;
-    e = launch_gemm(false, ga, s);
+    e = launch_gemm(false, p.narrow_e, ga, s);
     if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
   }
   {  // dAcat[j][e] = sum_tok G[tok][j] X[tok][e]
@@ -862,10 +868,10 @@ int psf_mlp_wide_bwd_f32(const void* saved, int64_t saved_bytes_given, int64_t T
     for (int t = 0; t < 3; ++t) ga.A.p[t] = ba.gp[t], ga.B.p[t] = sv + t * p.xp_plane;
     ga.A.rows_pad = p.g.T_pad, ga.A.blocks = p.g.J / 16;
     ga.B.rows_pad = p.g.T_pad, ga.B.blocks = E / 16;
-    ga.tiles_m = p.g.J_pad / 256, ga.tiles_n = p.g.E_pad / 256, ga.splits = p.splits, ga.chunks = (int32_t)(p.g.T_pad / 16);
+    ga.tiles_m = p.g.J_pad / 256, ga.tiles_n = p.tiles_e, ga.splits = p.splits, ga.chunks = (int32_t)(p.g.T_pad / 16);
     ga.n_fast = 0, ga.epilogue = kEpiRowMajor, ga.out = dapart, ga.ld = p.g.E_pad, ga.rows_alloc = p.g.J_pad;
     ga.rows_valid = p.g.J_pad, ga.cols_valid = p.g.E_pad;
-    e = launch_gemm(true, ga, s);
+    e = launch_gemm(true, p.narrow_e, ga, s);
     if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
   }
   hipLaunchKernelGGL(wide_reduce_small_k, dim3((kOtMax * 1024 + 32 + kOtMax * 32 + 255) / 256, (unsigned)(p.g.J / 32)), dim3(256), 0, s, ba);

@@ -15,7 +15,8 @@
 // so X and G are split once and never transposed in memory.
 //
 // Kernel: 256 x 256 output tile per 512-thread workgroup (8 waves as 2 x 4; a wave owns 128 x 64 = 4 x 2 accumulator
-// tiles of v_mfma_f32_32x32x16_bf16: 128 registers), one workgroup per CU. A k16 chunk of both operands is 6 planes x
+// tiles of v_mfma_f32_32x32x16_bf16: 128 registers; a 256 x 64 configuration serves narrow column dimensions), one
+// workgroup per CU. A k16 chunk of both operands is 6 planes x
 // 8 KB = 48 KB; three LDS stages, filled by LDS-DMA (global_load_lds_dwordx4, no registers) two chunks ahead of the
 // chunk being multiplied; per chunk ONE counted s_waitcnt vmcnt + ONE s_barrier:
 //     wait (own DMA of chunk i) -> barrier (everyone's DMA of chunk i landed, everyone done reading chunk i-1)
@@ -35,11 +36,25 @@ namespace psf_wide {
 
 using namespace psf_x3;
 
-constexpr int kTile = 256;                     // output tile edge (rows and columns)
-constexpr int kPlaneStage = kTile * 32;        // one plane of one operand of one k16 chunk: 8 KB
-constexpr int kStageBytes = 6 * kPlaneStage;   // 48 KB
+constexpr int kTile = 256;                     // output tile rows (and columns of the square configuration)
+constexpr int kTileNarrow = 64;                // output tile columns of the narrow configuration
 constexpr int kStages = 3;
 constexpr int kGemmThreads = 512;
+
+// Wave decomposition of a 512-thread workgroup: WM x WN waves, each MT x NTL accumulator tiles of 32 x 32.
+//   square  2 x 4 waves of 4 x 2 tiles: 256 x 256 (128 accumulator registers per lane)
+//   narrow  8 x 1 waves of 1 x 2 tiles: 256 x  64 — for a column dimension of <= 128 (E = 64: the square tile would
+//           spend three quarters of its MFMAs and B-operand loads on padding)
+template <int WM_, int WN_, int MT_, int NTL_>
+struct GemmShape {
+  static constexpr int WM = WM_, WN = WN_, MT = MT_, NTL = NTL_;
+  static constexpr int BM = WM * MT * 32, BN = WN * NTL * 32;
+  static constexpr int plane_a = BM * 32, plane_b = BN * 32;  // bytes of one plane of one k16 chunk
+  static constexpr int stage_bytes = 3 * (plane_a + plane_b);
+  static_assert(WM * WN * 64 == kGemmThreads && BM == kTile && plane_b % 1024 == 0, "workgroup shape");
+};
+using GemmSquare = GemmShape<2, 4, 4, 2>;
+using GemmNarrow = GemmShape<8, 1, 1, 2>;
 
 struct Operand {
   const unsigned char* p[3];  // the three term planes
@@ -78,13 +93,16 @@ __device__ __forceinline__ void glds16(uint32_t lds_at, uint32_t voff, const uns
       : "memory");
 }
 
-template <bool TN>
+template <bool TN, class S = GemmSquare>
 __global__ void __launch_bounds__(kGemmThreads, 1) x3_gemm_k(const GemmArgs g) {
+  constexpr int MT = S::MT, NTL = S::NTL, BM = S::BM, BN = S::BN;
+  constexpr int kStageBytes = S::stage_bytes, kPlaneA = S::plane_a, kPlaneB = S::plane_b;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[kStages * kStageBytes];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wv >> 2, wn = wv & 3;  // wave grid 2 (m) x 4 (n)
+  const int wm = wv / S::WN, wn = wv % S::WN;
   const int c = lane & 31, half = lane >> 5;
+  const bool loads_b = wv * 1024 < kPlaneB;  // wave-uniform: the B plane of a chunk is kPlaneB / 1024 wave-loads
 
   // ---- work items = (tile, K split). Persistent workgroups: item = round * gridDim.x + XCD-aware bijective remap of the
   // block id (consecutive logical ids run on one XCD at the same time and share operand tiles in its L2). The LDS ring is
@@ -115,7 +133,7 @@ __global__ void __launch_bounds__(kGemmThreads, 1) x3_gemm_k(const GemmArgs g) {
       tn = (int)(rem / (uint32_t)g.tiles_m);
       tm = (int)(rem - (uint32_t)tn * (uint32_t)g.tiles_m);
     }
-    it.m0 = (int64_t)tm * kTile, it.n0 = (int64_t)tn * kTile;
+    it.m0 = (int64_t)tm * BM, it.n0 = (int64_t)tn * BN;
     it.k_begin = it.sp * per;
     const int k_end = it.k_begin + per < g.chunks ? it.k_begin + per : g.chunks;
     it.nk = k_end - it.k_begin;
@@ -167,8 +185,8 @@ __global__ void __launch_bounds__(kGemmThreads, 1) x3_gemm_k(const GemmArgs g) {
     const uint32_t at = lds_wave + (uint32_t)stage * kStageBytes;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      glds16(at + t * kPlaneStage, voff_a, base_a[t]);
-      glds16(at + (3 + t) * kPlaneStage, voff_b, base_b[t]);
+      glds16(at + t * kPlaneA, voff_a, base_a[t]);
+      if (loads_b) glds16(at + 3 * kPlaneA + t * kPlaneB, voff_b, base_b[t]);
       base_a[t] += step_a;
       base_b[t] += step_b;
     }
@@ -182,16 +200,16 @@ __global__ void __launch_bounds__(kGemmThreads, 1) x3_gemm_k(const GemmArgs g) {
   // ---- fragment read offsets of this lane
   int fa[2], fb[2];
   if constexpr (!TN) {
-    fa[0] = (wm * 128 + c) * 32 + half * 16;  // + i * 1024
-    fb[0] = (wn * 64 + c) * 32 + half * 16;   // + j * 1024
+    fa[0] = (wm * MT * 32 + c) * 32 + half * 16;   // + i * 1024
+    fb[0] = (wn * NTL * 32 + c) * 32 + half * 16;  // + j * 1024
     fa[1] = fb[1] = 0;
   } else {
     const int cg = (lane >> 4) & 1, qq = (lane >> 2) & 3, p = lane & 3;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int o = cg * 512 + (((2 * half + t) ^ cg) * 128) + qq * 32 + 8 * p;
-      fa[t] = wm * 4 * 1024 + o;  // + i * 1024
-      fb[t] = wn * 2 * 1024 + o;  // + j * 1024
+      fa[t] = wm * MT * 1024 + o;   // + i * 1024
+      fb[t] = wn * NTL * 1024 + o;  // + j * 1024
     }
   }
   auto frag = [&](const unsigned char* plane, const int (&f)[2], int tile) -> bf16x8 {
@@ -209,44 +227,49 @@ __global__ void __launch_bounds__(kGemmThreads, 1) x3_gemm_k(const GemmArgs g) {
   const Item cur = decode(item_c);
   const int64_t m0 = cur.m0, n0 = cur.n0;
   const int sp = cur.sp;
-  f32x16 acc[4][2];
+  f32x16 acc[MT][NTL];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NTL; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   for (int i = 0; i < cur.nk; ++i) {
     // this wave's DMA of the chunk to multiply has landed; the chunk requested after it (six loads) may stay in flight.
     // (After an item boundary the previous tile's stores are younger than both: the counted wait then covers them too.)
-    if (in_flight > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (in_flight > 1) {
+      if (loads_b) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // a wave that loads no B plane has three loads per chunk
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     --in_flight;
     issue(st == 0 ? 2 : st - 1);  // into the stage the previous chunk used
     const unsigned char* sA = lds + st * kStageBytes;
-    const unsigned char* sB = sA + 3 * kPlaneStage;
-    Frag3 bf[2];
+    const unsigned char* sB = sA + 3 * kPlaneA;
+    Frag3 bf[NTL];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      bf[j] = Frag3{frag(sB, fb, j), frag(sB + kPlaneStage, fb, j), frag(sB + 2 * kPlaneStage, fb, j)};
+    for (int j = 0; j < NTL; ++j)
+      bf[j] = Frag3{frag(sB, fb, j), frag(sB + kPlaneB, fb, j), frag(sB + 2 * kPlaneB, fb, j)};
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii) {
-      const Frag3 af{frag(sA, fa, ii), frag(sA + kPlaneStage, fa, ii), frag(sA + 2 * kPlaneStage, fa, ii)};
+    for (int ii = 0; ii < MT; ++ii) {
+      const Frag3 af{frag(sA, fa, ii), frag(sA + kPlaneA, fa, ii), frag(sA + 2 * kPlaneA, fa, ii)};
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[ii][j] = mfma6(af, bf[j], acc[ii][j]);
+      for (int j = 0; j < NTL; ++j) acc[ii][j] = mfma6(af, bf[j], acc[ii][j]);
     }
     st = st == 2 ? 0 : st + 1;
   }
 
-  // ---- epilogue. Register r of lane (c, half) of tile (i, j) is D[m0 + wm*128 + i*32 + cd_row(r, half)][n0 + wn*64 + j*32 + c].
+  // ---- epilogue. Register r of lane (c, half) of tile (i, j) is
+  //      D[m0 + (wm * MT + i) * 32 + cd_row(r, half)][n0 + (wn * NTL + j) * 32 + c].
   if (g.epilogue == kEpiFragBias) {
-    const int64_t units = (int64_t)g.tiles_m * (kTile / 32);
+    const int64_t units = (int64_t)g.tiles_m * (BM / 32);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t mrow = m0 + wm * 128 + i * 32;
+    for (int i = 0; i < MT; ++i) {
+      const int64_t mrow = m0 + (wm * MT + i) * 32;
       float bv[16];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -254,8 +277,8 @@ __global__ void __launch_bounds__(kGemmThreads, 1) x3_gemm_k(const GemmArgs g) {
         bv[4 * q] = v.x, bv[4 * q + 1] = v.y, bv[4 * q + 2] = v.z, bv[4 * q + 3] = v.w;
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int64_t ncol = n0 + wn * 64 + j * 32;
+      for (int j = 0; j < NTL; ++j) {
+        const int64_t ncol = n0 + (wn * NTL + j) * 32;
         if (ncol >= g.cols_valid) continue;  // wave-uniform
         float* dst = g.out + (((ncol >> 5) * units + (mrow >> 5)) * 16) * 64 + lane;
 #pragma unroll
@@ -265,13 +288,13 @@ __global__ void __launch_bounds__(kGemmThreads, 1) x3_gemm_k(const GemmArgs g) {
   } else {
     float* out = g.out + (int64_t)sp * g.rows_alloc * g.ld;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int64_t ncol = n0 + wn * 64 + j * 32 + c;
+      for (int j = 0; j < NTL; ++j) {
+        const int64_t ncol = n0 + (wn * NTL + j) * 32 + c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int64_t mrow = m0 + wm * 128 + i * 32 + cd_row(r, half);
+          const int64_t mrow = m0 + (wm * MT + i) * 32 + cd_row(r, half);
           if (mrow < g.rows_valid && ncol < g.cols_valid) out[mrow * g.ld + ncol] = acc[i][j][r];
         }
       }
