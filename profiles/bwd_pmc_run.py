@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Workload for the backward-kernel counter passes: `iters` launches of dV alone, then of dW alone, at one shape.
+"""Workload for the backward-kernel counter passes: `iters` launches of dV alone, then of dW alone, then of the step that
+wants both (the fused kernel, csrc/bwd_fused.h, where it applies), at one shape.
 
     python3 profiles/bwd_pmc_run.py B N L C [iters]
 
@@ -28,6 +29,9 @@ def main():
     torch.cuda.synchronize()
     for _ in range(iters):
         chord._launch_bwd(dZ, W, V, dW, None, B, N, L, C, N * C, None)
+    torch.cuda.synchronize()
+    for _ in range(iters):
+        chord._launch_bwd(dZ, W, V, dW, dV, B, N, L, C, N * C, None)
     torch.cuda.synchronize()
     print(f"done B={B} N={N} L={L} C={C} iters={iters} alg_bytes={4 * B * N * (L + 2 * C)}")
 

@@ -29,7 +29,8 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     out = {"tag": tag, "shapes": {}}
     md = [f"# rocprofv3 summary, backward kernels — {tag}", "",
-          "Workload: `python3 profiles/bwd_pmc_run.py B N L C 100` (100 launches of dV alone, 100 of dW alone); one "
+          "Workload: `python3 profiles/bwd_pmc_run.py B N L C 100` (100 launches of dV alone, 100 of dW alone, 100 of the fused "
+          "step where it applies — its algorithmic bytes are 4BN(2L+3C)); one "
           "`--kernel-trace --stats` pass and one pass per `--pmc` group. Traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB.", ""]
     for shape, (B, N, L, C) in SHAPES.items():
         sdir = os.path.join(src, shape)
@@ -56,14 +57,15 @@ def main():
         for name, cs in vals.items():
             kernels[name]["counters_per_launch"] = {c: sum(v) / len(v) for c, v in cs.items()}
         md += [f"## {shape}: B={B} N={N} L={L} C={C}; algorithmic bytes per kernel 4BN(L+2C) = {alg / 1e6:.2f} MB", "",
-               "| kernel | calls | avg us | alg TB/s | of 8 TB/s | traffic MB (rd+wr) | traffic/alg | L2 hit | VMEM rd/wave | wait-inst/wave-cycles |",
-               "|---|---|---|---|---|---|---|---|---|---|"]
+               "| kernel | calls | avg us | alg TB/s | of 8 TB/s | traffic MB (rd+wr) | traffic/alg | L2 hit | VMEM rd/wave | wait-inst/wave-cycles | L2 requests / row |",
+               "|---|---|---|---|---|---|---|---|---|---|---|"]
         for name, k in sorted(kernels.items()):
             c = k.get("counters_per_launch", {})
             row = [f"`{name}`", str(k.get("calls", "")), f"{k.get('avg_us', float('nan')):.2f}"]
-            full = k.get("calls", 0) >= 50 and "false>" in name  # the main (full-tile) launch of the shape
+            fused = "fused" in name
+            full = k.get("calls", 0) >= 50 and ("false>" in name or fused)  # the main (full-tile) launch of the shape
             if "avg_us" in k and full:
-                tbs = alg / k["avg_us"] / 1e6
+                tbs = (4 * B * N * (2 * L + 3 * C) if fused else alg) / k["avg_us"] / 1e6  # the fused step: 4BN(2L+3C)
                 k["alg_tbs"], k["frac"] = tbs, tbs / 8.0
                 row += [f"{tbs:.2f}", f"{tbs / 8.0:.3f}"]
             else:
@@ -83,6 +85,9 @@ def main():
             row.append(f"{c['SQ_INSTS_VMEM_RD'] / c['SQ_WAVES']:.1f}" if "SQ_INSTS_VMEM_RD" in c and c.get("SQ_WAVES") else
                        (f"{c['SQ_INSTS_VMEM_RD']:.0f}/launch" if "SQ_INSTS_VMEM_RD" in c else ""))
             row.append(f"{c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']:.2f}" if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_ANY" in c else "")
+            if "TCC_REQ_sum" in c:
+                k["tcc_req_per_row"] = c["TCC_REQ_sum"] / (B * N)
+            row.append(f"{c['TCC_REQ_sum'] / (B * N):.2f}" if "TCC_REQ_sum" in c else "")
             md.append("| " + " | ".join(row) + " |")
         md.append("")
         out["shapes"][shape] = {"B": B, "N": N, "L": L, "C": C, "alg_bytes": alg, "kernels": kernels}

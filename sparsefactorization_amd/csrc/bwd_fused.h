@@ -29,8 +29,9 @@ struct BwdFusedCfg {
   static constexpr int lds_bytes = 2 * B::win_bytes + 2 * B::w_tile_bytes;
 };
 
+// 256 threads: five workgroups per CU (32 KB of LDS each at C = 8) need <= 96 registers; unbounded hipcc takes 100.
 template <int L, int TGS, int NT>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, NT == 256 ? 5 : 2)
 chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, const float* __restrict__ V,
                   float* __restrict__ dW, float* __restrict__ dV, const Geom gm, const Offsets offs, const int64_t w_total,
                   const float* __restrict__ wfar, const int far_k0) {
