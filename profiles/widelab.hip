@@ -142,7 +142,7 @@ int main(int argc, char** argv) {
       double ref = hb[j];
       for (int64_t e = 0; e < E; ++e) ref += (double)hW[j * E + e] * hX[t * E + e];
       const int jr = (int)(j & 31), hf = (jr >> 2) & 1, r = (jr & 3) + 4 * (jr >> 3);
-      const int64_t at = (((t >> 5) * units + (j >> 5)) * 16 + r) * 64 + hf * 32 + (t & 31);
+      const int64_t at = ((((t >> 5) * units + (j >> 5)) * 4 + (r >> 2)) * 64 + hf * 32 + (t & 31)) * 4 + (r & 3);
       e2 = std::max(e2, std::fabs(ref - hOut[at]));
     }
     printf("  fragment epilogue check: max|err| %.3e (rel %.3e)\n", e2, e2 / maxref);

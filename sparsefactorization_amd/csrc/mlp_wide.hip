@@ -21,8 +21,9 @@
 //             dAcat = G^T X          (TN GEMM over the tokens, split-K)     x3_gemm_k<true>  + fixed-order reduction
 //
 // What the forward leaves for the backward ("saved", caller-owned): XP (6 bytes per element of X) and HF (Hpre in the
-// accumulator-fragment order every consumer wants: register r of lane l of the 32 x 32 tile (hidden unit, token tile)
-// at ((tile_t * U + unit) * 16 + r) * 64 + l — 256-byte rows, coalesced for producer and consumers alike).
+// accumulator-fragment order every consumer wants: registers 4 q .. 4 q + 3 of lane l of the 32 x 32 tile (hidden unit,
+// token tile) as one 16-byte vector at (((tile_t * U + unit) * 4 + q) * 64 + l) * 4 floats — every access of producer
+// and consumers is a 1 KB dwordx4 burst).
 // Nothing is recomputed: at these widths recomputing Hpre would be a fourth 100-GFLOP GEMM, keeping it is 4 J bytes
 // per token of HBM traffic. All reductions run in a fixed order (no float atomics): bit-reproducible.
 //
@@ -286,7 +287,9 @@ __global__ void __launch_bounds__(256) wide_out_k(const WideFwdArgs a) {
   if (ttile * 32 >= g.T) return;  // wave-uniform
   const int64_t tok = ttile * 32 + c;
   const bool tok_ok = tok < g.T;
-  for (int k = 0; k < g.K; ++k) {
+  // blockIdx.y deals the MLPs round-robin: with one wave per token tile for ALL MLPs a ListOps batch is 2000 waves, eight
+  // per CU, and every Hpre load is exposed
+  for (int k = blockIdx.y; k < g.K; k += gridDim.y) {
     const WideFwdMlp& d = a.m[k];
     const int ot_n = d.ot, unit0 = d.joff >> 5, nu = (d.h + 31) >> 5;
     f32x16 acc2[kOtMax];
@@ -303,10 +306,13 @@ __global__ void __launch_bounds__(256) wide_out_k(const WideFwdArgs a) {
     }
     for (int u = 0; u < nu; ++u) {
       const int unit = unit0 + u;
-      const float* hf = a.HF + (((ttile * g.U + unit) * 16) << 6) + lane;
+      const float4* hf = reinterpret_cast<const float4*>(a.HF + (((ttile * g.U + unit) * 16) << 6)) + lane;
       float y[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) y[r] = hf[r * 64];
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = hf[q * 64];
+        y[4 * q] = v.x, y[4 * q + 1] = v.y, y[4 * q + 2] = v.z, y[4 * q + 3] = v.w;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) y[r] = gelu_only(y[r]);
       const Split16 ys = split16(y);
@@ -432,9 +438,12 @@ __global__ void __launch_bounds__(512, 1) wide_mid_k(const WideBwdArgs a, const 
     const int nel = two_d ? 16 : (32 * O + 63) >> 6;  // elements per lane (the last may be partial when O < 32)
     float hnext[16], dyt[NDY];
     auto prefetch = [&](int64_t ttile) {
-      const float* hfp = a.HF + (((ttile * g.U + unit) * 16) << 6) + lane;
+      const float4* hfp = reinterpret_cast<const float4*>(a.HF + (((ttile * g.U + unit) * 16) << 6)) + lane;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hnext[r] = hfp[r * 64];
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = hfp[q * 64];
+        hnext[4 * q] = v.x, hnext[4 * q + 1] = v.y, hnext[4 * q + 2] = v.z, hnext[4 * q + 3] = v.w;
+      }
       const float* tile = d.dY + ttile * 32 * O;
       const int64_t rows = g.T - ttile * 32;  // valid rows of this tile (may be <= 0 past the end)
       if (rows >= 32) {  // wave-uniform
@@ -801,7 +810,7 @@ int psf_mlp_wide_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const 
   ga.rows_valid = p.g.J_pad, ga.cols_valid = p.g.T_pad;
   hipError_t e = launch_gemm(false, false, ga, s);
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
-  hipLaunchKernelGGL(wide_out_k, dim3((unsigned)((T + 127) / 128)), dim3(256), 0, s, fa);
+  hipLaunchKernelGGL(wide_out_k, dim3((unsigned)((T + 127) / 128), (unsigned)(K < 12 ? K : 12)), dim3(256), 0, s, fa);
   e = hipGetLastError();
   return e == hipSuccess ? PSF_OK : psf_internal_fail((int)e, hipGetErrorString(e));
 }

@@ -65,7 +65,7 @@ struct Operand {
 
 enum Epilogue : int32_t {
   kEpiRowMajor = 0,  // out[(split * rows_alloc + m) * ld + n] = D[m][n]   for m < rows_valid, n < cols_valid
-  kEpiFragBias = 1   // out in accumulator-fragment order, + bias[m]: block (n >> 5, m >> 5) holds 16 registers x 64 lanes
+  kEpiFragBias = 1   // out in accumulator-fragment order, + bias[m]: block (n >> 5, m >> 5) = [4][64 lanes][4 registers]
 };
 
 struct GemmArgs {
@@ -280,9 +280,12 @@ __global__ void __launch_bounds__(kGemmThreads, 1) x3_gemm_k(const GemmArgs g) {
       for (int j = 0; j < NTL; ++j) {
         const int64_t ncol = n0 + (wn * NTL + j) * 32;
         if (ncol >= g.cols_valid) continue;  // wave-uniform
-        float* dst = g.out + (((ncol >> 5) * units + (mrow >> 5)) * 16) * 64 + lane;
+        // block (token tile, hidden unit) = 4 KB: [q = r >> 2][lane][r & 3] — four 1 KB dwordx4 bursts per tile
+        float4* dst = reinterpret_cast<float4*>(g.out + (((ncol >> 5) * units + (mrow >> 5)) * 16) * 64) + lane;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[r * 64] = acc[i][j][r] + bv[r];
+        for (int q = 0; q < 4; ++q)
+          dst[q * 64] = make_float4(acc[i][j][4 * q] + bv[4 * q], acc[i][j][4 * q + 1] + bv[4 * q + 1],
+                                    acc[i][j][4 * q + 2] + bv[4 * q + 2], acc[i][j][4 * q + 3] + bv[4 * q + 3]);
       }
     }
   } else {
