@@ -281,7 +281,8 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
  *   psf_mlp_wide_fwd_f32  Y[k] as psf_mlp_fwd_f32. It also fills `saved` (caller-owned, 256-byte aligned, at least
  *                         psf_mlp_wide_saved_bytes bytes): X as bf16 term planes and the pre-activations of the hidden
  *                         layers — what the backward needs, so that nothing is recomputed (at these widths recomputing
- *                         is a fourth 100-GFLOP GEMM; keeping is 4 x sum(h) bytes per token). Inference passes scratch.
+ *                         is a fourth 100-GFLOP GEMM; keeping is 4 x sum(h) bytes per token). Inference passes saved =
+ *                         NULL and a workspace of psf_mlp_wide_fwd_workspace + psf_mlp_wide_saved_bytes bytes.
  *   psf_mlp_wide_bwd_f32  the gradients of psf_mlp_bwd_f32 from `saved` and dY[k]; dX may be NULL (not computed).
  *   Layouts as psf_mlp_fwd_f32 / psf_mlp_bwd_f32. Limits: E a multiple of 16, 16 <= E <= 1024; 1 <= h[k] <= 128;
  *   1 <= O[k] <= 128; 1 <= K <= 24; T * E and T * (sum of h[k] rounded up to 32) below 2^30; X and A[k] 16-byte aligned.
@@ -340,6 +341,8 @@ int psf_mlp_wide_bwd_f32(const void* saved, int64_t saved_bytes, int64_t T, int3
  *                      on the bf16 matrix pipe, every operand split once, transposed operands by ds_read_b64_tr_b16;
  *                      1 = all-f32-MFMA kernel; 2 = the first split-bf16 kernel (steps 1, 2, 6 on bf16, the token
  *                      contractions on the f32 instruction)
+ *   key "wide_fuse"  : psf_mlp_wide_fwd_f32: 1 = the second layers of the MLPs with <= 32 outputs run inside the first
+ *                      layers' GEMM epilogue when every MLP has 97..128 hidden rows (default), 0 = always the separate kernel
  *   key "xcd_remap"  : 1 = keep a batch element's tiles on one XCD group (default), 0 = linear
  * psf_get_tuning returns the value (>= 0) or PSF_E_TUNING.
  */

@@ -31,12 +31,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/psf_chord.h"
 #include "mlp_planes.h"
 #include "mlp_x3_common.h"
 #include "x3_gemm.h"
 
 extern "C" int psf_internal_fail(int code, const char* message);
+extern std::atomic<int> psf_g_wide_fuse;  // psf_chord.hip: tuning knob "wide_fuse"
 
 namespace {
 
@@ -44,8 +47,7 @@ using namespace psf_wide;
 
 constexpr int kMaxWideMlps = 24;
 constexpr int kMaxWideUnits = 96;      // 24 MLPs x 4 units of 32 hidden rows
-constexpr int kOtMax = 4;              // output tiles of 32 per MLP (O <= 128)
-constexpr int kPack2Tile = 2048;       // one term of one (unit, output tile): [2 s][2 half][32 o][8] bf16
+constexpr int kOtMax = kOutTilesMax;    // output tiles of 32 per MLP (O <= 128)
 constexpr int kPackBtStep = 1024;      // one term of one (unit, k-step of 16 outputs): [2 half][32 j][8] bf16
 constexpr int kSplitsMax = 64;
 constexpr int kSlotClass = 4 * 96;           // work-item table of wide_mid_k: three classes x (<= 4 sub-items per unit)
@@ -66,17 +68,6 @@ __device__ __forceinline__ void gelu_and_grad(float x, float& y, float& dydx) {
   y = x * Phi;
   dydx = fmaf(x * 0.39894228040143267794f, E, Phi);
 }
-__device__ __forceinline__ float gelu_only(float x) {
-  const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.2316419f, 1.0f));
-  float p = fmaf(0.53070271f, t, -0.72657602f);
-  p = fmaf(p, t, 0.71070687f);
-  p = fmaf(p, t, -0.14224837f);
-  p = fmaf(p, t, 0.12741479f);
-  p = p * t;
-  const float E = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170368f);
-  return x * (0.5f + copysignf(0.5f - p * E, x));
-}
-
 __device__ __forceinline__ Frag3 load_frag3(const unsigned char* p, int term_stride) {
   return Frag3{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(p + term_stride),
                *reinterpret_cast<const bf16x8*>(p + 2 * term_stride)};
@@ -110,6 +101,7 @@ struct WideFwdArgs {
   unsigned char* pack2;    // [U][kOtMax][3 terms][kPack2Tile]
   float* b2;               // [K][kOtMax][2 half][16]: b_k[32 ot + cd_row(r, half)]
   const float* HF;         // Hpre fragments
+  uint32_t skip_mask;      // MLPs whose second layer ran in the forward GEMM's epilogue (x3_gemm.h, FusedOut)
 };
 
 struct WideBwdMlp {
@@ -290,6 +282,7 @@ __global__ void __launch_bounds__(256) wide_out_k(const WideFwdArgs a) {
   // blockIdx.y deals the MLPs round-robin: with one wave per token tile for ALL MLPs a ListOps batch is 2000 waves, eight
   // per CU, and every Hpre load is exposed
   for (int k = blockIdx.y; k < g.K; k += gridDim.y) {
+    if ((a.skip_mask >> k) & 1) continue;
     const WideFwdMlp& d = a.m[k];
     const int ot_n = d.ot, unit0 = d.joff >> 5, nu = (d.h + 31) >> 5;
     f32x16 acc2[kOtMax];
@@ -766,14 +759,18 @@ int64_t psf_mlp_wide_bwd_workspace(int64_t T, int32_t E, int32_t K, const int32_
 int psf_mlp_wide_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float* const* A, const float* const* a,
                          const float* const* B, const float* const* b, const int32_t* h, const int32_t* O, float* const* Y,
                          void* saved, int64_t saved_bytes_given, void* workspace, int64_t workspace_bytes, void* stream) {
-  if (!X || !A || !a || !B || !b || !h || !O || !Y || !saved || !workspace) return psf_internal_fail(PSF_E_NULL, "psf_mlp_wide_fwd: NULL argument");
+  if (!X || !A || !a || !B || !b || !h || !O || !Y || !workspace) return psf_internal_fail(PSF_E_NULL, "psf_mlp_wide_fwd: NULL argument");
   WidePlan p;
   if (!make_wide_plan(T, E, K, h, O, &p))
     return psf_internal_fail(PSF_E_SHAPE, "psf_mlp_wide_fwd: need T >= 1, E a multiple of 16 in [16, 1024], 1 <= K <= 24, 1 <= h <= 128, 1 <= O <= 128");
   if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(saved) & 255) || (reinterpret_cast<uintptr_t>(workspace) & 255))
     return psf_internal_fail(PSF_E_ALIGN, "psf_mlp_wide_fwd: X must be 16-byte aligned, saved and workspace 256-byte aligned");
-  if (saved_bytes_given < saved_bytes(p) || workspace_bytes < fwd_ws_bytes(p))
-    return psf_internal_fail(PSF_E_SHAPE, "psf_mlp_wide_fwd: saved / workspace too small (psf_mlp_wide_saved_bytes, psf_mlp_wide_fwd_workspace)");
+  // saved == NULL: inference. The record lives in the workspace (which must then hold both) and need not be complete.
+  const bool keep = saved != nullptr;
+  const int64_t ws_need = fwd_ws_bytes(p) + (keep ? 0 : saved_bytes(p));
+  if ((keep && saved_bytes_given < saved_bytes(p)) || workspace_bytes < ws_need)
+    return psf_internal_fail(PSF_E_SHAPE, "psf_mlp_wide_fwd: saved / workspace too small (psf_mlp_wide_saved_bytes, psf_mlp_wide_fwd_workspace; "
+                                          "with saved == NULL the workspace must hold both)");
   WideFwdArgs fa;
   for (int k = 0; k < kMaxWideMlps; ++k) fa.m[k] = WideFwdMlp{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
   for (int k = 0; k < K; ++k) {
@@ -782,8 +779,8 @@ int psf_mlp_wide_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const 
     fa.m[k] = WideFwdMlp{A[k], a[k], B[k], b[k], Y[k], h[k], O[k], p.joff[k], p.ot[k]};
   }
   fa.g = p.g;
-  unsigned char* sv = reinterpret_cast<unsigned char*>(saved);
   unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
+  unsigned char* sv = keep ? reinterpret_cast<unsigned char*>(saved) : ws + fwd_ws_bytes(p);
   for (int t = 0; t < 3; ++t) fa.w1p[t] = ws + t * p.w1p_plane;
   fa.acat = reinterpret_cast<float*>(ws + 3 * p.w1p_plane);
   fa.pack2 = ws + 3 * p.w1p_plane + up((int64_t)p.g.J_pad * 4, 256);
@@ -808,9 +805,27 @@ int psf_mlp_wide_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const 
   ga.tiles_m = p.g.J_pad / 256, ga.tiles_n = (int32_t)(p.g.T_pad / 256), ga.splits = 1, ga.chunks = E / 16;
   ga.n_fast = 0, ga.epilogue = kEpiFragBias, ga.out = HF, ga.bias = fa.acat;
   ga.rows_valid = p.g.J_pad, ga.cols_valid = p.g.T_pad;
+  // Second layers of the MLPs with <= 32 outputs run in the GEMM's epilogue when every MLP is exactly one wave tile of
+  // 128 (padded) hidden rows: the GEMM wave that holds an MLP's Hpre applies GELU and the second layer to it in registers.
+  bool whole = true;
+  for (int k = 0; k < K; ++k) whole = whole && (h[k] + 31) / 32 == 4;
+  fa.skip_mask = 0;
+  ga.fo.enabled = 0;
+  if (whole && psf_g_wide_fuse.load()) {
+    ga.fo.enabled = 1;
+    ga.fo.store_hpre = keep ? 1 : 0;
+    ga.fo.pack2 = fa.pack2;
+    ga.fo.b2 = fa.b2;
+    ga.fo.T = T;
+    for (int k = 0; k < kFusedMlpsMax; ++k) ga.fo.Y[k] = nullptr, ga.fo.O[k] = 0;
+    for (int k = 0; k < K; ++k)
+      if (p.ot[k] == 1) ga.fo.Y[k] = Y[k], ga.fo.O[k] = O[k], fa.skip_mask |= 1u << k;
+  }
   hipError_t e = launch_gemm(false, false, ga, s);
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
-  hipLaunchKernelGGL(wide_out_k, dim3((unsigned)((T + 127) / 128), (unsigned)(K < 12 ? K : 12)), dim3(256), 0, s, fa);
+  int left = 0;
+  for (int k = 0; k < K; ++k) left += !((fa.skip_mask >> k) & 1);
+  if (left) hipLaunchKernelGGL(wide_out_k, dim3((unsigned)((T + 127) / 128), (unsigned)(left < 12 ? left : 12)), dim3(256), 0, s, fa);
   e = hipGetLastError();
   return e == hipSuccess ? PSF_OK : psf_internal_fail((int)e, hipGetErrorString(e));
 }

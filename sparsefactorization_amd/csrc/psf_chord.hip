@@ -71,6 +71,7 @@ std::atomic<int> psf_g_mlp_variant{0};
 // Fused producer MLP backward: 0 = auto (= 3), 1 = all-f32-MFMA kernel, 2 = split-bf16 kernel with steps 4 and 5 left on
 // the f32 instruction, 3 = split-bf16 kernel on dual-use LDS planes (all five GEMMs on the bf16 matrix pipe)
 std::atomic<int> psf_g_mlp_bwd_variant{0};
+std::atomic<int> psf_g_wide_fuse{1};  // wide producer MLPs: second layers of narrow-output MLPs in the forward GEMM's epilogue
 namespace {
 
 struct Knob {
@@ -93,6 +94,7 @@ Knob g_knobs[] = {
     {"chain_cc", &g_chain_cc, 0, 1},
     {"mlp_variant", &psf_g_mlp_variant, 0, 3},
     {"mlp_bwd_variant", &psf_g_mlp_bwd_variant, 0, 3},
+    {"wide_fuse", &psf_g_wide_fuse, 0, 1},
 };
 
 int ceil_log2(int64_t x) {
@@ -653,10 +655,10 @@ const char* psf_last_error(void) { return g_err; }
 const char* psf_build_info(void) {
   return "libpsf_chord: gfx950 (CDNA4, wave64) | hipcc " __VERSION__
          " | fwd: generic<f32,f64> + LDS-window<f32, L=4..20, LDS-DMA staging> + LDS-resident chain<f32, N<=2048>"
-         " | bwd: generic dV/dW<f32,f64> + LDS-window dV/dW<f32>"
+         " | bwd: generic dV/dW<f32,f64> + LDS-window dV/dW<f32> + fused dV+dW step<f32, C<=32>"
          " | producers: fused MLP fwd (split-bf16 MFMA at f32 accuracy, f32 MFMA) + fused MLP bwd (split-bf16 MFMA on dual-use LDS planes, f32 MFMA),"
          " tall-skinny weight gradients (f32 MFMA), token embedding + positional add"
-         " wide producer MLPs (E <= 1024: stacked first layers as split-bf16 GEMMs from bf16 term planes, LDS-DMA ring)"
+         ", wide producer MLPs (E <= 1024: stacked first layers as split-bf16 GEMMs from bf16 term planes, LDS-DMA ring)"
          " | arithmetic of the chord path: uncontracted mul+add, links ascending"
 #ifdef PSF_CSRC_HASH
          " | csrc=" PSF_CSRC_HASH  // build.csrc_hash() of the sources this library was built from (_lib.load compares)

@@ -68,6 +68,35 @@ enum Epilogue : int32_t {
   kEpiFragBias = 1   // out in accumulator-fragment order, + bias[m]: block (n >> 5, m >> 5) = [4][64 lanes][4 registers]
 };
 
+constexpr int kOutTilesMax = 4;    // output tiles of 32 of a second layer (O <= 128)
+constexpr int kPack2Tile = 2048;   // one term of one (hidden unit, output tile) of the second-layer operand: [2 s][2 half][32 o][8] bf16
+constexpr int kFusedMlpsMax = 24;
+
+// The second layer inside the forward GEMM's epilogue (kEpiFragBias, square shape, every MLP exactly 128 padded hidden
+// rows): a wave's 128 x 64 tile is ONE MLP x two token tiles, so Y^T = B GELU(Hpre^T) + b needs nothing but the wave's own
+// accumulators (accumulator-as-operand). Y[k] == nullptr: MLP k is not fused (wide outputs) and only its Hpre is stored.
+struct FusedOut {
+  float* Y[kFusedMlpsMax];   // [T, O[k]] row-major
+  int32_t O[kFusedMlpsMax];
+  const unsigned char* pack2;  // [unit][kOutTilesMax][3 terms][kPack2Tile], operand order of wide_pack_fwd_k
+  const float* b2;             // [k][kOutTilesMax][2 half][16]
+  int64_t T;
+  int32_t enabled;             // 0: plain kEpiFragBias
+  int32_t store_hpre;          // 0 (inference): fused MLPs do not store their Hpre
+};
+
+// y = GELU(x) = x Phi(x); Phi by Abramowitz & Stegun 26.2.17 (|error| <= 7.5e-8), scalar f32 instructions (mlp_bwd.hip)
+__device__ __forceinline__ float gelu_only(float x) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.2316419f, 1.0f));
+  float p = fmaf(0.53070271f, t, -0.72657602f);
+  p = fmaf(p, t, 0.71070687f);
+  p = fmaf(p, t, -0.14224837f);
+  p = fmaf(p, t, 0.12741479f);
+  p = p * t;
+  const float E = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170368f);
+  return x * (0.5f + copysignf(0.5f - p * E, x));
+}
+
 struct GemmArgs {
   Operand A, B;          // NT: rows = m (n), column blocks = k chunks.  TN: rows = k, column blocks = m (n) / 16
   int32_t tiles_m, tiles_n, splits;
@@ -79,6 +108,7 @@ struct GemmArgs {
   int64_t ld;            // kEpiRowMajor: leading dimension (floats)
   int64_t rows_alloc;    // kEpiRowMajor with splits: rows per split slab
   int64_t rows_valid, cols_valid;
+  FusedOut fo;           // kEpiFragBias only
 };
 
 // 16 bytes per lane global -> LDS; the wave's 64 lanes fill 1 KB at the LDS address in M0. Issued as inline assembly:
@@ -267,25 +297,77 @@ __global__ void __launch_bounds__(kGemmThreads, 1) x3_gemm_k(const GemmArgs g) {
   //      D[m0 + (wm * MT + i) * 32 + cd_row(r, half)][n0 + (wn * NTL + j) * 32 + c].
   if (g.epilogue == kEpiFragBias) {
     const int64_t units = (int64_t)g.tiles_m * (BM / 32);
+    // block (token tile, hidden unit) of Hpre = 4 KB: [q = r >> 2][lane][r & 3] — four 1 KB dwordx4 bursts per tile
+    float* Yk = nullptr;
+    int k_mlp = 0, O = 0;
+    if constexpr (!TN && MT == 4) {
+      if (g.fo.enabled) {
+        k_mlp = (int)((m0 + wm * 128) >> 7);  // wave-uniform: the wave's 128 rows are MLP k_mlp's four units
+        Yk = g.fo.Y[k_mlp];
+        O = g.fo.O[k_mlp];
+      }
+    }
+    const bool keep_hpre = Yk == nullptr || g.fo.store_hpre;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int64_t mrow = m0 + (wm * MT + i) * 32;
-      float bv[16];
+    for (int j = 0; j < NTL; ++j) {
+      const int64_t ncol = n0 + (wn * NTL + j) * 32;
+      if (ncol >= g.cols_valid) continue;  // wave-uniform
+      f32x16 acc2;
+      if (Yk) {
+        const float4* bp = reinterpret_cast<const float4*>(g.fo.b2 + ((k_mlp * kOutTilesMax) * 2 + half) * 16);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(g.bias + mrow + 8 * q + 4 * half);
-        bv[4 * q] = v.x, bv[4 * q + 1] = v.y, bv[4 * q + 2] = v.z, bv[4 * q + 3] = v.w;
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = bp[q];
+          acc2[4 * q] = v.x, acc2[4 * q + 1] = v.y, acc2[4 * q + 2] = v.z, acc2[4 * q + 3] = v.w;
+        }
       }
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) {
-        const int64_t ncol = n0 + (wn * NTL + j) * 32;
-        if (ncol >= g.cols_valid) continue;  // wave-uniform
-        // block (token tile, hidden unit) = 4 KB: [q = r >> 2][lane][r & 3] — four 1 KB dwordx4 bursts per tile
-        float4* dst = reinterpret_cast<float4*>(g.out + (((ncol >> 5) * units + (mrow >> 5)) * 16) * 64) + lane;
+      for (int i = 0; i < MT; ++i) {
+        const int64_t mrow = m0 + (wm * MT + i) * 32;
+        float h[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          dst[q * 64] = make_float4(acc[i][j][4 * q] + bv[4 * q], acc[i][j][4 * q + 1] + bv[4 * q + 1],
-                                    acc[i][j][4 * q + 2] + bv[4 * q + 2], acc[i][j][4 * q + 3] + bv[4 * q + 3]);
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(g.bias + mrow + 8 * q + 4 * half);
+          h[4 * q] = acc[i][j][4 * q] + v.x, h[4 * q + 1] = acc[i][j][4 * q + 1] + v.y;
+          h[4 * q + 2] = acc[i][j][4 * q + 2] + v.z, h[4 * q + 3] = acc[i][j][4 * q + 3] + v.w;
+        }
+        if (keep_hpre) {
+          float4* dst = reinterpret_cast<float4*>(g.out + (((ncol >> 5) * units + (mrow >> 5)) * 16) * 64) + lane;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dst[q * 64] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+        }
+        if (Yk) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) h[r] = gelu_only(h[r]);
+          const Split16 ys = split16(h);
+          const unsigned char* wp = g.fo.pack2 + ((int64_t)((mrow >> 5) * kOutTilesMax) * 3) * kPack2Tile;
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const unsigned char* wq = wp + ((s2 * 2 + half) * 32 + c) * 16;
+            const Frag3 wb{*reinterpret_cast<const bf16x8*>(wq), *reinterpret_cast<const bf16x8*>(wq + kPack2Tile),
+                           *reinterpret_cast<const bf16x8*>(wq + 2 * kPack2Tile)};
+            const Frag3 hb{acc_frag(ys, 0, s2), acc_frag(ys, 1, s2), acc_frag(ys, 2, s2)};
+            acc2 = mfma6(wb, hb, acc2);
+          }
+        }
+      }
+      if (Yk) {  // the lane holds Y^T[o = 8 q + 4 half + (0..3)][tok = ncol + c] in registers 4 q .. 4 q + 3
+        const int64_t tok = ncol + c;
+        const bool vec_ok = (O & 3) == 0 && (reinterpret_cast<uintptr_t>(Yk) & 15) == 0;
+        if (tok < g.fo.T) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int o0 = 8 * q + 4 * half;
+            float* yp = Yk + tok * O + o0;
+            if (vec_ok) {
+              if (o0 < O) *reinterpret_cast<float4*>(yp) = make_float4(acc2[4 * q], acc2[4 * q + 1], acc2[4 * q + 2], acc2[4 * q + 3]);
+            } else {
+#pragma unroll
+              for (int i2 = 0; i2 < 4; ++i2)
+                if (o0 + i2 < O) yp[i2] = acc2[4 * q + i2];
+            }
+          }
+        }
       }
     }
   } else {

@@ -231,8 +231,9 @@ def _scratch(nbytes: int, dev) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)  # the caching allocator aligns to 512 bytes
 
 
-def _wide_forward_raw(x2: torch.Tensor, params: Sequence[torch.Tensor]):
-    """(Y_0..Y_{K-1}, saved): ``saved`` holds X as bf16 term planes and the hidden pre-activations (mlp_wide.hip)."""
+def _wide_forward_raw(x2: torch.Tensor, params: Sequence[torch.Tensor], keep: bool = True):
+    """(Y_0..Y_{K-1}, saved): ``saved`` holds X as bf16 term planes and the hidden pre-activations (mlp_wide.hip).
+    ``keep`` False (inference): no record is kept — the library works in scratch and skips what only a backward reads."""
     T, E, K, h, O = _wide_sizes(x2, params)
     dev = x2.device
     lib = _lib.load()
@@ -240,11 +241,12 @@ def _wide_forward_raw(x2: torch.Tensor, params: Sequence[torch.Tensor]):
     n_saved, n_ws = lib.psf_mlp_wide_saved_bytes(T, E, K, h, O), lib.psf_mlp_wide_fwd_workspace(T, E, K, h, O)
     if n_saved < 0 or n_ws < 0:
         raise ValueError("psf_mlp_wide_fwd does not support these layer sizes")
-    saved, ws = _scratch(n_saved, dev), _scratch(n_ws, dev)
+    saved = _scratch(n_saved, dev) if keep else None
+    ws = _scratch(n_ws + (0 if keep else n_saved + 256), dev)
     ys = [torch.empty((T, B.shape[0]), dtype=torch.float32, device=dev) for B in Bs]
     with torch.cuda.device(dev):
         rc = lib.psf_mlp_wide_fwd_f32(x2.data_ptr(), T, E, K, _ptrs(As), _ptrs(as_), _ptrs(Bs), _ptrs(bs), h, O, _ptrs(ys),
-                                      saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(),
+                                      saved.data_ptr() if keep else None, saved.numel() if keep else 0, ws.data_ptr(), ws.numel(),
                                       torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "psf_mlp_wide_fwd_f32")
     return ys, saved
@@ -299,7 +301,7 @@ def wide_apply(x: torch.Tensor, blocks: Sequence[nn.Module]) -> List[torch.Tenso
     if _needs_grad(x, blocks):
         ys = _WideMLPFn.apply(x.reshape(-1, E).contiguous(), *_params_of(blocks))
     else:
-        ys, _ = _wide_forward_raw(x.detach().reshape(-1, E).contiguous(), [p.detach().contiguous() for p in _params_of(blocks)])
+        ys, _ = _wide_forward_raw(x.detach().reshape(-1, E).contiguous(), [p.detach().contiguous() for p in _params_of(blocks)], keep=False)
     return [y.reshape(*lead, y.shape[1]) for y in ys]
 
 

@@ -159,3 +159,35 @@ def test_listops_network_takes_the_wide_path(gpu):
             assert p.grad is None, n
         else:
             assert rel_inf(p.grad.cpu().numpy(), q.grad.cpu().numpy()) <= 2e-4, n
+
+
+def test_second_layer_in_the_gemm_epilogue_equals_the_separate_kernel(gpu):
+    """Networks whose MLPs all have 97..128 hidden rows run the second layers of their narrow-output MLPs inside the first
+    layers' GEMM epilogue (knob wide_fuse): same arithmetic in the same order as wide_out_k — equal bits —, with a
+    wide-output MLP in the same call taking the separate kernel, in training and in inference (which keeps no record)."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import fused_mlp
+    torch.manual_seed(21)
+    blocks = _blocks(gpu, 128, [(128, 96), (128, 12), (100, 15), (128, 32), (97, 1)])
+    x = torch.randn(3, 777, 128, device=gpu)
+    outs = {}
+    for fuse in (1, 0):
+        sfa.set_tuning("wide_fuse", fuse)
+        try:
+            with torch.no_grad():
+                inf = fused_mlp.wide_apply(x, blocks)
+            xg = x.clone().requires_grad_(True)
+            tr = fused_mlp.wide_apply(xg, blocks)
+            torch.autograd.backward(tr, [torch.ones_like(t) for t in tr])
+            outs[fuse] = (inf, [t.detach() for t in tr], xg.grad, [p.grad.clone() for b in blocks for p in b.parameters()])
+            for b in blocks:
+                b.zero_grad()
+        finally:
+            sfa.set_tuning("wide_fuse", 1)
+    for a, b in zip(outs[1][0] + outs[1][1], outs[0][0] + outs[0][1]):
+        assert torch.equal(a, b)
+    assert all(torch.equal(a, b) for a, b in zip(outs[1][0], outs[1][1]))  # inference == training forward
+    assert torch.equal(outs[1][2], outs[0][2]) and all(torch.equal(a, b) for a, b in zip(outs[1][3], outs[0][3]))
+    for blk, y in zip(blocks, outs[1][0]):
+        ref = copy.deepcopy(blk).double()(x.double())
+        assert rel_inf(y.cpu().numpy(), ref.detach().cpu().numpy()) <= 1e-5
