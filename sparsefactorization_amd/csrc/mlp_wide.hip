@@ -122,7 +122,8 @@ struct WideBwdArgs {
   unsigned char* packbt;   // [U][8 k-steps][3 terms][kPackBtStep]
   unsigned char* gp[3];    // G planes: rows tok (T_pad), column blocks j
   const float* HF;
-  float* part;             // [workgroups][rec_total] partial sums of dB^T, da, db
+  float* part;             // [groups][rec_total] partial sums of dB^T, da, db
+  float* red;              // [kRedSlices][rec_total] first stage of their reduction
   const float* dapart;     // [splits][J_pad][E_pad] partial dAcat
   // float offset of a unit's first record in a group's slab; a unit has nsub(unit) records of rec_size(unit) floats:
   // [ot][1024] dB^T | [32] da | [ot][32] db (first unit of its MLP)
@@ -215,14 +216,16 @@ __global__ void __launch_bounds__(256) wide_pack_fwd_k(const WideFwdArgs a) {
 __global__ void __launch_bounds__(256) wide_pack_bwd_k(const WideBwdArgs a) {
   const WideGeom& g = a.g;
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
-  if (gid < 3) {  // (0) the work items of wide_mid_k of class gid, in unit order
+  if (gid < g.J / 32) {  // (0) the work items of wide_mid_k by unit class, in unit order: thread `unit` places its own
+    const int unit = (int)gid;
+    const WideBwdMlp& d = a.m[g.unit_k[unit]];
+    const int cls = wide_class(d.O), nsub = wide_nsub(d.ot);
     int n = 0;
-    for (int unit = 0; unit < g.J / 32; ++unit) {
-      const WideBwdMlp& d = a.m[g.unit_k[unit]];
-      if (wide_class(d.O) != (int)gid) continue;
-      const int nsub = wide_nsub(d.ot);
-      for (int sub = 0; sub < nsub; ++sub) a.slots[gid * kSlotClass + n++] = (uint32_t)unit | ((uint32_t)sub << 8) | ((uint32_t)nsub << 16);
+    for (int u2 = 0; u2 < unit; ++u2) {
+      const WideBwdMlp& d2 = a.m[g.unit_k[u2]];
+      if (wide_class(d2.O) == cls) n += wide_nsub(d2.ot);
     }
+    for (int sub = 0; sub < nsub; ++sub) a.slots[cls * kSlotClass + n + sub] = (uint32_t)unit | ((uint32_t)sub << 8) | ((uint32_t)nsub << 16);
   }
   // (1) Wcat^T planes: rows e (E_pad), column blocks jb (J / 16): element (e, j) = Wcat[j][e]
   const int jb_n = g.J / 16;
@@ -592,8 +595,43 @@ __global__ void __launch_bounds__(512, 1) wide_mid_k(const WideBwdArgs a, const 
   }
 }
 
-// dB, da, db: sum the items' records in a fixed order and scatter.
-__global__ void __launch_bounds__(256) wide_reduce_small_k(const WideBwdArgs a) {
+// dB, da, db: sum the items' records in a fixed order and scatter. Two stages: kRedSlices workgroup slices each sum a
+// contiguous range of the records v = group * nsub + sub with eight loads in flight per thread (one stage over all 250 -
+// 1000 records of a unit was a chain of 32 - 125 dependent memory round trips: 86 us for 65 MB), then the slices are added
+// in order.
+constexpr int kRedSlices = 8;
+
+__global__ void __launch_bounds__(256) wide_reduce_small1_k(const WideBwdArgs a) {
+  const WideGeom& g = a.g;
+  const int unit = blockIdx.y, slice = blockIdx.z;
+  const int k = g.unit_k[unit];
+  if (k < 0) return;
+  const WideBwdMlp& d = a.m[k];
+  const bool first = 32 * unit == d.joff;
+  const int rec_size = wide_rec_size(d.ot, first), nsub = wide_nsub(d.ot);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rec_size) return;
+  const float* p = a.part + a.rec_off[unit] + i;
+  const int sh = nsub == 4 ? 2 : nsub == 2 ? 1 : 0, n = a.groups << sh;
+  const int per = (n + kRedSlices - 1) / kRedSlices;
+  const int v0 = slice * per, v1 = v0 + per < n ? v0 + per : n;
+  auto at = [&](int v) { return p[(int64_t)(v >> sh) * a.rec_total + (v & (nsub - 1)) * rec_size]; };
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int w = v0;
+  for (; w + 8 <= v1; w += 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = at(w + q);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] += v[q];
+  }
+  for (int q = 0; w < v1; ++w, ++q) acc[q] += at(w);
+  // one slot per (slice, first sub-record position of the unit): the slab of group 0 is laid out like every other
+  a.red[(int64_t)slice * a.rec_total + a.rec_off[unit] + i] =
+      (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])));
+}
+
+__global__ void __launch_bounds__(256) wide_reduce_small2_k(const WideBwdArgs a) {
   const WideGeom& g = a.g;
   const int unit = blockIdx.y;
   const int k = g.unit_k[unit];
@@ -601,25 +639,13 @@ __global__ void __launch_bounds__(256) wide_reduce_small_k(const WideBwdArgs a) 
   const WideBwdMlp& d = a.m[k];
   const int hb = 32 * unit - d.joff;
   const bool first = hb == 0;
-  const int rec_size = wide_rec_size(d.ot, first), nsub = wide_nsub(d.ot);
+  const int rec_size = wide_rec_size(d.ot, first);
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= rec_size) return;
-  const float* p = a.part + a.rec_off[unit] + i;
-  // fixed order: eight interleaved running sums over the records v = group * nsub + sub (eight independent loads in
-  // flight per thread: the loop is bound by load latency; nsub is 1, 2 or 4)
-  const int sh = nsub == 4 ? 2 : nsub == 2 ? 1 : 0, n = a.groups << sh;
-  auto at = [&](int v) { return p[(int64_t)(v >> sh) * a.rec_total + (v & (nsub - 1)) * rec_size]; };
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  int w = 0;
-  for (; w + 8 <= n; w += 8) {
-    float v[8];
+  const float* p = a.red + a.rec_off[unit] + i;
+  float total = p[0];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = at(w + q);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] += v[q];
-  }
-  for (int q = 0; w < n; ++w, ++q) acc[q] += at(w);
-  const float total = (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])));
+  for (int sl = 1; sl < kRedSlices; ++sl) total += p[(int64_t)sl * a.rec_total];
   if (i < d.ot * 1024) {
     const int ot = i >> 10, j = (i >> 5) & 31, o = 32 * ot + (i & 31);
     if (hb + j < d.h && o < d.O) d.dB[(int64_t)o * d.h + hb + j] = total;
@@ -724,7 +750,7 @@ int64_t fwd_ws_bytes(const WidePlan& p) {
   return 3 * p.w1p_plane + up((int64_t)p.g.J_pad * 4, 256) + p.pack2_bytes + up((int64_t)p.g.K * kOtMax * 32 * 4, 256);
 }
 int64_t bwd_ws_bytes(const WidePlan& p) {
-  return 3 * p.w1tp_plane + p.packbt_bytes + kSlotBytes + 3 * p.gp_plane + up((int64_t)p.groups * p.rec_total * 4, 256) +
+  return 3 * p.w1tp_plane + p.packbt_bytes + kSlotBytes + 3 * p.gp_plane + up((int64_t)(p.groups + 8) * p.rec_total * 4, 256) +
          (int64_t)p.splits * p.g.J_pad * p.g.E_pad * 4;
 }
 
@@ -856,7 +882,8 @@ int psf_mlp_wide_bwd_f32(const void* saved, int64_t saved_bytes_given, int64_t T
   ba.slots = reinterpret_cast<uint32_t*>(ba.packbt + p.packbt_bytes);
   for (int t = 0; t < 3; ++t) ba.gp[t] = ba.packbt + p.packbt_bytes + kSlotBytes + t * p.gp_plane;
   ba.part = reinterpret_cast<float*>(ba.gp[0] + 3 * p.gp_plane);
-  float* dapart = ba.part + up((int64_t)p.groups * p.rec_total * 4, 256) / 4;
+  ba.red = ba.part + (int64_t)p.groups * p.rec_total;  // kRedSlices = 8 slabs
+  float* dapart = ba.part + up((int64_t)(p.groups + 8) * p.rec_total * 4, 256) / 4;
   ba.dapart = dapart;
   ba.HF = reinterpret_cast<const float*>(sv + 3 * p.xp_plane);
   for (int u = 0; u < kMaxWideUnits; ++u) ba.rec_off[u] = p.rec_off[u];
@@ -898,7 +925,12 @@ int psf_mlp_wide_bwd_f32(const void* saved, int64_t saved_bytes_given, int64_t T
     e = launch_gemm(true, p.narrow_e, ga, s);
     if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(wide_reduce_small_k, dim3((kOtMax * 1024 + 32 + kOtMax * 32 + 255) / 256, (unsigned)(p.g.J / 32)), dim3(256), 0, s, ba);
+  static_assert(kRedSlices == 8, "workspace layout");
+  {
+    const dim3 grid((kOtMax * 1024 + 32 + kOtMax * 32 + 255) / 256, (unsigned)(p.g.J / 32), kRedSlices);
+    hipLaunchKernelGGL(wide_reduce_small1_k, grid, dim3(256), 0, s, ba);
+    hipLaunchKernelGGL(wide_reduce_small2_k, dim3(grid.x, grid.y), dim3(256), 0, s, ba);
+  }
   hipLaunchKernelGGL(wide_reduce_da_k, dim3((unsigned)(((int64_t)p.g.J * (E / 4) + 255) / 256)), dim3(256), 0, s, ba);
   e = hipGetLastError();
   return e == hipSuccess ? PSF_OK : psf_internal_fail((int)e, hipGetErrorString(e));
