@@ -314,7 +314,10 @@ TRAIN_BATCH, TRAIN_BATCHES, EVAL_BATCHES, TRAIN_EPOCHS = 40, 8, 2, 2
 def gen_training(se, utils):
     """cfg1 (N = 128, n_W = 7, batch 40; synthetic_training_config.py:4-18,72-86), `seed_everything(42)` as
     psf_training.py:16, Adam(lr) and the loss choice of psf_training.py:50-58, the reference's own TrainModel over
-    8 fixed training batches per epoch (shuffle off), 2 epochs, evaluation after each (test_freq = 1)."""
+    8 fixed training batches per epoch (shuffle off), 2 epochs, evaluation after each (test_freq = 1).
+    The INPUT sequences and labels are drawn with this package's own seeded generators (``synth_data``, whose label rules and
+    distributions are pinned to the reference's generators by ``synth_data_reference_samples.npz``) and stored in the fixture:
+    what the fixture pins is the reference's model, loss, optimiser and loop on those inputs, not the reference's sampler."""
     import contextlib
     import io
     import re
