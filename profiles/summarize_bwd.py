@@ -73,8 +73,9 @@ def main():
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 rd, wr = 2.0 * c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
                 k["traffic_bytes"], k["traffic_read"], k["traffic_write"] = rd + wr, rd, wr
-                k["traffic_over_alg"] = (rd + wr) / alg
-                row += [f"{(rd + wr) / 1e6:.1f} ({rd / 1e6:.1f}+{wr / 1e6:.1f})", f"{(rd + wr) / alg:.3f}" if full else ""]
+                alg_k = 4 * B * N * (2 * L + 3 * C) if fused else alg
+                k["traffic_over_alg"] = (rd + wr) / alg_k
+                row += [f"{(rd + wr) / 1e6:.1f} ({rd / 1e6:.1f}+{wr / 1e6:.1f})", f"{(rd + wr) / alg_k:.3f}" if full else ""]
             else:
                 row += ["", ""]
             if c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0) > 0:
