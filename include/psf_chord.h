@@ -341,6 +341,8 @@ int psf_mlp_wide_bwd_f32(const void* saved, int64_t saved_bytes, int64_t T, int3
  *                      on the bf16 matrix pipe, every operand split once, transposed operands by ds_read_b64_tr_b16;
  *                      1 = all-f32-MFMA kernel; 2 = the first split-bf16 kernel (steps 1, 2, 6 on bf16, the token
  *                      contractions on the f32 instruction)
+ *   key "mlp_fwd_store": split-bf16 MLP forward: 1 = finished output tiles are stored straight from the accumulator registers
+ *                      (default), 0 = through an LDS transposition as contiguous bursts (the first form; equal bits)
  *   key "wide_fuse"  : psf_mlp_wide_fwd_f32: 1 = the second layers of the MLPs with <= 32 outputs run inside the first
  *                      layers' GEMM epilogue when every MLP has 97..128 hidden rows (default), 0 = always the separate kernel
  *   key "xcd_remap"  : 1 = keep a batch element's tiles on one XCD group (default), 0 = linear

@@ -30,6 +30,9 @@
 #include "mlp_fwd_x3.h"
 #include "mlp_x3_common.h"
 
+#include <atomic>
+extern std::atomic<int> psf_g_mlp_fwd_store;  // psf_chord.hip: tuning knob "mlp_fwd_store"
+
 namespace {
 
 using namespace psf_x3;
@@ -65,6 +68,12 @@ struct X3Args {
   int64_t T;
   int32_t E, U;
 };
+
+// 4-byte-aligned vectors: hipcc emits global_store_dwordx4 / x3 / x2 for them (rows of O floats are 16-byte aligned only
+// when O is a multiple of 4; gfx950 stores unaligned vectors)
+struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
+struct __attribute__((packed, aligned(4))) F3u { float x, y, z; };
+struct __attribute__((packed, aligned(4))) F2u { float x, y; };
 
 // GELU(x) = x Phi(x) for a PAIR of values, on packed f32 math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two
 // elements per instruction — the kernel is VALU-issue-bound, rocprofv3: ~70 % VALU-busy, 22 % matrix-pipe-busy).
@@ -143,9 +152,14 @@ __device__ unsigned long long psf_x3f_trace[4][16];
 #define PSF_FTRACE(slot) do { } while (0)
 #endif
 
-template <int TPW>
+// DIRECT: finished Y^T tiles leave straight from the accumulator registers (knob "mlp_fwd_store" = 1, the default) instead of
+// through the LDS transposition + contiguous bursts of the first form (0): equal bits, 1-10 % less time
+// (profiles/r03ag_mlp_fwd_store_ab.log; keeping the tile in registers and storing it a unit later, ahead of the next
+// barrier's vmcnt(0), measured the same) — per unit the park + flush were ~2000 of ~7700 clocks of a wave.
+template <int TPW, int MODE>  // MODE: 0 = LDS-transposed bursts, 1 = direct stores at the end of the unit
 __global__ void __launch_bounds__(256, 2)  // <= 256 registers: two workgroups (two waves per SIMD) per CU
 x3_fwd_k(const X3Args a) {
+  constexpr bool DIRECT = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int c = lane & 31, half = lane >> 5;
@@ -154,6 +168,9 @@ x3_fwd_k(const X3Args a) {
   const int64_t tiles = (a.T + 31) / 32;
   const int64_t tiles_per_block = 4 * TPW;
 
+  // (The inline-assembly form of this DMA that mlp_bwd.hip uses — hidden from hipcc's alias rule, explicit vmcnt(0) before the
+  // barrier — was tried here too: its M0 save / restore per piece made the issue take 1050 instead of 420 clocks per unit and
+  // the kernel 4 % slower.)
   auto stage = [&](int u) {
     const unsigned char* src = a.images + (size_t)u * kImgBytes;
     unsigned char* dst = lds_raw + (u & 1) * kImgBytes;
@@ -257,6 +274,27 @@ x3_fwd_k(const X3Args a) {
       pend = -1;
     };
 
+    // The lane holds Y^T[o = 8 q + 4 half + (0..3)][tok = c] in registers 4 q .. 4 q + 3: up to four consecutive floats of its
+    // token's row go out as one (unaligned) vector store per q — no LDS transposition, no parked tile, no flush.
+    auto store_direct = [&](int k, const f32x16 (&y)[TPW]) {
+      const X3Mlp& dp = a.m[k];
+      const int O = dp.O;
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) {
+        const int64_t tok = t0[tp] + c;
+        if (tok < a.T) {
+          float* yrow = dp.Y + tok * O;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int o0 = 8 * q + 4 * half, n = O - o0;
+            if (n >= 4) *reinterpret_cast<F4u*>(yrow + o0) = F4u{y[tp][4 * q], y[tp][4 * q + 1], y[tp][4 * q + 2], y[tp][4 * q + 3]};
+            else if (n == 3) *reinterpret_cast<F3u*>(yrow + o0) = F3u{y[tp][4 * q], y[tp][4 * q + 1], y[tp][4 * q + 2]};
+            else if (n == 2) *reinterpret_cast<F2u*>(yrow + o0) = F2u{y[tp][4 * q], y[tp][4 * q + 1]};
+            else if (n == 1) yrow[o0] = y[tp][4 * q];
+          }
+        }
+      }
+    };
     for (int u = 0; u < U; ++u) {
 #ifdef PSF_X3F_TRACE
       const bool trace_on = blockIdx.x == 700 && u == 5;
@@ -266,7 +304,9 @@ x3_fwd_k(const X3Args a) {
       PSF_FTRACE(1);
       if (u + 1 < U) stage(u + 1);
       PSF_FTRACE(6);
-      if (pend >= 0) flush();
+      if constexpr (!DIRECT) {
+        if (pend >= 0) flush();
+      }
       PSF_FTRACE(2);
       const unsigned char* img = lds_raw + (u & 1) * kImgBytes;
       const float* sa = reinterpret_cast<const float*>(img + kOffSa);
@@ -354,7 +394,9 @@ x3_fwd_k(const X3Args a) {
       }
 
       PSF_FTRACE(4);
-      if (last) {  // park the Y^T tiles as [tok][o] (stride 33); stored at the start of the next unit
+      if (MODE == 1 && last) {
+        store_direct((int)(a.unit[u] & 0xff), acc2);
+      } else if (!DIRECT && last) {  // park the Y^T tiles as [tok][o] (stride 33); stored at the start of the next unit
 #pragma unroll
         for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
@@ -363,7 +405,9 @@ x3_fwd_k(const X3Args a) {
       }
       PSF_FTRACE(5);
     }
-    if (pend >= 0) flush();
+    if constexpr (!DIRECT) {
+      if (pend >= 0) flush();
+    }
   }
 }
 
@@ -421,12 +465,16 @@ hipError_t psf_x3_mlp_fwd_launch(const float* X, int64_t T, int32_t E, int32_t K
   const int64_t blocks_needed = (tiles + 4 * tpw - 1) / (4 * tpw);
   const int grid = (int)(blocks_needed < 4096 ? blocks_needed : 4096);
   const size_t lds = 2 * (size_t)kImgBytes + 4 * (size_t)tpw * kScr * sizeof(float);
-  if (tpw == 2) {
-    e = hipFuncSetAttribute((const void*)x3_fwd_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((x3_fwd_k<2>), dim3(grid), dim3(256), lds, s, args);
-  } else {
-    hipLaunchKernelGGL((x3_fwd_k<1>), dim3(grid), dim3(256), lds, s, args);
-  }
+  auto launch = [&](auto kernel) {
+    if (lds > 48 * 1024) {
+      e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, args);
+  };
+  const int mode = psf_g_mlp_fwd_store.load();
+  if (tpw == 2) mode == 1 ? launch(x3_fwd_k<2, 1>) : launch(x3_fwd_k<2, 0>);
+  else mode == 1 ? launch(x3_fwd_k<1, 1>) : launch(x3_fwd_k<1, 0>);
+  if (e != hipSuccess) return e;
   return hipGetLastError();
 }
