@@ -340,7 +340,10 @@ int psf_mlp_wide_bwd_f32(const void* saved, int64_t saved_bytes, int64_t T, int3
  *   key "mlp_bwd_variant": psf_mlp_bwd_f32: 0 = auto (default) = 3 = split-bf16 on dual-use LDS planes: all five GEMMs
  *                      on the bf16 matrix pipe, every operand split once, transposed operands by ds_read_b64_tr_b16;
  *                      1 = all-f32-MFMA kernel; 2 = the first split-bf16 kernel (steps 1, 2, 6 on bf16, the token
- *                      contractions on the f32 instruction)
+ *                      contractions on the f32 instruction); 4 = the same arithmetic as 3 with the two waves of a SIMD in
+ *                      different roles (a producer wave: GELU and splits; a consumer wave: the contractions over tokens),
+ *                      handed over through LDS counters without workgroup barriers — measured 8 % slower than 3
+ *                      (one wave alone issues vector instructions at half the SIMD's rate) and kept as a record
  *   key "mlp_fwd_store": split-bf16 MLP forward: 1 = finished output tiles are stored straight from the accumulator registers
  *                      (default), 0 = through an LDS transposition as contiguous bursts (the first form; equal bits)
  *   key "wide_fuse"  : psf_mlp_wide_fwd_f32: 1 = the second layers of the MLPs with <= 32 outputs run inside the first

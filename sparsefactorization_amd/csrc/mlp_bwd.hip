@@ -945,8 +945,31 @@ mlp_bwd_x3p_k(const BwdArgs a) {
       for (int i = 0; i < NDY; ++i) dbp[i] = 0.f;
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp) {
-        // 0. this tile's dY values -> split terms (the lane's step-2 B fragments); start the next tile-unit's loads
         PSF_TRACE(2 + 8 * tp);
+        const unsigned char* xp = XP + tp * 3 * kPlaneBytes;
+        // 1. Hpre^T = A_u X^T + a_u : both operands by row reads. In front of the first use of the dY registers: these twelve
+        // MFMAs need the image and the X planes only, and cover what is left of the dY loads' (and, behind the partial-sum
+        // stores of the previous unit, the stores') round trip.
+        f32x16 acc1;
+        {
+          const float4* sa4 = reinterpret_cast<const float4*>(img + kPOffSa + 64 * half);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = sa4[q];
+            acc1[4 * q] = v.x;
+            acc1[4 * q + 1] = v.y;
+            acc1[4 * q + 2] = v.z;
+            acc1[4 * q + 3] = v.w;
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const Frag3 wa{row_frag(img, L, s), row_frag(img + kPlaneBytes, L, s), row_frag(img + 2 * kPlaneBytes, L, s)};
+          const Frag3 xb{row_frag(xp, L, s), row_frag(xp + kPlaneBytes, L, s), row_frag(xp + 2 * kPlaneBytes, L, s)};
+          acc1 = mfma6(wa, xb, acc1);
+        }
+        asm volatile("" : "+v"(acc1) : : "memory");
+        // 0. this tile's dY values -> split terms (the lane's step-2 B fragments); start the next tile-unit's loads
         if (t0[tp] + 32 > a.T) {  // wave-uniform: the partial tile (and tiles past the end)
 #pragma unroll
           for (int i = 0; i < NDY; ++i) dyn[i] = t0[tp] + c < a.T ? dyn[i] : 0.f;
@@ -975,7 +998,6 @@ mlp_bwd_x3p_k(const BwdArgs a) {
         else if (u + 1 < U)
           dy_fetch(u + 1, t0[0]);
         if (t0[tp] >= a.T) continue;  // wave-uniform
-        const unsigned char* xp = XP + tp * 3 * kPlaneBytes;
         PSF_TRACE(3 + 8 * tp);
         // the same terms through the scratch planes [tok][o] and back transposed: the step-4 B operand. Issued first: the
         // round trips overlap with the MFMAs of steps 1 and 2.
@@ -999,33 +1021,19 @@ mlp_bwd_x3p_k(const BwdArgs a) {
           asm volatile("" ::: "memory");
         }
 
-        // 1. Hpre^T = A_u X^T + a_u : both operands by row reads
-        f32x16 acc1, acc3;
-        {
-          const float4* sa4 = reinterpret_cast<const float4*>(img + kPOffSa + 64 * half);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 v = sa4[q];
-            acc1[4 * q] = v.x;
-            acc1[4 * q + 1] = v.y;
-            acc1[4 * q + 2] = v.z;
-            acc1[4 * q + 3] = v.w;
-          }
-        }
+        f32x16 acc3;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const Frag3 wa{row_frag(img, L, s), row_frag(img + kPlaneBytes, L, s), row_frag(img + 2 * kPlaneBytes, L, s)};
-          const Frag3 xb{row_frag(xp, L, s), row_frag(xp + kPlaneBytes, L, s), row_frag(xp + 2 * kPlaneBytes, L, s)};
-          acc1 = mfma6(wa, xb, acc1);
-        }
         // 2. dHpost^T = B_u^T dY^T : B operand = the lane's own dY fragment
 #pragma unroll
         for (int s = 0; s < NS2; ++s)
           acc3 = mfma6(load_frag3(img + kPOffBT + ((s * 2 + half) * 32 + c) * 16, kXFragTerm), dy3[s], acc3);
         // 3. GELU and its derivative
         PSF_TRACE(4 + 8 * tp);
+        // Priority by phase: a wave in its vector phase (GELU, splits) yields to the SIMD's other wave whenever that one is in
+        // a matrix phase, whose instructions need one issue slot in eight; raised again in front of the matrix steps below.
+        // With step 1 ahead of the dY wait: 3 % (profiles/r03ah_x3p_experiments.log).
+        __builtin_amdgcn_s_setprio(0);
         float y[16], g[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1046,6 +1054,7 @@ mlp_bwd_x3p_k(const BwdArgs a) {
         store_acc_plane(YP, L, ys, 1);
         asm volatile("" ::: "memory");
         const Split16 gs = split16(g);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) ha[s].t1 = tr_frag(HP, L, s), ha[s].t2 = tr_frag(YP, L, s);
         asm volatile("" ::: "memory");
@@ -1145,6 +1154,524 @@ mlp_bwd_x3p_k(const BwdArgs a) {
             if (e0 < E)
               *reinterpret_cast<float4*>(a.dX + tok * E + e0) =
                   make_float4(dxa[tp][4 * gq], dxa[tp][4 * gq + 1], dxa[tp][4 * gq + 2], dxa[tp][4 * gq + 3]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the same arithmetic with the SIMD's two waves in different ROLES (knob mlp_bwd_variant = 4)
+// ------------------------------------------------------------------------------------------------------------------
+// In mlp_bwd_x3p_k every wave runs the whole chain of a tile — matrix steps 1-2, the GELU and the splits on the vector ALU,
+// matrix steps 4-6 — and the SIMD's second wave runs the same chain: each wave's phases wait for each other, both waves
+// meet four workgroup barriers per unit, and the matrix pipe and the vector ALU co-execute for an eighth of the time
+// (profiles/r02ad_mlp_bwd_pmc.json). Here waves 0-3 are PRODUCERS (steps 1, 2, the GELU, the splits, step 6: everything
+// that needs the token on the lane) and waves 4-7 CONSUMERS (the two contractions over tokens, steps 4 and 5, da and db:
+// matrix instructions on transposed LDS reads only, and all weight-gradient sums); wave w and w + 4 share SIMD w
+// (MI355X_MICROARCH.md: a workgroup's waves go to the SIMDs cyclically) and form a PAIR that owns TPW tiles of the block.
+//   * The producer hands each tile-unit over as three pieces through single LDS slots of the pair: the dY terms (D slot),
+//     the Hpost^T terms and the G terms (S slot, one after the other). Hand-over is by sequence counters in LDS that the
+//     partner polls (s_sleep between polls): no workgroup barrier anywhere after the start of the kernel. LDS operations
+//     of one wave execute in order, so "data, then counter" needs no wait on either side.
+//   * The consumers own dA, dB^T, da, db of the unit: the cross-wave combine is among four waves, through the pair's slots
+//     (free at that point), while the producers are already in the next unit's first tile; its arrival and done counters are
+//     LDS atomics.
+//   * The consumers also stage the unit images (LDS-DMA); a producer starts unit g when all four quarters of image g have
+//     landed, a consumer overwrites a buffer when all four producers are done with the unit that used it.
+//   * db = 1^T dY comes off the matrix pipe like da = G 1 (a fragment of ones as the A operand), so the producer has no
+//     per-lane sums and no DPP reduction.
+// All sums keep a fixed order: bit-reproducible. Every wave passes every counter of every (block, unit, tile) exactly once —
+// tiles past the end of the input run as zero tiles — so no wave can wait for a partner that has left.
+constexpr int kPsPairs = 4;
+enum PsFlag : int { kFDReady = 0, kFDFree = 4, kFSReady = 8, kFSFree = 12, kFImgReady = 16, kFUnitDone = 20, kFCombArrive = 24, kFCombDone = 25, kFCount = 32 };
+
+// The counters are addressed as LDS (address space 3): through a generic pointer a volatile access is a FLAT load with
+// s_waitcnt vmcnt(0), which drains the dY prefetch on every poll (first build: 1.2 ms).
+using ps_flag_t = volatile __attribute__((address_space(3))) uint32_t;
+#ifdef PSF_PS_GUARD  // lab builds: a wait that never ends gives up, marks the launch and lets every later wait fall through
+__device__ unsigned int psf_ps_stuck;
+__device__ __forceinline__ void ps_wait_ge(const ps_flag_t* f, uint32_t target) {
+  asm volatile("" ::: "memory");
+  int spins = 0;
+  while ((int32_t)(__builtin_amdgcn_readfirstlane(*f) - target) < 0) {
+    __builtin_amdgcn_s_sleep(1);
+    if (*(volatile unsigned int*)&psf_ps_stuck != 0u) break;
+    if (++spins > (1 << 18)) {
+      psf_ps_stuck = 1u + ((unsigned int)(uintptr_t)f >> 2) % 64u;
+      break;
+    }
+  }
+  asm volatile("" ::: "memory");
+}
+#else
+__device__ __forceinline__ void ps_wait_ge(const ps_flag_t* f, uint32_t target) {
+  asm volatile("" ::: "memory");
+  while ((int32_t)(__builtin_amdgcn_readfirstlane(*f) - target) < 0) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+#endif
+__device__ __forceinline__ void ps_wait4_ge(const ps_flag_t* f, uint32_t target) {
+#pragma unroll
+  for (int i = 0; i < kPsPairs; ++i) ps_wait_ge(f + i, target);
+}
+__device__ __forceinline__ void ps_signal(ps_flag_t* f, uint32_t value) {
+  asm volatile("" ::: "memory");
+  *f = value;
+  asm volatile("" ::: "memory");
+}
+
+// Keeps a computation in the basic block it is written in: hipcc sinks pure arithmetic into the block of its first use,
+// which for values handed over after a poll loop is the far side of the loop — out of the matrix instructions' shadow.
+__device__ __forceinline__ void ps_pin(psf_x3::Split16& x) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+    asm volatile("" : "+v"(x.d[t][0]), "+v"(x.d[t][1]), "+v"(x.d[t][2]), "+v"(x.d[t][3]), "+v"(x.d[t][4]), "+v"(x.d[t][5]),
+                      "+v"(x.d[t][6]), "+v"(x.d[t][7]));
+}
+__device__ __forceinline__ void ps_pin(float (&x)[16]) {
+#pragma unroll
+  for (int t = 0; t < 16; t += 8)
+    asm volatile("" : "+v"(x[t]), "+v"(x[t + 1]), "+v"(x[t + 2]), "+v"(x[t + 3]), "+v"(x[t + 4]), "+v"(x[t + 5]), "+v"(x[t + 6]),
+                      "+v"(x[t + 7]));
+}
+
+template <int TPW, int NDY>
+__global__ void __launch_bounds__(512, 1)
+mlp_bwd_ps_k(const BwdArgs a) {
+  using namespace psf_x3;
+  constexpr int NS2 = NDY / 8;
+  constexpr int kDyPlane = NDY == 8 ? 1024 : kPlaneBytes;  // [32 tok][16 o] in 32-byte rows, or a full swizzled plane
+  constexpr int kXBytes = TPW * 3 * kPlaneBytes;
+  constexpr int kPairBytes = kXBytes + 3 * kPlaneBytes + 3 * kDyPlane;
+  static_assert(3 * kPlaneBytes + 3 * kDyPlane >= (2048 + 64) * 4, "the pair's slots hold a consumer's sums for the combine");
+  static_assert(2 * kPImgBytes + kPsPairs * kPairBytes + kFCount * 4 <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char img_lds[2 * kPImgBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char pair_lds[kPsPairs * kPairBytes];
+  __shared__ uint32_t flag_lds[kFCount];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, half = lane >> 5;
+  const int pr = wv & 3;
+  const bool producer = wv < 4;
+  unsigned char* XP = pair_lds + pr * kPairBytes;  // the pair's X planes [tile][term]
+  unsigned char* SP = XP + kXBytes;                // S slot: three planes [tok][j], Hpost^T terms or G terms
+  unsigned char* DP = SP + 3 * kPlaneBytes;        // D slot: three dY planes [tok][o]
+  ps_flag_t* F = (ps_flag_t*)flag_lds;
+  const PlaneLane L = plane_lane(lane);
+  const int E = a.E, U = a.U;
+  const int64_t tiles = (a.T + 31) / 32;
+  const int64_t tiles_per_block = kPsPairs * TPW;
+  const unsigned char* images = reinterpret_cast<const unsigned char*>(a.images);
+  if (tid < kFCount) flag_lds[tid] = 0u;
+  __syncthreads();
+
+  uint32_t n = 0;  // tile-units of this pair so far (= pieces of the D slot; the S slot has had 2 n)
+  uint32_t g = 0;  // units of this workgroup so far: image g lives in buffer g & 1
+  for (int64_t blk = blockIdx.x; blk * tiles_per_block < tiles; blk += gridDim.x) {
+    const bool last_block = (blk + gridDim.x) * tiles_per_block >= tiles;
+    const int64_t tile0 = blk * tiles_per_block + pr * TPW;  // the pair's first tile
+    if (producer) {
+      // ---------------------------------------------------------------------------------------------- producer
+      // Software pipeline over the pair's U x TPW tile-units (i = u TPW + tp): while the vector ALU runs the GELU and the
+      // splits of tile-unit i, the matrix pipe runs steps 1 and 2 of tile-unit i + 1. A dependent MFMA blocks the wave's
+      // in-order issue until its predecessor retires, so the two only overlap when they alternate in the instruction
+      // stream (sched_group_barrier below).
+      const int NI = U * TPW;
+      float dyn[NDY];
+      // The lane's token, outputs 16 s + 8 half + (0..7). Loads only, no use of the values here (see mlp_bwd_x3p_k): rows past
+      // T and outputs past O read an in-bounds neighbour instead. The unit's dY pointer and width are fetched from the
+      // kernel arguments one step ahead (dy_unit): two dependent scalar loads in front of the address arithmetic cost a
+      // tile-unit ~400 clocks.
+      const float* dy_base = nullptr;
+      int dy_w = 0;
+      auto dy_unit = [&](int u2) {
+        const BwdMlp& d2 = a.m[a.unit[u2] & 0xff];
+        dy_base = d2.dY;
+        dy_w = d2.O;
+      };
+      auto dy_fetch = [&](int tp2) {
+        const int W = dy_w;
+        const int64_t tok = (tile0 + tp2) * 32 + c;
+        const float* src = dy_base + (tok < a.T ? tok : 0) * W;
+#pragma unroll
+        for (int s = 0; s < NS2; ++s)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int o = 16 * s + 8 * half + i;
+            dyn[8 * s + i] = src[o < W ? o : 0];
+          }
+      };
+      auto dy_split = [&](int i2, Frag3 (&out)[NS2]) {  // consumes dyn
+        const int tp2 = i2 % TPW;
+        const int64_t t02 = (tile0 + tp2) * 32;
+        if (t02 + 32 > a.T) {  // wave-uniform: the partial tile and tiles past the end
+#pragma unroll
+          for (int i = 0; i < NDY; ++i) dyn[i] = t02 + c < a.T ? dyn[i] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < NS2; ++s) {
+          const float v[8] = {dyn[8 * s], dyn[8 * s + 1], dyn[8 * s + 2], dyn[8 * s + 3],
+                              dyn[8 * s + 4], dyn[8 * s + 5], dyn[8 * s + 6], dyn[8 * s + 7]};
+          out[s] = split_pack8(v);
+        }
+#pragma unroll
+        for (int s = 0; s < NS2; ++s) asm volatile("" : "+v"(out[s].t1), "+v"(out[s].t2), "+v"(out[s].t3) : : "memory");
+      };
+      auto bias_acc = [&](const unsigned char* img) {
+        f32x16 acc;
+        const float4* sa4 = reinterpret_cast<const float4*>(img + kPOffSa + 64 * half);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = sa4[q];
+          acc[4 * q] = v.x;
+          acc[4 * q + 1] = v.y;
+          acc[4 * q + 2] = v.z;
+          acc[4 * q + 3] = v.w;
+        }
+        return acc;
+      };
+      dy_unit(0);
+      dy_fetch(0);
+      ps_wait_ge(F + kFSFree + pr, 2u * n);  // the consumer has read the previous block's X planes for the last time
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) {
+        const int64_t tok = (tile0 + tp) * 32 + c;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int e0 = 16 * s + 8 * half;
+          float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+          if (tok < a.T && e0 < E) lo = *reinterpret_cast<const float4*>(a.X + tok * E + e0);
+          if (tok < a.T && e0 + 4 < E) hi = *reinterpret_cast<const float4*>(a.X + tok * E + e0 + 4);
+          const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          const Frag3 f = split_pack8(v);
+          unsigned char* xp = XP + tp * 3 * kPlaneBytes + L.row[s];
+          *reinterpret_cast<bf16x8*>(xp) = f.t1;
+          *reinterpret_cast<bf16x8*>(xp + kPlaneBytes) = f.t2;
+          *reinterpret_cast<bf16x8*>(xp + 2 * kPlaneBytes) = f.t3;
+        }
+      }
+      // prologue: steps 1 and 2 of tile-unit 0
+      f32x16 acc1, acc3;
+      Frag3 dy3[NS2];
+      ps_wait4_ge(F + kFImgReady, g + 1u);  // all four quarters of image g have landed
+      {
+        const unsigned char* img = img_lds + (g & 1u) * kPImgBytes;
+        acc1 = bias_acc(img);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const Frag3 wa{row_frag(img, L, s), row_frag(img + kPlaneBytes, L, s), row_frag(img + 2 * kPlaneBytes, L, s)};
+          const Frag3 xb{row_frag(XP, L, s), row_frag(XP + kPlaneBytes, L, s), row_frag(XP + 2 * kPlaneBytes, L, s)};
+          acc1 = mfma6(wa, xb, acc1);
+        }
+        dy_split(0, dy3);
+        if (TPW == 1 && U > 1) dy_unit(1);
+        dy_fetch(TPW > 1 ? 1 : 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS2; ++s)
+          acc3 = mfma6(load_frag3(img + kPOffBT + ((s * 2 + half) * 32 + c) * 16, kXFragTerm), dy3[s], acc3);
+        if (TPW == 1) ps_signal(F + kFUnitDone + pr, g + 1u);
+      }
+      int un = 0, tpn = 0;  // unit and tile of tile-unit i + 1 (clamped to the last one)
+      int u2 = TPW > 1 ? 0 : (U > 1 ? 1 : 0), tp2 = TPW > 1 ? 1 : 0;  // ... of tile-unit i + 2, whose dY is fetched in step i
+      for (int i = 0; i < NI; ++i, ++n) {
+#ifdef PSF_X3P_TRACE
+        const bool trace_on = blockIdx.x == 300 && i / TPW == 5 && i % TPW < 2;
+        const int tslot = 8 * (i % TPW);
+#endif
+        PSF_TRACE(tslot + 0);
+        if (i + 2 < NI) {
+          if (++tp2 == TPW) {
+            tp2 = 0;
+            dy_unit(++u2);  // scalar loads now, used in A2
+          }
+        }
+        const bool next = i + 1 < NI;
+        if (next) {
+          if (++tpn == TPW) tpn = 0, ++un;
+          if (tpn == 0) ps_wait4_ge(F + kFImgReady, g + (uint32_t)un + 1u);  // the next unit's image has landed
+        }
+        const unsigned char* imgn = img_lds + ((g + (uint32_t)un) & 1u) * kPImgBytes;
+        const unsigned char* xpn = XP + tpn * 3 * kPlaneBytes;
+        PSF_TRACE(tslot + 1);
+        // A1: GELU and its derivative of tile-unit i, split of Hpost^T  ||  step 1 of tile-unit i + 1
+        f32x16 acc1n = bias_acc(imgn);
+        Frag3 wa[2], xb[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          wa[s] = Frag3{row_frag(imgn, L, s), row_frag(imgn + kPlaneBytes, L, s), row_frag(imgn + 2 * kPlaneBytes, L, s)};
+          xb[s] = Frag3{row_frag(xpn, L, s), row_frag(xpn + kPlaneBytes, L, s), row_frag(xpn + 2 * kPlaneBytes, L, s)};
+        }
+        // Source order IS the issue order here (sched_barrier after every step): the GELU of one pair of values (or the
+        // split of two pairs), then one matrix instruction, which runs while the next step's vector work issues.
+        // The two counters the hand-over needs are read NOW and looked at after the block: a poll costs an LDS round trip
+        // even when the partner is long done.
+        const uint32_t d_free_early = F[kFDFree + pr], s_free_early = F[kFSFree + pr];
+        float y[16], gg[16];
+        Split16 ys;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+          if (m < 8) {
+            float d0, d1;
+            gelu_and_grad1(acc1[2 * m], y[2 * m], d0);
+            gelu_and_grad1(acc1[2 * m + 1], y[2 * m + 1], d1);
+            gg[2 * m] = acc3[2 * m] * d0;  // G = dHpre^T
+            gg[2 * m + 1] = acc3[2 * m + 1] * d1;
+          } else {
+            split16_pair(y[4 * (m - 8)], y[4 * (m - 8) + 1], ys, 2 * (m - 8));
+            split16_pair(y[4 * (m - 8) + 2], y[4 * (m - 8) + 3], ys, 2 * (m - 8) + 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (m < 6) acc1n = mfma6_term(wa[0], xb[0], acc1n, m);
+          else acc1n = mfma6_term(wa[1], xb[1], acc1n, m - 6);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        ps_pin(ys);
+        ps_pin(gg);
+        asm volatile("" : "+v"(acc1n));
+        PSF_TRACE(tslot + 2);
+        // hand-over 1: the dY terms of tile-unit i (split one iteration ago)
+        if ((int32_t)(__builtin_amdgcn_readfirstlane(d_free_early) - n) < 0) ps_wait_ge(F + kFDFree + pr, n);
+        if (NDY == 8) {
+          unsigned char* dp = DP + 32 * c + 16 * half;
+          *reinterpret_cast<bf16x8*>(dp) = dy3[0].t1;
+          *reinterpret_cast<bf16x8*>(dp + kDyPlane) = dy3[0].t2;
+          *reinterpret_cast<bf16x8*>(dp + 2 * kDyPlane) = dy3[0].t3;
+        } else {
+#pragma unroll
+          for (int s = 0; s < NS2; ++s) {
+            *reinterpret_cast<bf16x8*>(DP + L.row[s]) = dy3[s].t1;
+            *reinterpret_cast<bf16x8*>(DP + kDyPlane + L.row[s]) = dy3[s].t2;
+            *reinterpret_cast<bf16x8*>(DP + 2 * kDyPlane + L.row[s]) = dy3[s].t3;
+          }
+        }
+        ps_signal(F + kFDReady + pr, n + 1u);
+        PSF_TRACE(tslot + 3);
+        // hand-over 2: Hpost^T
+        if ((int32_t)(__builtin_amdgcn_readfirstlane(s_free_early) - 2u * n) < 0) ps_wait_ge(F + kFSFree + pr, 2u * n);
+        store_acc_plane(SP, L, ys, 0);
+        store_acc_plane(SP + kPlaneBytes, L, ys, 1);
+        store_acc_plane(SP + 2 * kPlaneBytes, L, ys, 2);
+        ps_signal(F + kFSReady + pr, 2u * n + 1u);
+        PSF_TRACE(tslot + 4);
+        // A2: split of the next tile-unit's dY and of G  ||  step 2 of tile-unit i + 1
+        const uint32_t s_free_early2 = F[kFSFree + pr];
+        Frag3 bt[NS2];
+#pragma unroll
+        for (int s = 0; s < NS2; ++s) bt[s] = load_frag3(imgn + kPOffBT + ((s * 2 + half) * 32 + c) * 16, kXFragTerm);
+        if (i % TPW == 1) PSF_TRACE(16);
+        dy_split(i + 1 < NI ? i + 1 : NI - 1, dy3);
+        if (i % TPW == 1) PSF_TRACE(17);
+        dy_fetch(tp2);
+        if (i % TPW == 1) PSF_TRACE(18);
+        f32x16 acc3n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3n[r] = 0.f;
+        Split16 gs;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {  // one matrix instruction of step 2, then one pair of G split
+          if (m < 6 * NS2 && m < 6) acc3n = mfma6_term(bt[0], dy3[0], acc3n, m);
+          else if (NS2 == 2 && m < 8) acc3n = mfma6_term(bt[NS2 - 1], dy3[NS2 - 1], acc3n, m - 6);
+          __builtin_amdgcn_sched_barrier(0);
+          split16_pair(gg[2 * m], gg[2 * m + 1], gs, m);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (NS2 == 2) {
+#pragma unroll
+          for (int k = 2; k < 6; ++k) acc3n = mfma6_term(bt[NS2 - 1], dy3[NS2 - 1], acc3n, k);
+        }
+        ps_pin(gs);
+        asm volatile("" : "+v"(acc3n));
+        PSF_TRACE(tslot + 5);
+        if (next && tpn == TPW - 1) ps_signal(F + kFUnitDone + pr, g + (uint32_t)un + 1u);  // image reads of that unit: all issued
+        // hand-over 3: G
+        if ((int32_t)(__builtin_amdgcn_readfirstlane(s_free_early2) - (2u * n + 1u)) < 0) ps_wait_ge(F + kFSFree + pr, 2u * n + 1u);
+        PSF_TRACE(tslot + 6);
+        store_acc_plane(SP, L, gs, 0);
+        store_acc_plane(SP + kPlaneBytes, L, gs, 1);
+        store_acc_plane(SP + 2 * kPlaneBytes, L, gs, 2);
+        ps_signal(F + kFSReady + pr, 2u * n + 2u);
+        acc1 = acc1n;
+        acc3 = acc3n;
+      }
+      g += (uint32_t)U;
+    } else {
+      // ---------------------------------------------------------------------------------------------- consumer
+      // quarter pr of image `unit` -> buffer `buf` by LDS-DMA (inline assembly: see mlp_bwd_x3p_k)
+      auto stage = [&](int unit, uint32_t buf) {
+        const unsigned char* src = images + (size_t)unit * kXImgBytes;
+        unsigned char* dst = img_lds + buf * kPImgBytes;
+        for (int v0 = 0; v0 < kPImgVecs; v0 += 64 * kPsPairs) {
+          const int v = v0 + 64 * pr + lane;
+          const uint32_t lds_at = __builtin_amdgcn_readfirstlane(
+              (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)(dst + 16 * (v0 + 64 * pr))));
+          uint32_t m0_saved;
+          if (v < kPImgVecs)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_saved) : "s"(lds_at), "v"(src + 16 * v) : "memory");
+        }
+      };
+      float* part = a.partials + (blk * (int64_t)U) * kPart;
+      float* SCR = reinterpret_cast<float*>(SP);  // the pair's two slots as one f32 area for the combine
+      const float* SCR0 = reinterpret_cast<const float*>(pair_lds + kXBytes);
+      const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+      int dtr[2];  // transposed read of a 32-byte-row dY plane: rows 8 half + 4 t + q, columns 4 p .. 4 p + 3 (NDY == 8)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) dtr[t] = 32 * (8 * half + 4 * t + ((lane >> 2) & 3)) + 8 * (lane & 3);
+      f32x16 dxa[TPW];
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dxa[tp][r] = 0.f;
+      for (int u = 0; u < U; ++u, ++g) {
+#ifdef PSF_X3P_TRACE
+        const bool trace_on = blockIdx.x == 300 && u == 5;
+#endif
+        PSF_TRACE(30);
+        if (g == 0) {
+          stage(0, 0u);
+          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+          ps_signal(F + kFImgReady + pr, 1u);
+        }
+        const bool has_next = u + 1 < U || !last_block;
+        if (has_next) {
+          ps_wait4_ge(F + kFUnitDone, g);  // every producer is done with unit g - 1, whose image buffer this one takes
+          stage(u + 1 < U ? u + 1 : 0, (g + 1u) & 1u);
+        }
+        const unsigned char* img = img_lds + (g & 1u) * kPImgBytes;
+        const bool first_block_of_mlp = (a.unit[u] >> 8) == 0;
+        f32x16 dA, dBT, dav, dbv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dA[r] = dBT[r] = dav[r] = dbv[r] = 0.f;
+#pragma unroll
+        for (int tp = 0; tp < TPW; ++tp, ++n) {
+          const unsigned char* xp = XP + tp * 3 * kPlaneBytes;
+          Frag3 yb[2], ha[2], ga[2], gb[2];
+          if (tp < 2) PSF_TRACE(8 * tp + 0);
+          ps_wait_ge(F + kFDReady + pr, n + 1u);
+          if (tp < 2) PSF_TRACE(8 * tp + 1);
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            if (NDY == 8) {
+              yb[s].t1 = join8(tr_read(DP + dtr[0] + 512 * s), tr_read(DP + dtr[1] + 512 * s));
+              yb[s].t2 = join8(tr_read(DP + kDyPlane + dtr[0] + 512 * s), tr_read(DP + kDyPlane + dtr[1] + 512 * s));
+              yb[s].t3 = join8(tr_read(DP + 2 * kDyPlane + dtr[0] + 512 * s), tr_read(DP + 2 * kDyPlane + dtr[1] + 512 * s));
+            } else {
+              yb[s].t1 = tr_frag(DP, L, s), yb[s].t2 = tr_frag(DP + kDyPlane, L, s), yb[s].t3 = tr_frag(DP + 2 * kDyPlane, L, s);
+            }
+          }
+          if (tp + 1 < TPW) ps_signal(F + kFDFree + pr, n + 1u);  // (a unit's last tile: after the combine)
+          ps_wait_ge(F + kFSReady + pr, 2u * n + 1u);
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            ha[s].t1 = tr_frag(SP, L, s), ha[s].t2 = tr_frag(SP + kPlaneBytes, L, s), ha[s].t3 = tr_frag(SP + 2 * kPlaneBytes, L, s);
+          ps_signal(F + kFSFree + pr, 2u * n + 1u);
+          if (tp < 2) PSF_TRACE(8 * tp + 2);
+          // 4. dB^T[j][o] += Hpost^T[j][tok] dY[tok][o];  db[o] += 1 dY[tok][o]
+#pragma unroll
+          for (int s = 0; s < 2; ++s) dBT = mfma6(ha[s], yb[s], dBT);
+          if (first_block_of_mlp) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              dbv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, yb[s].t3, dbv, 0, 0, 0);
+              dbv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, yb[s].t2, dbv, 0, 0, 0);
+              dbv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, yb[s].t1, dbv, 0, 0, 0);
+            }
+          }
+          if (tp == 0 && has_next) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's quarter of image g + 1 has landed
+            ps_signal(F + kFImgReady + pr, g + 2u);
+          }
+          if (tp < 2) PSF_TRACE(8 * tp + 3);
+          ps_wait_ge(F + kFSReady + pr, 2u * n + 2u);
+          if (tp < 2) PSF_TRACE(8 * tp + 4);
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            ga[s].t1 = tr_frag(SP, L, s), ga[s].t2 = tr_frag(SP + kPlaneBytes, L, s), ga[s].t3 = tr_frag(SP + 2 * kPlaneBytes, L, s);
+            gb[s].t1 = row_frag(SP, L, s), gb[s].t2 = row_frag(SP + kPlaneBytes, L, s), gb[s].t3 = row_frag(SP + 2 * kPlaneBytes, L, s);
+          }
+          if (tp + 1 < TPW) ps_signal(F + kFSFree + pr, 2u * n + 2u);
+          // 5. dA[j][e] += G[j][tok] X[tok][e],  da[j] += G[j][tok] 1
+          // 6. dX^T[e][tok] += A_u^T[e][j] G[j][tok]   (A^T by transposed reads of the image, G by row reads of its planes)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const Frag3 xb{tr_frag(xp, L, s), tr_frag(xp + kPlaneBytes, L, s), tr_frag(xp + 2 * kPlaneBytes, L, s)};
+            dA = mfma6(ga[s], xb, dA);
+            dav = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[s].t3, ones, dav, 0, 0, 0);
+            dav = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[s].t2, ones, dav, 0, 0, 0);
+            dav = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[s].t1, ones, dav, 0, 0, 0);
+            if (a.dX) {
+              const Frag3 at{tr_frag(img, L, s), tr_frag(img + kPlaneBytes, L, s), tr_frag(img + 2 * kPlaneBytes, L, s)};
+              dxa[tp] = mfma6(at, gb[s], dxa[tp]);
+            }
+          }
+        }
+        // combine among the four consumers (fixed order 0..3) through the pairs' slots, one partial slot per workgroup
+        PSF_TRACE(16);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) SCR[cd_row(r, half) * 32 + c] = dA[r];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) SCR[1024 + cd_row(r, half) * 32 + c] = dBT[r];
+        if (c == 0) {  // every column of dav is da
+#pragma unroll
+          for (int r = 0; r < 16; ++r) SCR[2048 + cd_row(r, half)] = dav[r];
+        }
+        if (half == 0) SCR[2080 + c] = dbv[0];  // every row of dbv is db
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t*)flag_lds + kFCombArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        PSF_TRACE(17);
+        ps_wait_ge(F + kFCombArrive, 4u * (g + 1u));
+        PSF_TRACE(18);
+        float* pu = part + (int64_t)u * kPart;
+        auto sum4 = [&](int off) {  // off: float offset into a consumer's area, 16-byte aligned
+          float4 acc = *reinterpret_cast<const float4*>(SCR0 + off);
+#pragma unroll
+          for (int w = 1; w < kPsPairs; ++w) {
+            const float4 v = *reinterpret_cast<const float4*>(SCR0 + w * (kPairBytes / 4) + off);
+            acc.x += v.x;
+            acc.y += v.y;
+            acc.z += v.z;
+            acc.w += v.w;
+          }
+          return acc;
+        };
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int at = 512 * pr + 256 * i + 4 * lane;
+          *reinterpret_cast<float4*>(pu + at) = sum4(at);
+        }
+        if (lane < 8) {  // da [2][32] | db [2][32]: the whole sums in row 0
+          const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (pr == 0) *reinterpret_cast<float4*>(pu + 2048 + 4 * lane) = sum4(2048 + 4 * lane);
+          else if (pr == 1) *reinterpret_cast<float4*>(pu + 2112 + 4 * lane) = sum4(2080 + 4 * lane);
+          else if (pr == 2) *reinterpret_cast<float4*>(pu + 2080 + 4 * lane) = zero;
+          else *reinterpret_cast<float4*>(pu + 2144 + 4 * lane) = zero;
+        }
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t*)flag_lds + kFCombDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        PSF_TRACE(19);
+        ps_wait_ge(F + kFCombDone, 4u * (g + 1u));
+        PSF_TRACE(20);
+        ps_signal(F + kFDFree + pr, n);        // the slots go back to the producer
+        ps_signal(F + kFSFree + pr, 2u * n);
+      }
+      if (a.dX) {  // the lane holds dX^T[e = 8 gq + 4 half + (0..3)][tok = c] in registers 4 gq .. 4 gq + 3
+#pragma unroll
+        for (int tp = 0; tp < TPW; ++tp) {
+          const int64_t tok = (tile0 + tp) * 32 + c;
+          if (tok < a.T) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              const int e0 = 8 * gq + 4 * half;
+              if (e0 < E)
+                *reinterpret_cast<float4*>(a.dX + tok * E + e0) =
+                    make_float4(dxa[tp][4 * gq], dxa[tp][4 * gq + 1], dxa[tp][4 * gq + 2], dxa[tp][4 * gq + 3]);
+            }
           }
         }
       }
@@ -1294,7 +1821,11 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   }
   const int variant = psf_g_mlp_bwd_variant.load();
   const bool x3 = variant == 2;                      // the first split-bf16 form (steps 1, 2, 6 on bf16)
-  const bool planes = variant == 0 || variant == 3;  // split-bf16 on dual-use LDS planes (the default)
+  int max_o = 1;
+  for (int k = 0; k < K; ++k) max_o = O[k] > max_o ? O[k] : max_o;
+  const bool roles = variant == 4;                   // producer / consumer waves (mlp_bwd_ps_k)
+  const bool planes = variant == 0 || variant == 3 || roles;  // split-bf16 on dual-use LDS planes (the default)
+  const int ps_tiles = kPsPairs * (max_o <= 16 ? 4 : 3);      // tiles per workgroup of mlp_bwd_ps_k
   if (planes && dX && (reinterpret_cast<uintptr_t>(dX) & 15) != 0)
     return psf_internal_fail(PSF_E_ALIGN, "psf_mlp_bwd: dX must be 16-byte aligned");
   float* ws = reinterpret_cast<float*>(workspace);
@@ -1304,7 +1835,7 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   args.partials = ws + (int64_t)p.U * kImgFloatsMax;
   args.stage1 = args.partials + (p.G > p.G8 ? p.G : p.G8) * p.U * kPart;
   args.T = T;
-  args.G = (x3 || planes) ? p.G8 : p.G;
+  args.G = roles ? ((T + 31) / 32 + ps_tiles - 1) / ps_tiles : (x3 || planes) ? p.G8 : p.G;
   args.E = E;
   args.K = K;
   args.U = p.U;
@@ -1318,8 +1849,6 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   // every slot of the partial buffer is written exactly once: one workgroup per waves*TPW tiles
   const int64_t blocks = args.G;
   if (blocks > 0x7fffffff) return psf_internal_fail(PSF_E_SHAPE, "psf_mlp_bwd: T too large");
-  int max_o = 1;
-  for (int k = 0; k < K; ++k) max_o = O[k] > max_o ? O[k] : max_o;
   auto launch = [&](auto kernel, int waves, size_t img_bytes, int tpw, int sd, int img_bufs) {
     const size_t lds_bytes = (size_t)img_bufs * img_bytes + sizeof(float) * (size_t)waves * (tpw * 32 * 33 + 32 * sd + 32 * 33);
     e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1328,7 +1857,10 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   auto launch_planes = [&](auto kernel, int waves) {  // static LDS: 2 images + 8 x (tpw x 3 planes + scratch) = 160,000 B at tpw = 2
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * waves), 0, s, args);
   };
-  if (planes) {
+  if (roles) {
+    if (max_o <= 16) launch_planes(mlp_bwd_ps_k<4, 8>, 8);
+    else launch_planes(mlp_bwd_ps_k<3, 16>, 8);
+  } else if (planes) {
     if (max_o <= 16) {
       if (p.tpw8 == 2) launch_planes(mlp_bwd_x3p_k<2, 8>, 8);
       else launch_planes(mlp_bwd_x3p_k<1, 8>, 8);

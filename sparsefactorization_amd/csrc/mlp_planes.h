@@ -85,19 +85,22 @@ struct Split16 {
   uint32_t d[3][8];
 };
 
+// registers 2 m and 2 m + 1 of the tile -> dword m of the three terms
+__device__ __forceinline__ void split16_pair(float v0, float v1, Split16& r, int m) {
+  const uint32_t a0 = __float_as_uint(v0) & 0xffff0000u, a1 = __float_as_uint(v1) & 0xffff0000u;
+  // scalar subtractions: packed f32 VALU is slow beside the sibling wave's MFMAs (see gelu_and_grad1 in mlp_bwd.hip)
+  const float r1x = v0 - __uint_as_float(a0), r1y = v1 - __uint_as_float(a1);
+  const uint32_t b0 = __float_as_uint(r1x) & 0xffff0000u, b1 = __float_as_uint(r1y) & 0xffff0000u;
+  const f32x2 r2 = {r1x - __uint_as_float(b0), r1y - __uint_as_float(b1)};
+  r.d[0][m] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+  r.d[1][m] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+  r.d[2][m] = __builtin_amdgcn_perm(__float_as_uint(r2.y), __float_as_uint(r2.x), 0x07060302u);
+}
+
 __device__ __forceinline__ Split16 split16(const float (&v)[16]) {
   Split16 r;
 #pragma unroll
-  for (int i = 0; i < 16; i += 2) {
-    const uint32_t a0 = __float_as_uint(v[i]) & 0xffff0000u, a1 = __float_as_uint(v[i + 1]) & 0xffff0000u;
-    // scalar subtractions: packed f32 VALU is slow beside the sibling wave's MFMAs (see gelu_and_grad1 in mlp_bwd.hip)
-    const float r1x = v[i] - __uint_as_float(a0), r1y = v[i + 1] - __uint_as_float(a1);
-    const uint32_t b0 = __float_as_uint(r1x) & 0xffff0000u, b1 = __float_as_uint(r1y) & 0xffff0000u;
-    const f32x2 r2 = {r1x - __uint_as_float(b0), r1y - __uint_as_float(b1)};
-    r.d[0][i >> 1] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
-    r.d[1][i >> 1] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
-    r.d[2][i >> 1] = __builtin_amdgcn_perm(__float_as_uint(r2.y), __float_as_uint(r2.x), 0x07060302u);
-  }
+  for (int i = 0; i < 16; i += 2) split16_pair(v[i], v[i + 1], r, i >> 1);
   return r;
 }
 

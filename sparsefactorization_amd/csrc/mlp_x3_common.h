@@ -86,6 +86,13 @@ __device__ __forceinline__ f32x16 mfma6(const Frag3& w, const Frag3& x, f32x16 a
   return acc;
 }
 
+// term k (0..5) of mfma6, for callers that place the six instructions one by one
+__device__ __forceinline__ f32x16 mfma6_term(const Frag3& w, const Frag3& x, f32x16 acc, int k) {
+  const bf16x8& a = (k == 0 || k == 3 || k == 5) ? w.t1 : (k == 1 || k == 4) ? w.t2 : w.t3;
+  const bf16x8& b = k == 0 ? x.t3 : (k == 1 || k == 3) ? x.t2 : x.t1;
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+
 __device__ __forceinline__ uint16_t bf16_bits(uint32_t f32_pattern) { return (uint16_t)(f32_pattern >> 16); }
 
 }  // namespace psf_x3

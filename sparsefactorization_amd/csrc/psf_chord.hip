@@ -94,7 +94,7 @@ Knob g_knobs[] = {
     {"chain_fused", &g_chain_fused, 0, 2},
     {"chain_cc", &g_chain_cc, 0, 1},
     {"mlp_variant", &psf_g_mlp_variant, 0, 3},
-    {"mlp_bwd_variant", &psf_g_mlp_bwd_variant, 0, 3},
+    {"mlp_bwd_variant", &psf_g_mlp_bwd_variant, 0, 4},
     {"wide_fuse", &psf_g_wide_fuse, 0, 1},
     {"mlp_fwd_store", &psf_g_mlp_fwd_store, 0, 1},
 };

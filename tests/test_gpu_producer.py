@@ -183,10 +183,10 @@ MLP_TRAIN_CASES = [  # (T, E, [(h, out), ...])
 ]
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["bwd_auto_bf16x3_planes", "bwd_f32_mfma", "bwd_bf16x3_steps126"])
+@pytest.fixture(params=[0, 1, 2, 4], ids=["bwd_auto_bf16x3_planes", "bwd_f32_mfma", "bwd_bf16x3_steps126", "bwd_bf16x3_roles"])
 def mlp_bwd_variant(request):
     """Every kernel of psf_mlp_bwd_f32 (csrc/mlp_bwd.hip): the exact split-bf16 ones (on dual-use LDS planes = the default; the
-    first form with the token contractions on f32) and the all-f32-MFMA one."""
+    first form with the token contractions on f32; the producer / consumer form) and the all-f32-MFMA one."""
     import sparsefactorization_amd as sfa
     sfa.set_tuning("mlp_bwd_variant", request.param)
     yield request.param
