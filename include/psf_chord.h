@@ -346,6 +346,8 @@ int psf_mlp_wide_bwd_f32(const void* saved, int64_t saved_bytes, int64_t T, int3
  *                      (one wave alone issues vector instructions at half the SIMD's rate) and kept as a record
  *   key "mlp_fwd_store": split-bf16 MLP forward: 1 = finished output tiles are stored straight from the accumulator registers
  *                      (default), 0 = through an LDS transposition as contiguous bursts (the first form; equal bits)
+ *   key "mlp_fwd_tpw": split-bf16 MLP forward, tiles of 32 tokens per wave: 0 = by store form (default: one with the direct
+ *                      stores — three workgroups per CU —, round 2's length rule otherwise), 1, 2 = forced (equal bits)
  *   key "wide_fuse"  : psf_mlp_wide_fwd_f32: 1 = the second layers of the MLPs with <= 32 outputs run inside the first
  *                      layers' GEMM epilogue when every MLP has 97..128 hidden rows (default), 0 = always the separate kernel
  *   key "xcd_remap"  : 1 = keep a batch element's tiles on one XCD group (default), 0 = linear

@@ -32,6 +32,7 @@
 
 #include <atomic>
 extern std::atomic<int> psf_g_mlp_fwd_store;  // psf_chord.hip: tuning knob "mlp_fwd_store"
+extern std::atomic<int> psf_g_mlp_fwd_tpw;    // psf_chord.hip: tuning knob "mlp_fwd_tpw"
 
 namespace {
 
@@ -460,8 +461,17 @@ hipError_t psf_x3_mlp_fwd_launch(const float* X, int64_t T, int32_t E, int32_t K
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int64_t tiles = (T + 31) / 32;
-  int tpw = 2;
-  while (tpw > 1 && (tiles + 4 * tpw - 1) / (4 * tpw) < 512) tpw >>= 1;
+  const int mode = psf_g_mlp_fwd_store.load();
+  // Tiles per wave. With the direct stores (mode 1) the one-tile instance needs 146 registers, so THREE workgroups share a CU
+  // (12 waves) where the two-tile instance (226) has two: 4-6 % less time at every length (profiles/r03ak_mlp_fwd_tpw_ab.log).
+  // The LDS-transposing form keeps round 2's rule (two tiles once there are >= 512 workgroups of them).
+  int tpw = 1;
+  if (mode != 1) {
+    tpw = 2;
+    while (tpw > 1 && (tiles + 4 * tpw - 1) / (4 * tpw) < 512) tpw >>= 1;
+  }
+  const int forced_tpw = psf_g_mlp_fwd_tpw.load();  // knob "mlp_fwd_tpw": 0 = the rule above
+  if (forced_tpw == 1 || forced_tpw == 2) tpw = forced_tpw;
   const int64_t blocks_needed = (tiles + 4 * tpw - 1) / (4 * tpw);
   const int grid = (int)(blocks_needed < 4096 ? blocks_needed : 4096);
   const size_t lds = 2 * (size_t)kImgBytes + 4 * (size_t)tpw * kScr * sizeof(float);
@@ -472,7 +482,6 @@ hipError_t psf_x3_mlp_fwd_launch(const float* X, int64_t T, int32_t E, int32_t K
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, args);
   };
-  const int mode = psf_g_mlp_fwd_store.load();
   if (tpw == 2) mode == 1 ? launch(x3_fwd_k<2, 1>) : launch(x3_fwd_k<2, 0>);
   else mode == 1 ? launch(x3_fwd_k<1, 1>) : launch(x3_fwd_k<1, 0>);
   if (e != hipSuccess) return e;
