@@ -129,9 +129,18 @@ template <int L, int TGS, int NT>
 hipError_t launch_fused(const BwdWinArgs& a) {
   using Cfg = BwdFusedCfg<L, TGS, NT>;
   auto kern = chord_bwd_fused_k<L, TGS, NT>;
+  int lds = Cfg::lds_bytes;
+  if (a.wg_per_cu > 0) {  // occupancy limiter as in the forward launcher (fwd_window_inst.hip)
+    const int floor_bytes = kLdsPerCu / (a.wg_per_cu + 1) + 256;
+    if (floor_bytes > lds && floor_bytes <= 64 * 1024) lds = floor_bytes;
+  }
   static std::atomic<int> done{0};
-  if (hipError_t e = raise_lds_limit(kern, Cfg::lds_bytes, done); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(NT), Cfg::lds_bytes, a.stream, a.dZ, a.WV, a.V2, a.out2, a.out,
+  if (lds > 48 * 1024 && done.load() < lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    done.store(lds);
+  }
+  hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(NT), lds, a.stream, a.dZ, a.WV, a.V2, a.out2, a.out,
                      a.gm, a.offs, a.w_total, a.wfar, a.far_k0);
   return hipGetLastError();
 }

@@ -60,6 +60,7 @@ std::atomic<int> g_chain_cc{0};     // fused chain: 0 = auto channel groups per 
 std::atomic<int> g_fwd_wide{0};
 // Forward window kernel, workgroups per CU: 0 = auto (3 for narrow rows on large launches), 1 = no limit, 2..4 = cap
 std::atomic<int> g_fwd_wg_limit{0};
+std::atomic<int> g_bwd_fused_wg_limit{0};  // fused backward step: 0 = whatever fits (five of 256 threads at C = 8), n = at most n
 // Per-step launches of a chain: 1 = alternate the direction in which each XCD walks its tile range
 std::atomic<int> g_chain_zigzag{1};
 thread_local bool t_walk_backwards = false;  // set by chain_impl around the launches of odd steps
@@ -89,6 +90,7 @@ Knob g_knobs[] = {
     {"dv_threads", &g_dv_threads, 0, 2},
     {"bwd_fused", &g_bwd_fused, 0, 2},
     {"bwd_fused_nt", &g_bwd_fused_nt, 0, 1},
+    {"bwd_fused_wg_limit", &g_bwd_fused_wg_limit, 0, 5},
     {"dw_tgs", &g_dw_tgs, 0, 5},
     {"fwd_wg_limit", &g_fwd_wg_limit, 0, 4},
     {"chain_zigzag", &g_chain_zigzag, 0, 1},
@@ -409,10 +411,12 @@ int fwd_window_f32(const WinPick& pk, const float* W, const float* V, const floa
   a.stream = s;
   // Workgroups per CU. Measured (profiles/r01e_fwd_wg_per_cu.log, us per launch, 4 / 3 per CU): cfg2 (C = 8, 4096
   // tiles) 27.6 / 27.0; the same at B = 40 (2560 tiles) 18.9 / 18.8; C = 32, B = 16: 24.5 / 24.8; N = 4096, C = 16:
-  // 8.9 / 9.2; 2 per CU: 30.0 at cfg2. So: three for narrow rows on launches of >= 4096 tiles, no limit otherwise.
+  // 8.9 / 9.2; 2 per CU: 30.0 at cfg2. Round 3, chains that keep every step's output (training; N = 16384, C = 8, no limit /
+  // three per CU, profiles/r03al_fwd_wg_limit_sweep.log): B = 16 (1024 tiles) 9.4 / 9.7; B = 24 13.5 / 13.2; B = 32 16.5 /
+  // 16.1; B = 40 19.9 / 19.0; B = 48 22.8 / 21.8. So: three for narrow rows on launches of >= 1536 tiles, no limit otherwise.
   const int knob = g_fwd_wg_limit.load();
   const int64_t tiles_total = B * (int64_t)(pk.tiles_full + (pk.ragged ? 1 : 0));
-  a.wg_per_cu = knob == 0 ? ((pk.tgs <= 1 && pk.nt == 256 && tiles_total >= 4096) ? 3 : 0) : (knob == 1 ? 0 : knob);
+  a.wg_per_cu = knob == 0 ? ((pk.tgs <= 1 && pk.nt == 256 && tiles_total >= 1536) ? 3 : 0) : (knob == 1 ? 0 : knob);
   return window_launches(pk, pk.all_edge, B, N, L, C, v_batch_stride, true, &a.gm, &a.edge,
                          [&] { return launch_win(pk, L, a); }, "chord_fwd_win launch");
 }
@@ -495,6 +499,7 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
         BwdWinArgs a{dZ, W, dV, Geom{}, offs, w_total, false, s};
         a.V2 = V;
         a.out2 = dW;
+        a.wg_per_cu = g_bwd_fused_wg_limit.load();
         if (wfar != nullptr && far_k0 >= 0 && far_k0 <= pk.KN && pk.KN < L) {
           a.wfar = wfar;
           a.far_k0 = far_k0;
