@@ -49,6 +49,8 @@ if ROOT not in sys.path:
 N_SEQ, M_FACTORS, C_CH, B_PER_GPU = 16384, 14, 8, 64
 L_LINKS = M_FACTORS + 1
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the rate this box sustains is measured below
+# several ranks: the data-parallel training leg is abandoned after this long (see main); the variable exists for the test of it
+TRAIN_DEADLINE_S = float(os.environ.get("PSF_BENCH_TRAIN_DEADLINE_S", "300"))
 PREHEAT_S = 0.3        # seconds of untimed chains before the warm-up steps (brings the clocks up; printed in the line)
 TRAIN_PROBLEM, TRAIN_N, TRAIN_B = "order", 16384, 40  # SyntheticExperiments/synthetic_training_config.py:72-86
 
@@ -347,13 +349,7 @@ def run_rank(args) -> int:
             bw = {"error": repr(exc)}
     if args.train_graph is None:
         args.train_graph = world > 1
-    train = None
-    train_listops = None
-    if args.train:
-        train = train_leg(args, device, rank, world, dist)
-        if world == 1:
-            train_listops = listops_leg(args, device)
-
+    line = None
     if rank == 0:
         tokens = world * B_PER_GPU * N_SEQ * args.steps
         launches = args.steps * M_FACTORS
@@ -405,6 +401,35 @@ def run_rank(args) -> int:
         }
         if rehearsal():
             line["rehearsal"] = "ranks share GPUs over gloo: plumbing check only, the numbers are meaningless"
+
+    # The secondary legs run AFTER the headline is complete. With several ranks the training leg contains collectives
+    # that no box with more than one GPU has ever run: a rank that fails inside one leaves the others
+    # waiting. A deadline guards the headline: when it passes, rank 0 prints the line with the leg marked as abandoned and
+    # every rank leaves with code 0.
+    train = None
+    train_listops = None
+    if args.train:
+        guard = None
+        if world > 1:
+            import threading
+
+            def abandon():
+                if rank == 0 and line is not None:
+                    line["train"] = {"error": f"the training leg did not finish within {TRAIN_DEADLINE_S} s on {world} ranks; "
+                                              "abandoned so that the headline line is kept"}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+
+            guard = threading.Timer(TRAIN_DEADLINE_S, abandon)
+            guard.daemon = True
+            guard.start()
+        train = train_leg(args, device, rank, world, dist)
+        if guard is not None:
+            guard.cancel()
+        if world == 1:
+            train_listops = listops_leg(args, device)
+
+    if rank == 0:
         if train is not None:
             line["train"] = train
         if train_listops is not None:
@@ -428,19 +453,31 @@ def run_rank(args) -> int:
 def train_leg(args, device, rank, world, dist):
     """Temporal Order N = 16384, B = 40 per GPU: whole-job training tokens/s and the gradient all-reduce's device time."""
     import torch
+    r, err = None, None
+    if os.environ.get("PSF_BENCH_TEST_STALL_RANK") == str(rank):  # test hook: this rank never reaches the leg's collectives
+        time.sleep(3600)
     try:
         from sparsefactorization_amd.psf_training import train_benchmark
         r = train_benchmark(TRAIN_PROBLEM, TRAIN_N, TRAIN_B, steps=args.train_steps, warmup=5, device=device,
                             rank=rank, world=world, graph=args.train_graph)
-        vals = [r["seconds"], r["event_ms"], r["allreduce_us"] if r["allreduce_us"] is not None else -1.0]
+        vals = [r["seconds"], r["event_ms"], r["allreduce_us"] if r["allreduce_us"] is not None else -1.0, 1.0]
+    except Exception as exc:  # this rank still takes part in the gather below: the others must not wait for it
+        err = repr(exc)
+        vals = [0.0, 0.0, -1.0, 0.0]
+    try:
         if dist is not None:
             t = torch.tensor(vals, device="cpu" if rehearsal() else device, dtype=torch.float64)
             gathered = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(gathered, t)
+            failed = [i for i, g in enumerate(gathered) if float(g[3]) == 0.0]
+            if failed:
+                return {"error": err if err is not None else f"the training leg failed on rank(s) {failed}"}
             secs = max(float(g[0]) for g in gathered)
             ms = [float(g[1]) / r["steps"] for g in gathered]
             ar = max(float(g[2]) for g in gathered)
         else:
+            if err is not None:
+                return {"error": err}
             secs, ms, ar = vals[0], [vals[1] / r["steps"]], vals[2]
         return {
             "metric": "PSF train tokens/sec, Temporal Order N=16384, B=40/GPU, Adam",

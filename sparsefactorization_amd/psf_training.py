@@ -79,7 +79,18 @@ def train_benchmark(problem: str, n_vec: int, batch: int, steps: int, warmup: in
     reducer = dp.FlatGradAllReduce(net.parameters(), timing=True) if world > 1 else None
     X, Y = make_split(problem, batch * n_batches, n_vec, device, 1000 + rank)
     batches = [(X[i * batch:(i + 1) * batch], Y[i * batch:(i + 1) * batch]) for i in range(n_batches)]
-    graphed = GraphedStep(net, optimizer, loss, *batches[0], reducer=reducer) if graph else None
+    graphed, graph_error = None, None
+    if graph:
+        try:
+            graphed = GraphedStep(net, optimizer, loss, *batches[0], reducer=reducer)
+        except Exception as exc:
+            if world == 1:
+                raise
+            # Several ranks: a capture that fails next to a live process group (never seen: no multi-GPU box yet) must not
+            # cost the measurement. Every rank has made the same number of reducer calls (the warm-up steps), so an eager
+            # continuation stays in step with ranks whose capture worked.
+            graph_error = repr(exc)
+            torch.cuda.synchronize(device)
 
     def one(i):
         x, y = batches[i % n_batches]
@@ -117,7 +128,8 @@ def train_benchmark(problem: str, n_vec: int, batch: int, steps: int, warmup: in
     return {"seconds": dt, "event_ms": e0.elapsed_time(e1), "steps": steps, "loss": float(last),
             "allreduce_us": reducer.mean_us() if reducer is not None else None,
             "grad_bytes": 4 * sum(p.numel() for p in net.parameters() if p.requires_grad),
-            "hip_graph": ("fwd+bwd" if use_graph_dp else "step") if graph else None}
+            "hip_graph": (("fwd+bwd" if use_graph_dp else "step") if graphed is not None else f"eager after: {graph_error}")
+            if graph else None}
 
 
 def main(argv=None):

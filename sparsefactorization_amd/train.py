@@ -276,7 +276,10 @@ class GraphedStep:
     in the graph's memory pool."""
 
     def __init__(self, net, optimizer, loss, X: torch.Tensor, Y: torch.Tensor, warmup_steps: int = 3,
-                 reducer: Optional[Callable[[], None]] = None):
+                 reducer: Optional[Callable[[], None]] = None, capture_error_mode: Optional[str] = None):
+        """``capture_error_mode`` (``torch.cuda.graph``): None = "thread_local" when a reducer is given — with a process
+        group alive its watchdog thread queries events while this thread captures, and in "global" mode a call from ANY
+        thread can invalidate the capture — else "global" (the strictest check, nothing else runs in a single process)."""
         if not X.is_cuda:
             raise RuntimeError("GraphedStep needs GPU tensors")
         check_capturable(net)
@@ -316,7 +319,10 @@ class GraphedStep:
                                "token_linear.TokenEmbedding (same parameters and state_dict) or train eagerly.")
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        if capture_error_mode is None:
+            capture_error_mode = "thread_local" if reducer is not None else "global"
+        self.capture_error_mode = capture_error_mode
+        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
             self.output = self._step(zero=False, eager_tail=False)
         self.warmup_steps = warmup_steps
         with torch.no_grad():
