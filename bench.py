@@ -290,10 +290,10 @@ def run_rank(args) -> int:
         import torch.distributed as dist  # backend "nccl" is RCCL on ROCm
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if rehearsal():
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # The default group is gloo: the forward path has NO data-path collective, its ranks only meet at barriers and at
+        # two small gathers of timings (CPU tensors), so the headline of an N-GPU run does not depend on RCCL coming up.
+        # RCCL carries what needs it — the gradient all-reduce of the training leg — in its own group (train_leg).
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import sparsefactorization_amd as sfa
 
@@ -332,7 +332,7 @@ def run_rank(args) -> int:
 
     per_rank_ms = [ev_ms]
     if dist is not None:
-        t = torch.tensor([elapsed, ev_ms], device="cpu" if rehearsal() else device, dtype=torch.float64)  # gloo gathers CPU tensors
+        t = torch.tensor([elapsed, ev_ms], device="cpu", dtype=torch.float64)  # the default group is gloo
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
         elapsed = max(float(g[0]) for g in gathered)  # MAX over ranks
@@ -458,15 +458,17 @@ def train_leg(args, device, rank, world, dist):
         time.sleep(3600)
     try:
         from sparsefactorization_amd.psf_training import train_benchmark
+        # gradients travel over RCCL ("nccl" on ROCm), in a group of their own; the rehearsal (ranks sharing a GPU) stays on gloo
+        group = dist.new_group(backend="nccl") if (dist is not None and world > 1 and not rehearsal()) else None
         r = train_benchmark(TRAIN_PROBLEM, TRAIN_N, TRAIN_B, steps=args.train_steps, warmup=5, device=device,
-                            rank=rank, world=world, graph=args.train_graph)
+                            rank=rank, world=world, graph=args.train_graph, group=group)
         vals = [r["seconds"], r["event_ms"], r["allreduce_us"] if r["allreduce_us"] is not None else -1.0, 1.0]
     except Exception as exc:  # this rank still takes part in the gather below: the others must not wait for it
         err = repr(exc)
         vals = [0.0, 0.0, -1.0, 0.0]
     try:
         if dist is not None:
-            t = torch.tensor(vals, device="cpu" if rehearsal() else device, dtype=torch.float64)
+            t = torch.tensor(vals, device="cpu", dtype=torch.float64)
             gathered = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(gathered, t)
             failed = [i for i, g in enumerate(gathered) if float(g[3]) == 0.0]

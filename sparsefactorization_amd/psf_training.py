@@ -62,21 +62,23 @@ def make_split(problem: str, n_seq: int, n_vec: int, device, seed: int):
 
 
 def train_benchmark(problem: str, n_vec: int, batch: int, steps: int, warmup: int, device, rank: int = 0,
-                    world: int = 1, graph: bool = False, n_batches: int = 4) -> dict:
+                    world: int = 1, graph: bool = False, n_batches: int = 4, group=None) -> dict:
     """Time ``steps`` optimisation steps of the reference training loop body (psf_utils.py:62-71: zero_grad, forward,
     loss, backward, [gradient all-reduce,] Adam step) on this rank's shard: ``batch`` sequences per rank per step,
     synthetic data of the task's distribution generated on the device (rank-offset seed), replicas started from rank
     0's weights. Returns per-rank numbers; the caller aggregates over ranks (bench.py --train, ``--json`` below).
-    The region is bracketed by a barrier + device synchronisation on both sides when a process group exists."""
+    The region is bracketed by a barrier + device synchronisation on both sides when a process group exists. ``group``:
+    the process group of the parameter broadcast and the gradient all-reduce (None = the default group); the barriers use
+    the default group (bench.py keeps that one on gloo and hands an RCCL group in here)."""
     import torch.distributed as dist
     seed_everything(42)
     net = build_model(problem, n_vec).to(device)
-    dp.broadcast_parameters(net)
+    dp.broadcast_parameters(net, group=group)
     lr = config[problem]["training"]["learning_rate"]
     use_graph_dp = graph and world > 1
     optimizer = make_adam(net.parameters(), lr, capturable=graph and world == 1)
     loss = nn.MSELoss() if problem == "adding" else nn.CrossEntropyLoss()
-    reducer = dp.FlatGradAllReduce(net.parameters(), timing=True) if world > 1 else None
+    reducer = dp.FlatGradAllReduce(net.parameters(), group=group, timing=True) if world > 1 else None
     X, Y = make_split(problem, batch * n_batches, n_vec, device, 1000 + rank)
     batches = [(X[i * batch:(i + 1) * batch], Y[i * batch:(i + 1) * batch]) for i in range(n_batches)]
     graphed, graph_error = None, None

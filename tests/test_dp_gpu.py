@@ -108,3 +108,37 @@ def test_bench_keeps_the_headline_when_a_rank_stalls_in_the_training_leg(gpu):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["roofline"]["frac"] > 0
     assert "did not finish" in line["train"]["error"]
+
+
+def test_rccl_group_beside_a_gloo_default_group(gpu):
+    """bench.py keeps its default process group on gloo (barriers and timing gathers: the headline must not depend on RCCL)
+    and gives the training leg's reducer an RCCL group of its own. The same combination with one rank: a forced flat
+    all-reduce through the RCCL group leaves the gradients as they were."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        from sparsefactorization_amd import dp
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        g = dist.new_group(backend="nccl")
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        lin = torch.nn.Linear(64, 32).to(dev)
+        lin(torch.randn(8, 64, device=dev)).square().sum().backward()
+        before = [p.grad.clone() for p in lin.parameters()]
+        red = dp.FlatGradAllReduce(lin.parameters(), group=g, timing=True, force=True)
+        red()
+        torch.cuda.synchronize()
+        assert dist.get_backend(g) == "nccl" and dist.get_backend() == "gloo"
+        assert all(torch.equal(a, p.grad) for a, p in zip(before, lin.parameters()))
+        assert red.mean_us() > 0
+        dist.barrier()
+        dist.destroy_process_group()
+        print("ok")
+    """ % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-3000:]
