@@ -1,7 +1,9 @@
 // x3flab.hip — phase timing of x3_fwd_k (csrc/mlp_fwd_x3.hip built with PSF_X3F_TRACE): shader-clock timestamps that
 // every wave of one workgroup takes at the phase boundaries of one unit, 15 MLPs (E = h = 32) over T tokens.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o /tmp/x3flab profiles/x3flab.hip && /tmp/x3flab
+#ifndef PSF_X3F_NOTRACE  // -DPSF_X3F_NOTRACE: timing only, three readings of 30 calls after a warm-up
 #define PSF_X3F_TRACE 1
+#endif
 #include <cstdio>
 #include <vector>
 
@@ -50,6 +52,21 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
+#ifdef PSF_X3F_NOTRACE
+  for (int it = 0; it < 100; ++it)
+    CK(psf_x3_mlp_fwd_launch(X, T, E, K, A.data(), a.data(), B.data(), b.data(), h.data(), O.data(), Y.data(), ws, nullptr));
+  for (int rd = 0; rd < 3; ++rd) {
+    CK(hipEventRecord(e0));
+    for (int it = 0; it < 30; ++it)
+      CK(psf_x3_mlp_fwd_launch(X, T, E, K, A.data(), a.data(), B.data(), b.data(), h.data(), O.data(), Y.data(), ws, nullptr));
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float msr = 0;
+    CK(hipEventElapsedTime(&msr, e0, e1));
+    std::printf("x3 forward, T = %lld: %.4f ms per call\n", (long long)T, msr / 30);
+  }
+  return 0;
+#else
   for (int it = 0; it < 3; ++it)
     CK(psf_x3_mlp_fwd_launch(X, T, E, K, A.data(), a.data(), B.data(), b.data(), h.data(), O.data(), Y.data(), ws, nullptr));
   CK(hipEventRecord(e0));
@@ -75,4 +92,5 @@ int main(int argc, char** argv) {
     std::printf("\n");
   }
   return 0;
+#endif
 }

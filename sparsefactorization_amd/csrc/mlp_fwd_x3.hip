@@ -387,6 +387,8 @@ x3_fwd_k(const X3Args a) {
           f32x16 acc1;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc1[r] = sa[cd_row(r, half)];
+          // (s_setprio by phase — 1 around the matrix chains, 0 around the GELU halves, what gained 3 % in the backward kernel —
+          // costs 2 % here at three waves per SIMD: profiles/r03an_x3f_prio.log)
           acc1 = mfma6(wa[0], xf[tp][0], acc1);
           acc1 = mfma6(wa[1], xf[tp][1], acc1);
           acc2[tp] = mfma6(wb[0], half_gelu(acc1, 0), acc2[tp]);
