@@ -25,6 +25,7 @@ against that restatement (cross-checked in tests against spmul/spmul_cuda.cu's f
 
     python oracle/gen_golden.py            # rewrites every fixture
     python oracle/gen_golden.py cfg3       # only train_lra_listops_cfg3_n2048.npz
+    PSF_GOLDEN_OUT=/tmp/g python oracle/gen_golden.py && python oracle/compare_golden.py /tmp/g   # do the fixtures reproduce?
 """
 from __future__ import annotations
 
@@ -39,7 +40,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
-OUT = os.path.join(ROOT, "tests", "golden")
+# PSF_GOLDEN_OUT=<dir>: write there instead (to check that the committed fixtures reproduce: tests/golden/README or
+# `python oracle/compare_golden.py <dir>`)
+OUT = os.environ.get("PSF_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)
 
 from oracle.chord_oracle import torch_spmm_port  # noqa: E402
