@@ -232,6 +232,14 @@ int psf_embed_tokens_bwd_f32(const int64_t* idx, const float* dOut, int64_t T, i
  *   sizes). One read of X; per-chunk partial sums are added in a fixed order (bit-reproducible).
  */
 int64_t psf_flat_head_workspace(int32_t B, int64_t K, int32_t J);
+/*
+ * Its backward (what autograd computes for that nn.Linear):  dW[j,i] = sum_b dY[b,j] * X[b,i],  dX[b,i] = sum_j dY[b,j] * W[j,i]
+ *   dY [B,J] contiguous; dX [B,K] and / or dW [J,K] (NULL = not wanted; dW needs X, dX needs W); 1 <= B <= 1024,
+ *   1 <= J <= 16 (the first layer of CIFAR-10's non-linear head has 16), K a positive multiple of 4; X, W, dX, dW 16-byte aligned. One read of X, sums over b in ascending order
+ *   (bit-reproducible). The bias gradient (the column sums of dY) is left to the caller.
+ */
+int psf_flat_head_bwd_f32(const float* dY, const float* X, const float* W, float* dX, float* dW, int32_t B, int64_t K, int32_t J,
+                          void* stream);
 int psf_flat_head_f32(const float* X, const float* W, const float* bias, float* out, int32_t B, int64_t K, int32_t J,
                       void* workspace, int64_t workspace_bytes, void* stream);
 

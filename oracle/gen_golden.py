@@ -25,6 +25,7 @@ against that restatement (cross-checked in tests against spmul/spmul_cuda.cu's f
 
     python oracle/gen_golden.py            # rewrites every fixture
     python oracle/gen_golden.py cfg3       # only train_lra_listops_cfg3_n2048.npz
+    python oracle/gen_golden.py genome_train   # only train_genome_n320.npz
     PSF_GOLDEN_OUT=/tmp/g python oracle/gen_golden.py && python oracle/compare_golden.py /tmp/g   # do the fixtures reproduce?
 """
 from __future__ import annotations
@@ -542,6 +543,77 @@ def gen_genome(gen):
          **state_arrays(net))
 
 
+def gen_training_genome(gen, utils):
+    """The genome classification loop: the reference's TrainPSF of Genome_Clf/psf_utils.py:48-151 — the LRA loop plus
+    clip_grad_norm_(max_norm=1.0) between backward and step (:73) and a ROC-AUC of the hard predictions in both evaluation
+    loops (:109-126) — on its own PSFNet (Genome_Clf/psf.py:63-240) configured as genome_training_config.py:2-22 (vocab 6,
+    E = C = 32, FLATTEN pooling, linear head, no residual, no positional embedding; dropouts 0 for a device-independent
+    trajectory) at a small size: N = 320, n_W = 9, 2 epochs x 6 fixed batches of 8, evaluation on 2 + 2 batches,
+    CrossEntropyLoss(reduction="sum") — so that the gradient norms exceed 1 and the clip acts —, Adam(1e-4 as :115),
+    seed_everything(42). Inputs: seeded torch.randint tokens / labels."""
+    import contextlib
+    import io
+    import re
+    from torch.utils.data import DataLoader
+    cfg = dict(vocab_size=6, embedding_size=32, n_vec=320, n_W=9, Ws=[32, 'GELU'], V=[32, 'GELU'], n_channels_V=32,
+               n_class=2, pooling_type="FLATTEN", head=['linear'], use_cuda=False, use_residuals=False, dropout1_p=0,
+               dropout2_p=0, dropout3_p=0, init_embedding_weights=False, use_pos_embedding=False)
+    BATCH, NB, NE, EPOCHS = 8, 6, 2, 2
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        utils.seed_everything(42)
+        net = gen.PSFNet(**cfg)
+        sd0 = state_arrays(net)
+        optimizer = torch.optim.Adam(net.parameters(), lr=0.0001)
+        # reduction="sum": with the mean the gradient norms of this small network stay below 1 and the clip would be a no-op
+        loss = RecordingLoss(torch.nn.CrossEntropyLoss(reduction="sum"))
+        g = torch.Generator().manual_seed(2027)
+        # gradient norms before clipping, as clip_grad_norm_ returns them (the loop discards the value)
+        norms = []
+        real_clip = torch.nn.utils.clip_grad_norm_
+
+        def recording_clip(parameters, max_norm, *a, **k):
+            total = real_clip(parameters, max_norm, *a, **k)
+            norms.append(float(total))
+            return total
+
+        def split(n):
+            return torch.randint(0, 5, (n, cfg["n_vec"]), generator=g), torch.randint(0, 2, (n,), generator=g)
+
+        (Xtr, Ytr), (Xva, Yva), (Xte, Yte) = split(BATCH * NB), split(BATCH * NE), split(BATCH * NE)
+        mk = lambda X, Y: DataLoader(utils.DatasetCreator(X, Y), batch_size=BATCH, shuffle=False, drop_last=True,  # noqa: E731
+                                     num_workers=0)
+        buf = io.StringIO()
+        torch.nn.utils.clip_grad_norm_ = recording_clip
+        try:
+            with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+                utils.TrainPSF(net=net, trainloader=mk(Xtr, Ytr), valloader=mk(Xva, Yva), testloader=mk(Xte, Yte),
+                               n_epochs=EPOCHS, test_freq=1, optimizer=optimizer, loss=loss, saving_criteria=1e9)
+        finally:
+            torch.nn.utils.clip_grad_norm_ = real_clip
+        text = buf.getvalue()
+        num = r"([-+0-9.eE]+)"
+        printed = {key: [float(x) for x in re.findall(pat + num, text)]
+                   for key, pat in (("train_loss", r"Training loss:\s+"), ("val_loss", r"Val  loss: "),
+                                    ("test_loss", r"Test loss: "), ("val_acc", r"Val  accuracy: "),
+                                    ("test_acc", r"Test accuracy: "), ("val_rocauc", r"Val  ROCAUC: "),
+                                    ("test_rocauc", r"Test ROCAUC: "))}
+        per_epoch = NB + 2 * NE
+        assert len(loss.values) == EPOCHS * per_epoch and all(len(v) == EPOCHS for v in printed.values())
+        assert len(norms) == EPOCHS * NB and max(norms) > 1.0, norms  # the clip is exercised
+        vals = np.asarray(loss.values, dtype=np.float64).reshape(EPOCHS, per_epoch)
+        u8 = lambda t: t.numpy().astype(np.uint8)  # noqa: E731
+        save("train_genome_n320.npz", Xtr=u8(Xtr), Ytr=u8(Ytr), Xva=u8(Xva), Yva=u8(Yva), Xte=u8(Xte), Yte=u8(Yte),
+             step_loss=vals[:, :NB].copy(), val_batch_loss=vals[:, NB:NB + NE].copy(), test_batch_loss=vals[:, NB + NE:].copy(),
+             grad_norm=np.asarray(norms, dtype=np.float64).reshape(EPOCHS, NB),
+             **{"printed_" + k: np.asarray(v) for k, v in printed.items()},
+             **sd0, **{"final::" + k[4:]: v for k, v in state_arrays(net).items()})
+        print(f"  genome: step losses epoch0 {vals[0, :3]} ... grad norms {norms[:3]} ... printed {printed}")
+    finally:
+        torch.Tensor.cuda = real_cuda
+
+
 # ---------------------------------------------------------------------------------------------------
 # 6. the reference's data generators
 # ---------------------------------------------------------------------------------------------------
@@ -563,7 +635,7 @@ def gen_synth_data(gen):
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # deterministic CPU reductions
-    only = sys.argv[1] if len(sys.argv) > 1 else None  # "cfg3": only that fixture
+    only = sys.argv[1] if len(sys.argv) > 1 else None  # "cfg3" / "genome_train": only that fixture
     se = import_reference("ref_se_psf", "SyntheticExperiments/psf.py")
     lra = import_reference("ref_lra_psf", "LRA/psf.py")
     if only is None:
@@ -574,6 +646,9 @@ def main():
     lra_utils = import_reference("ref_lra_psf_utils", "LRA/psf_utils.py")
     if only in (None, "cfg3"):
         gen_training_lra_cfg3(lra, lra_utils)
+    if only in (None, "genome_train"):
+        gen_training_genome(import_reference("ref_genome_psf", "Genome_Clf/psf.py"),
+                            import_reference("ref_genome_psf_utils", "Genome_Clf/psf_utils.py"))
     if only is not None:
         return
     gen_training_lra(lra, lra_utils)

@@ -50,6 +50,7 @@ SIGNATURES = {
     "psf_embed_tokens_bwd_f32": ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp], ctypes.c_int),
     "psf_flat_head_workspace": ([c_i32, c_i64, c_i32], c_i64),
     "psf_flat_head_f32": ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_i64, c_vp], ctypes.c_int),
+    "psf_flat_head_bwd_f32": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp], ctypes.c_int),
     "psf_mlp_fwd_workspace": ([c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)], c_i64),
     "psf_mlp_fwd_f32": ([c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                          ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_vp), c_vp,

@@ -29,9 +29,12 @@ struct BwdFusedCfg {
   static constexpr int lds_bytes = 2 * B::win_bytes + 2 * B::w_tile_bytes;
 };
 
-// 256 threads: five workgroups per CU (32 KB of LDS each at C = 8) need <= 96 registers; unbounded hipcc takes 100.
+// 256 threads at C <= 8: five workgroups per CU (32 KB of LDS each at C = 8) need <= 96 registers; unbounded hipcc takes 100.
+// Wider rows have more far links to hold (8 at C = 32): under that bound the C = 32 instance spilled 22 registers and took
+// 99 us per step where the 512-thread one takes 54 (genome shape, profiles/r03ap_bwd_fused_c32.log), so the bound is for the
+// narrow instances only.
 template <int L, int TGS, int NT>
-__global__ void __launch_bounds__(NT, NT == 256 ? 5 : 2)
+__global__ void __launch_bounds__(NT, (NT == 256 && TGS <= 1) ? 5 : 2)
 chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, const float* __restrict__ V,
                   float* __restrict__ dW, float* __restrict__ dV, const Geom gm, const Offsets offs, const int64_t w_total,
                   const float* __restrict__ wfar, const int far_k0) {

@@ -67,7 +67,7 @@ class MLPBlock(nn.Module):
 
 
 class _FlatHeadFn(torch.autograd.Function):
-    """out = flat @ weight.T + bias on ``psf_flat_head_f32`` (csrc/flat_head.hip); backward: the usual small GEMMs."""
+    """out = flat @ weight.T + bias on ``psf_flat_head_f32``, its backward on ``psf_flat_head_bwd_f32`` (csrc/flat_head.hip)."""
 
     @staticmethod
     def forward(ctx, flat, weight, bias):
@@ -75,6 +75,13 @@ class _FlatHeadFn(torch.autograd.Function):
         flat_c, w_c = flat.contiguous(), weight.contiguous()
         B, K = flat_c.shape
         J = w_c.shape[0]
+        ctx.save_for_backward(flat_c, w_c)
+        ctx.has_bias = bias is not None
+        if J > 8:
+            # The forward kernel holds J weight chunks in registers (J <= 8). CIFAR-10's first head layer (16 outputs, K = 16384)
+            # keeps the library GEMM forward — in two groups of eight rows the kernel's 16 workgroups took 2 x 26 us against the
+            # GEMM's 28 (profiles/r03ap_family_step_kernels.log) — and takes the streaming kernel backward (13 us).
+            return torch.nn.functional.linear(flat_c, w_c, bias)
         ws_bytes = lib.psf_flat_head_workspace(B, K, J)
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=flat.device)
         out = torch.empty((B, J), dtype=torch.float32, device=flat.device)
@@ -83,15 +90,29 @@ class _FlatHeadFn(torch.autograd.Function):
                                        out.data_ptr(), B, K, J, ws.data_ptr(), ws_bytes,
                                        torch.cuda.current_stream(flat.device).cuda_stream)
         _lib.check(rc, "psf_flat_head_f32")
-        ctx.save_for_backward(flat_c, w_c)
-        ctx.has_bias = bias is not None
         return out
 
     @staticmethod
     def backward(ctx, dy):
         flat, weight = ctx.saved_tensors
-        d_flat = dy.mm(weight) if ctx.needs_input_grad[0] else None
-        d_w = dy.t().mm(flat) if ctx.needs_input_grad[1] else None
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        d_flat = d_w = None
+        B, K = flat.shape
+        J = weight.shape[0]
+        if (need_x or need_w) and dy.dtype == torch.float32 and B <= 1024 and flat.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0:
+            # psf_flat_head_bwd_f32: one pass over X instead of two library GEMMs with K in the hundreds of thousands and
+            # J, B tiny (272 us for dW at the genome shape; csrc/flat_head.hip)
+            dy_c = dy.contiguous()
+            d_flat = torch.empty_like(flat) if need_x else None
+            d_w = torch.empty_like(weight) if need_w else None
+            with torch.cuda.device(flat.device):
+                rc = _lib.load().psf_flat_head_bwd_f32(dy_c.data_ptr(), flat.data_ptr(), weight.data_ptr(),
+                                                       d_flat.data_ptr() if need_x else None, d_w.data_ptr() if need_w else None,
+                                                       B, K, J, torch.cuda.current_stream(flat.device).cuda_stream)
+            _lib.check(rc, "psf_flat_head_bwd_f32")
+        else:
+            d_flat = dy.mm(weight) if need_x else None
+            d_w = dy.t().mm(flat) if need_w else None
         d_b = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return d_flat, d_w, d_b
 
@@ -100,7 +121,10 @@ def _flat_head(final: nn.Module, flat: torch.Tensor) -> torch.Tensor:
     """``final(flat)`` for the FLATTEN head, Linear(N*C -> n_class) on [B, N*C] (psf.py:129-134). As a GEMM the
     library takes 0.57 ms (Adding, one output) or 117 us (Temporal Order, four) at N*C = 131072, B = 64
     (profiles/r01_e2e_forward_split.log); ``psf_flat_head_f32`` reads the activations once."""
-    if (isinstance(final, nn.Linear) and final.out_features <= 8 and flat.is_cuda and flat.dim() == 2
+    if isinstance(final, nn.Sequential) and len(final) > 0 and isinstance(final[0], nn.Linear):
+        # the non-linear head (LRA/psf.py: Linear(N*C -> hidden), GELU, Linear(hidden -> n_class)): its first layer is the wide one
+        return final[1:](_flat_head(final[0], flat))
+    if (isinstance(final, nn.Linear) and final.out_features <= 16 and flat.is_cuda and flat.dim() == 2
             and flat.dtype == torch.float32 and final.weight.dtype == torch.float32 and flat.shape[1] % 4 == 0
             and flat.shape[1] >= 4096):
         return _FlatHeadFn.apply(flat, final.weight, final.bias)
@@ -300,7 +324,10 @@ class _TokenPSFNet(_ChordMixer):
     def pool_and_classify(self, V):
         if self.pooling_type == 'CLS':
             V = V[:, 0, :]
-        return self.final(V.reshape(V.size(0), -1))
+        flat = V.reshape(V.size(0), -1)
+        if self.pooling_type == 'FLATTEN':  # Linear(N*C -> n_class): the streaming head kernels where they apply
+            return _flat_head(self.final, flat)
+        return self.final(flat)
 
     def forward(self, data):
         return self.pool_and_classify(self.features(data))

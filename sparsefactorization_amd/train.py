@@ -224,9 +224,35 @@ def _count_correct(pred: torch.Tensor, Y: torch.Tensor, problem: str) -> torch.T
     return pred.max(1)[1].eq(Y).sum()                         # psf_utils.py:105-106
 
 
+def binary_roc_auc(targets, scores) -> float:
+    """Area under the ROC curve of ``scores`` for binary ``targets`` (what sklearn.metrics.roc_auc_score returns for them):
+    the Mann-Whitney statistic with average ranks for ties. Genome_Clf/psf_utils.py:112,126 call it on the HARD predictions,
+    where it equals (true-positive rate + true-negative rate) / 2. Raises, like sklearn, when only one class is present."""
+    import numpy as np
+    y = np.asarray(targets).astype(np.int64).ravel()
+    s = np.asarray(scores, dtype=np.float64).ravel()
+    n_pos = int((y == 1).sum())
+    n_neg = int(y.size - n_pos)
+    if n_pos == 0 or n_neg == 0:
+        raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+    order = np.argsort(s, kind="mergesort")
+    ranks = np.empty(s.size, dtype=np.float64)
+    sorted_s = s[order]
+    i = 0
+    while i < s.size:  # average rank of each run of equal scores
+        j = i
+        while j + 1 < s.size and sorted_s[j + 1] == sorted_s[i]:
+            j += 1
+        ranks[order[i:j + 1]] = 0.5 * (i + j) + 1.0
+        i = j + 1
+    return float((ranks[y == 1].sum() - n_pos * (n_pos + 1) / 2.0) / (n_pos * n_neg))
+
+
 @torch.no_grad()
-def evaluate(net, loader: Iterable, loss, problem: str) -> Dict[str, float]:
-    """Mean loss and accuracy (%) over a loader, as the validation / test loops of TrainModel (92-121)."""
+def evaluate(net, loader: Iterable, loss, problem: str, roc_auc: bool = False) -> Dict[str, float]:
+    """Mean loss and accuracy (%) over a loader, as the validation / test loops of TrainModel (92-121). ``roc_auc``: also
+    the ROC-AUC of the hard predictions over the whole loader, as Genome_Clf/psf_utils.py:95-126 (key "rocauc", in [0, 1];
+    the predictions and targets behind it as "predictions" / "targets")."""
     dev = _device_of(net)
     was_training = net.training
     net.eval()
@@ -234,15 +260,24 @@ def evaluate(net, loader: Iterable, loss, problem: str) -> Dict[str, float]:
     loss_sum = torch.zeros((), device=dev)
     correct = torch.zeros((), device=dev)
     batches = 0
+    kept_pred, kept_y = [], []
     for X, Y in loader:
         X, Y = X.to(dev, non_blocking=True), Y.to(dev, non_blocking=True)
         pred = net(X)
         loss_sum += loss(pred.squeeze(), Y)
         correct += _count_correct(pred, Y, problem)
+        if roc_auc:
+            kept_pred.append(pred.max(1)[1])
+            kept_y.append(Y)
         total += Y.size(0)
         batches += 1
     net.train(was_training)
-    return {"loss": float(loss_sum) / max(batches, 1), "accuracy": 100.0 * float(correct) / max(total, 1)}
+    out = {"loss": float(loss_sum) / max(batches, 1), "accuracy": 100.0 * float(correct) / max(total, 1)}
+    if roc_auc:
+        out["predictions"] = torch.cat(kept_pred).cpu().numpy() if kept_pred else []
+        out["targets"] = torch.cat(kept_y).cpu().numpy() if kept_y else []
+        out["rocauc"] = binary_roc_auc(out["targets"], out["predictions"])
+    return out
 
 
 def check_capturable(net: torch.nn.Module) -> None:
@@ -276,7 +311,8 @@ class GraphedStep:
     in the graph's memory pool."""
 
     def __init__(self, net, optimizer, loss, X: torch.Tensor, Y: torch.Tensor, warmup_steps: int = 3,
-                 reducer: Optional[Callable[[], None]] = None, capture_error_mode: Optional[str] = None):
+                 reducer: Optional[Callable[[], None]] = None, capture_error_mode: Optional[str] = None,
+                 grad_clip_norm: Optional[float] = None):
         """``capture_error_mode`` (``torch.cuda.graph``): None = "thread_local" when a reducer is given — with a process
         group alive its watchdog thread queries events while this thread captures, and in "global" mode a call from ANY
         thread can invalidate the capture — else "global" (the strictest check, nothing else runs in a single process)."""
@@ -287,6 +323,9 @@ class GraphedStep:
             raise RuntimeError("GraphedStep captures optimizer.step(): build the optimizer with capturable=True "
                                "(make_adam(..., capturable=True)); a host-side step count would be frozen into the graph")
         self.net, self.optimizer, self.loss, self.reducer = net, optimizer, loss, reducer
+        # clip_grad_norm_(max_norm) between backward (and the all-reduce) and the step — Genome_Clf/psf_utils.py:73. Its
+        # norm, coefficient and scaling are device operations with no read-back: capturable.
+        self.grad_clip_norm = grad_clip_norm
         self.X, self.Y = X.clone(), Y.clone()
         # a plain nn.Embedding that is actually looked up (not just a parameter holder like pos_embedding, whose
         # .weight is added directly) has the same uncapturable gradient: watch for calls during the warm-up
@@ -344,11 +383,17 @@ class GraphedStep:
         out = self.loss(self.net(self.X).squeeze(), self.Y)
         out.backward()
         if self.reducer is None:
+            self._clip()
             self.optimizer.step()
         elif eager_tail:
             self.reducer()
+            self._clip()
             self.optimizer.step()
         return out.detach()
+
+    def _clip(self):
+        if self.grad_clip_norm is not None:
+            torch.nn.utils.clip_grad_norm_(self.net.parameters(), max_norm=self.grad_clip_norm)
 
     def __call__(self, X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
         """One optimisation step on (X, Y); returns the loss (a static tensor, overwritten by the next call)."""
@@ -357,15 +402,17 @@ class GraphedStep:
         self.graph.replay()
         if self.reducer is not None:
             self.reducer()
+            self._clip()
             self.optimizer.step()
         return self.output
 
 
 def train_epoch(net, loader: Iterable, optimizer, loss, reducer: Optional[Callable[[], None]] = None,
-                max_steps: Optional[int] = None, graphed: Optional[GraphedStep] = None) -> Dict[str, float]:
+                max_steps: Optional[int] = None, graphed: Optional[GraphedStep] = None,
+                grad_clip_norm: Optional[float] = None) -> Dict[str, float]:
     """One pass of the training loop (psf_utils.py:60-74). Returns mean loss, steps and seconds. With ``graphed``
     every step is a replay of that captured step (same net / optimizer / loss; a data-parallel ``GraphedStep`` calls
-    its own reducer, ``reducer`` here is then ignored)."""
+    its own reducer, ``reducer`` here is then ignored; likewise its own ``grad_clip_norm``)."""
     dev = _device_of(net)
     running = torch.zeros((), device=dev)
     steps = 0
@@ -384,6 +431,8 @@ def train_epoch(net, loader: Iterable, optimizer, loss, reducer: Optional[Callab
         output.backward()
         if reducer is not None:
             reducer()
+        if grad_clip_norm is not None:  # Genome_Clf/psf_utils.py:73; after the all-reduce, so every rank clips the same gradient
+            torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=grad_clip_norm)
         optimizer.step()
         running += output.detach()
         steps += 1
@@ -424,3 +473,45 @@ def TrainModel(net, trainloader, valloader, testloader, n_epochs, test_freq, opt
 
 
 TrainPSF = TrainModel  # LRA/psf_utils.py:48 name
+
+
+def TrainGenomePSF(net, trainloader, valloader, testloader, n_epochs, test_freq, optimizer, loss, saving_criteria,
+                   reducer: Optional[Callable[[], None]] = None, save_dir: str = ".", log: Callable[[str], None] = print,
+                   is_main: bool = True, graphed: Optional[GraphedStep] = None, grad_clip_norm: float = 1.0):
+    """``TrainPSF`` of Genome_Clf/psf_utils.py:48-151 — same arguments (it has no ``problem``): the LRA loop with
+    ``clip_grad_norm_(net.parameters(), max_norm=1.0)`` between backward and step (:73) and the ROC-AUC of the hard
+    predictions in both evaluation loops (:95-126), printed in per cent (:134-135). A ``graphed`` step must have been built
+    with the same ``grad_clip_norm``. When the test accuracy exceeds ``saving_criteria`` the state_dict, the test
+    predictions and the test targets are saved (:138-151; the reference's file-name pattern there has more fields than
+    arguments and cannot format — the names here are genome_psf_epoch{E}_acc{A}.pt / _predictions.pt / _targets.pt)."""
+    if isinstance(graphed, GraphedStep) and graphed.grad_clip_norm != grad_clip_norm:
+        raise ValueError(f"the graphed step clips at {graphed.grad_clip_norm}, this loop at {grad_clip_norm}")
+    history = []
+    for epoch in range(n_epochs):
+        if is_main:
+            log(str(len(trainloader)))  # :64
+        stats = train_epoch(net, trainloader, optimizer, loss, reducer, graphed=graphed, grad_clip_norm=grad_clip_norm)
+        if is_main:
+            log("Epoch {} - Training loss:  {} — Time:  {}sec".format(epoch, stats["loss"], stats["seconds"]))
+        record = {"epoch": epoch, "train": stats}
+        if epoch % test_freq == 0:
+            val = evaluate(net, valloader, loss, "genome", roc_auc=True)
+            test = evaluate(net, testloader, loss, "genome", roc_auc=True)
+            record.update(val={k: v for k, v in val.items() if k not in ("predictions", "targets")},
+                          test={k: v for k, v in test.items() if k not in ("predictions", "targets")})
+            if is_main:
+                log("Val  loss: {}".format(val["loss"]))
+                log("Test loss: {}".format(test["loss"]))
+                log("Val  accuracy: {}".format(val["accuracy"]))
+                log("Test accuracy: {}".format(test["accuracy"]))
+                log("Val  ROCAUC: {}".format(100. * val["rocauc"]))
+                log("Test ROCAUC: {}".format(100. * test["rocauc"]))
+                log('_' * 40)
+                if test["accuracy"] > saving_criteria:
+                    stem = os.path.join(save_dir, 'genome_psf_epoch{}'.format(epoch))
+                    torch.save(net.state_dict(), '{}_acc{}.pt'.format(stem, test["accuracy"]))
+                    torch.save(list(test["predictions"]), stem + '_predictions.pt')
+                    torch.save(list(test["targets"]), stem + '_targets.pt')
+                    record["checkpoint"] = '{}_acc{}.pt'.format(stem, test["accuracy"])
+        history.append(record)
+    return history

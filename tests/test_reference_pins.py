@@ -567,3 +567,113 @@ def test_cfg3_listops_training_follows_the_reference_at_full_size(gpu, mode):
     for key in g.files:
         if key.startswith("final::"):
             assert rel_inf(sd[key[7:]], g[key]) <= 2e-3, key  # four Adam steps of lr 1e-3 on top of 1e-4-accurate gradients
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Genome classification loop (Genome_Clf/psf_utils.py:48-151): gradient-norm clip + ROC-AUC
+# ----------------------------------------------------------------------------------------------------------------------
+GENOME_SMALL = dict(vocab_size=6, embedding_size=32, n_vec=320, n_W=9, Ws=[32, 'GELU'], V=[32, 'GELU'], n_channels_V=32,
+                    n_class=2, pooling_type="FLATTEN", head=['linear'], use_residuals=False, dropout1_p=0, dropout2_p=0,
+                    dropout3_p=0, init_embedding_weights=False, use_pos_embedding=False)
+
+
+def test_binary_roc_auc_is_the_rank_statistic():
+    """train.binary_roc_auc = sklearn.metrics.roc_auc_score on binary targets (the call of Genome_Clf/psf_utils.py:112,126):
+    hand-checked cases, ties, hard predictions, and sklearn itself where it is installed."""
+    from sparsefactorization_amd.train import binary_roc_auc
+    assert binary_roc_auc([0, 0, 1, 1], [0.1, 0.4, 0.35, 0.8]) == pytest.approx(0.75)
+    assert binary_roc_auc([0, 1], [0, 1]) == 1.0 and binary_roc_auc([0, 1], [1, 0]) == 0.0
+    assert binary_roc_auc([0, 1, 0, 1], [1, 1, 1, 1]) == 0.5  # all tied
+    y, p = [1, 1, 1, 0, 0, 0, 0, 1], [1, 0, 1, 0, 0, 1, 0, 1]  # hard predictions: (TPR + TNR) / 2 = (3/4 + 3/4) / 2
+    assert binary_roc_auc(y, p) == pytest.approx(0.75)
+    with pytest.raises(ValueError):
+        binary_roc_auc([1, 1, 1], [0.2, 0.3, 0.4])
+    try:
+        from sklearn.metrics import roc_auc_score
+    except Exception:
+        return
+    rng = np.random.default_rng(7)
+    for n in (3, 16, 257):
+        for _ in range(10):
+            yy = rng.integers(0, 2, n)
+            if yy.min() == yy.max():
+                continue
+            for ss in (rng.integers(0, 2, n), rng.normal(size=n), rng.integers(0, 4, n)):
+                assert binary_roc_auc(yy, ss) == pytest.approx(roc_auc_score(yy, ss), abs=1e-12)
+
+
+def test_genome_seed_42_draws_the_reference_initial_weights():
+    from sparsefactorization_amd.genome_psf import PSFNet
+    from sparsefactorization_amd.train import seed_everything
+    g = load_golden("train_genome_n320.npz")
+    seed_everything(42)
+    net = PSFNet(**GENOME_SMALL, use_cuda=False)
+    want = golden_state_dict(g)
+    assert list(net.state_dict().keys()) == list(want.keys())
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, want[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_genome_train_harness_follows_the_reference_trajectory(gpu, mode, monkeypatch):
+    """train.TrainGenomePSF on the fixture's batches reproduces what the reference's own TrainPSF
+    (Genome_Clf/psf_utils.py:48-151) did on its own PSFNet: the 12 step losses to 1e-4 relative, the gradient norms its
+    clip_grad_norm_(max_norm=1.0) saw (all above 1: the clip acts), the evaluation losses, accuracies and ROC-AUCs it
+    printed, and the final parameters; eagerly and with the step (clip included) replayed from a HIP graph."""
+    from sparsefactorization_amd.genome_psf import PSFNet
+    from sparsefactorization_amd.train import DeviceBatches, GraphedStep, TrainGenomePSF, make_adam, seed_everything
+    g = load_golden("train_genome_n320.npz")
+    seed_everything(42)
+    net = PSFNet(**GENOME_SMALL, use_cuda=True).to(gpu)
+    i64 = lambda k: torch.from_numpy(g[k].astype(np.int64)).to(gpu)  # noqa: E731
+    data = {s: (i64("X" + s), i64("Y" + s)) for s in ("tr", "va", "te")}
+    mk = lambda s: DeviceBatches(*data[s], 8, shuffle=False, drop_last=True)  # noqa: E731
+    loss = _Recording(torch.nn.CrossEntropyLoss(reduction="sum"))
+    optimizer = make_adam(net.parameters(), 0.0001, capturable=mode == "graph")
+    norms = []
+    real_clip = torch.nn.utils.clip_grad_norm_
+
+    def recording_clip(parameters, max_norm, *a, **k):
+        assert max_norm == 1.0
+        total = real_clip(parameters, max_norm, *a, **k)
+        norms.append(total.detach().clone())
+        return total
+
+    tap, steps = None, []
+    if mode == "graph":
+        graphed = GraphedStep(net, optimizer, loss.inner, data["tr"][0][:8], data["tr"][1][:8], grad_clip_norm=1.0)
+        assert graphed.grad_clip_norm == 1.0
+
+        def tap(X, Y):
+            out = graphed(X, Y)
+            steps.append(out.detach().clone())
+            return out
+    else:
+        monkeypatch.setattr(torch.nn.utils, "clip_grad_norm_", recording_clip)
+    lines = []
+    hist = TrainGenomePSF(net=net, trainloader=mk("tr"), valloader=mk("va"), testloader=mk("te"), n_epochs=2, test_freq=1,
+                          optimizer=optimizer, loss=loss, saving_criteria=1e9, log=lines.append, graphed=tap)
+    vals = np.asarray([float(v) for v in loss.values])
+    if mode == "graph":
+        got_steps, got_eval = np.asarray([float(v) for v in steps]).reshape(2, 6), vals.reshape(2, 4)
+    else:
+        got = vals.reshape(2, 10)
+        got_steps, got_eval = got[:, :6], got[:, 6:]
+        got_norms = np.asarray([float(v) for v in norms]).reshape(2, 6)
+        assert g["grad_norm"].min() > 1.0
+        assert np.max(np.abs(got_norms - g["grad_norm"]) / g["grad_norm"]) <= 1e-3, (got_norms, g["grad_norm"])
+    assert np.max(np.abs(got_steps - g["step_loss"]) / np.abs(g["step_loss"])) <= 1e-4, (got_steps, g["step_loss"])
+    assert np.allclose(got_eval[:, :2], g["val_batch_loss"], rtol=2e-4)
+    assert np.allclose(got_eval[:, 2:], g["test_batch_loss"], rtol=2e-4)
+    for e in range(2):
+        assert abs(hist[e]["train"]["loss"] - g["printed_train_loss"][e]) <= 1e-4 * g["printed_train_loss"][e]
+        assert hist[e]["val"]["accuracy"] == pytest.approx(g["printed_val_acc"][e], abs=1e-9)
+        assert hist[e]["test"]["accuracy"] == pytest.approx(g["printed_test_acc"][e], abs=1e-9)
+        assert 100.0 * hist[e]["val"]["rocauc"] == pytest.approx(g["printed_val_rocauc"][e], abs=1e-9)
+        assert 100.0 * hist[e]["test"]["rocauc"] == pytest.approx(g["printed_test_rocauc"][e], abs=1e-9)
+    assert sum(ln.startswith("Val  ROCAUC: ") for ln in lines) == 2 and sum(ln.startswith("Test ROCAUC: ") for ln in lines) == 2
+    final = {k[len("final::"):]: v for k, v in g.items() if k.startswith("final::")}
+    for k, v in net.state_dict().items():
+        want = final[k]
+        assert rel_inf(v.detach().cpu().numpy(), want) <= 2e-4, k
