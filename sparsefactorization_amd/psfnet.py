@@ -411,8 +411,21 @@ class ChangedPSF(LRAPSFNet):
     def forward(self, data):
         Ws: List[torch.Tensor] = []
         V = self.features(data, Ws)  # dropout3 after the chain, as in the reference
-        eye = torch.eye(self.n_vec, self.n_vec, dtype=V.dtype, device=V.device)
-        W_final = chord_chain(Ws, eye, False)
+        # The map is the chain applied to eye(N): C = N channels. The LDS-window kernels need C to be a multiple of four (16-byte
+        # row chunks); IMDb's N = 4097 is not, and its map then ran on the generic kernel at 179 us per step (1.5 TB/s,
+        # profiles/r03aq_family_infer_kernels.log). The identity is ours to shape: up to three zero columns are appended and
+        # cut off again from the result (a view), which moves 0.07 % more bytes and keeps every product on the window kernels:
+        # 133 us per step. (Padding on to whole 256-channel groups, 4352, does not shed the edge instance — W's size is not a
+        # multiple of 16 bytes either — and costs its 6 %: 148 us.)
+        n = self.n_vec
+        cp = (n + 3) // 4 * 4
+        if cp != n and V.is_cuda:
+            eye = torch.zeros(n, cp, dtype=V.dtype, device=V.device)
+            eye.diagonal().fill_(1)
+            W_final = chord_chain(Ws, eye, False)[..., :n]
+        else:
+            eye = torch.eye(n, n, dtype=V.dtype, device=V.device)
+            W_final = chord_chain(Ws, eye, False)
         return self.pool_and_classify(V), W_final
 
 
