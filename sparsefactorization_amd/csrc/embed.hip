@@ -100,6 +100,8 @@ embed_bwd_partial_k(const int64_t* __restrict__ idx, const float* __restrict__ d
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) mine[v[u] * ep] += g[u];  // in token order; a single wave's LDS accesses stay ordered
+    // (ds_add_f32 without return instead of this read-add-write — same order, same bits — is SLOWER: 32 -> 110 us at the
+    //  Temporal-Order vocabulary of 6, where consecutive adds hit the same addresses; 35 -> 38 us at 225 rows)
   }
   // sub-tables -> one table, in sub order; this slice's partial result
   float* out = part + (size_t)blockIdx.x * V * E;
