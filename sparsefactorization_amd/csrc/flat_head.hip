@@ -16,19 +16,21 @@ extern "C" int psf_internal_fail(int code, const char* message);
 
 namespace {
 
-constexpr int kChunk = 4096;   // floats of K per workgroup: 256 threads x 4 float4
+constexpr int kChunk = 4096;   // floats of K per workgroup at U = 4: 256 threads x 4 float4 (U = 1: 1024)
 constexpr int kRowsPerWg = 8;  // batch rows per workgroup
 constexpr int kMaxJ = 8;
 
-template <int J>
+// U float4 of K per thread: 4 (the first form) or 1 — with 4096-float chunks Temporal Order's head (K = 131072, B = 40) is 160
+// workgroups on 256 CUs and read its 21 MB at 1 TB/s; the launcher takes U = 1 whenever U = 4 would give fewer than 1024.
+template <int J, int U>
 __global__ void __launch_bounds__(256)
 flat_head_partial_k(const float* __restrict__ X, const float* __restrict__ W, int32_t B, int64_t K, float* __restrict__ part) {
   __shared__ float red[4][J];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t k0 = (int64_t)blockIdx.x * kChunk;
-  float4 w[J][4];
+  const int64_t k0 = (int64_t)blockIdx.x * (1024 * U);
+  float4 w[J][U];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < U; ++u) {
     const int64_t k = k0 + 4 * (tid + 256 * u);
 #pragma unroll
     for (int j = 0; j < J; ++j)
@@ -38,9 +40,9 @@ flat_head_partial_k(const float* __restrict__ X, const float* __restrict__ W, in
   for (int r = 0; r < kRowsPerWg; ++r) {
     const int b = b0 + r;
     if (b >= B) break;  // workgroup-uniform
-    float4 x[4];
+    float4 x[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int64_t k = k0 + 4 * (tid + 256 * u);
       x[u] = k < K ? *reinterpret_cast<const float4*>(X + (int64_t)b * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -49,7 +51,7 @@ flat_head_partial_k(const float* __restrict__ X, const float* __restrict__ W, in
     for (int j = 0; j < J; ++j) {
       float a = 0.f;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         a = fmaf(x[u].x, w[j][u].x, a);
         a = fmaf(x[u].y, w[j][u].y, a);
         a = fmaf(x[u].z, w[j][u].z, a);
@@ -85,8 +87,16 @@ flat_head_reduce_k(const float* __restrict__ part, const float* __restrict__ bia
 }
 
 template <int J>
-void launch_partial(const float* X, const float* W, int32_t B, int64_t K, float* part, int chunks, hipStream_t s) {
-  hipLaunchKernelGGL((flat_head_partial_k<J>), dim3(chunks, (B + kRowsPerWg - 1) / kRowsPerWg), dim3(256), 0, s, X, W, B, K, part);
+void launch_partial(const float* X, const float* W, int32_t B, int64_t K, float* part, int chunks, int u, hipStream_t s) {
+  const dim3 grid(chunks, (B + kRowsPerWg - 1) / kRowsPerWg);
+  if (u == 4) hipLaunchKernelGGL((flat_head_partial_k<J, 4>), grid, dim3(256), 0, s, X, W, B, K, part);
+  else hipLaunchKernelGGL((flat_head_partial_k<J, 1>), grid, dim3(256), 0, s, X, W, B, K, part);
+}
+
+// chunk size of a launch: 4096 floats, or 1024 when that would leave fewer than 1024 workgroups
+int head_unroll(int32_t B, int64_t K) {
+  const int64_t wgs4 = ((K + kChunk - 1) / kChunk) * ((B + kRowsPerWg - 1) / kRowsPerWg);
+  return wgs4 >= 1024 ? 4 : 1;
 }
 
 // ---- backward ----------------------------------------------------------------------------------------------------
@@ -205,7 +215,7 @@ extern "C" int psf_flat_head_bwd_f32(const float* dY, const float* X, const floa
 
 extern "C" int64_t psf_flat_head_workspace(int32_t B, int64_t K, int32_t J) {
   if (B < 1 || K < 4 || (K & 3) || J < 1 || J > kMaxJ) return -1;
-  return ((K + kChunk - 1) / kChunk) * (int64_t)B * J * (int64_t)sizeof(float);
+  return ((K + 1023) / 1024) * (int64_t)B * J * (int64_t)sizeof(float);  // sized for the smaller chunk
 }
 
 extern "C" int psf_flat_head_f32(const float* X, const float* W, const float* bias, float* out, int32_t B, int64_t K,
@@ -216,20 +226,21 @@ extern "C" int psf_flat_head_f32(const float* X, const float* W, const float* bi
   if (workspace_bytes < need) return psf_internal_fail(PSF_E_SHAPE, "psf_flat_head: workspace smaller than psf_flat_head_workspace(B, K, J)");
   if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(W) & 15))
     return psf_internal_fail(PSF_E_ALIGN, "psf_flat_head: X and W must be 16-byte aligned");
-  const int64_t chunks64 = (K + kChunk - 1) / kChunk;
+  const int u = head_unroll(B, K);
+  const int64_t chunks64 = (K + 1024 * u - 1) / (1024 * u);
   if (chunks64 > 0x7fffffff) return psf_internal_fail(PSF_E_SHAPE, "psf_flat_head: K too large");
   const int chunks = (int)chunks64;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   float* part = reinterpret_cast<float*>(workspace);
   switch (J) {
-    case 1: launch_partial<1>(X, W, B, K, part, chunks, s); break;
-    case 2: launch_partial<2>(X, W, B, K, part, chunks, s); break;
-    case 3: launch_partial<3>(X, W, B, K, part, chunks, s); break;
-    case 4: launch_partial<4>(X, W, B, K, part, chunks, s); break;
-    case 5: launch_partial<5>(X, W, B, K, part, chunks, s); break;
-    case 6: launch_partial<6>(X, W, B, K, part, chunks, s); break;
-    case 7: launch_partial<7>(X, W, B, K, part, chunks, s); break;
-    default: launch_partial<8>(X, W, B, K, part, chunks, s); break;
+    case 1: launch_partial<1>(X, W, B, K, part, chunks, u, s); break;
+    case 2: launch_partial<2>(X, W, B, K, part, chunks, u, s); break;
+    case 3: launch_partial<3>(X, W, B, K, part, chunks, u, s); break;
+    case 4: launch_partial<4>(X, W, B, K, part, chunks, u, s); break;
+    case 5: launch_partial<5>(X, W, B, K, part, chunks, u, s); break;
+    case 6: launch_partial<6>(X, W, B, K, part, chunks, u, s); break;
+    case 7: launch_partial<7>(X, W, B, K, part, chunks, u, s); break;
+    default: launch_partial<8>(X, W, B, K, part, chunks, u, s); break;
   }
   const int n = B * J;
   hipLaunchKernelGGL(flat_head_reduce_k, dim3(n), dim3(64), 0, s, part, bias, chunks, n, J, out);
