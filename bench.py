@@ -504,17 +504,22 @@ def train_leg(args, device, rank, world, dist):
 def listops_leg(args, device):
     """BASELINE.json configs[2], "LRA ListOps — full PSF model training loop on 1 x MI355X", twice: the reference's own
     configuration (LRA/psf_training_config.py:2-30: N = 1 + 1999, E = 512, 128 channels, batch 32) and BASELINE's wording
-    (N = 2048, dim = 64). Eager steps, one GPU; outside the headline's timed region."""
+    (N = 2048, dim = 64). One GPU; outside the headline's timed region. The whole step (zero_grad, forward, loss, backward, Adam)
+    is replayed from a HIP graph (train.GraphedStep: the same kernels in the same order; a step of the small configuration is
+    ~200 launches for ~1.3 ms of GPU work, and issued one by one it takes 1.4-1.9 ms depending on the host); the eagerly
+    stepped time is reported beside it."""
     out = {}
     try:
         from sparsefactorization_amd.lra_training import train_benchmark
         for tag, over in (("reference_config", {}), ("baseline_wording", dict(n_vec=2048, embedding_size=64, n_channels_V=64))):
-            r = train_benchmark("listops", steps=args.train_steps, warmup=5, device=device, graph=False, **over)
+            eager = train_benchmark("listops", steps=args.train_steps, warmup=5, device=device, graph=False, **over)
+            r = train_benchmark("listops", steps=args.train_steps, warmup=5, device=device, graph=True, **over)
             out[tag] = {"metric": f"PSF train tokens/sec, ListOps N={r['n_vec']}, E={r['embedding_size']}, "
                                   f"C={r['n_channels_V']}, B={r['batch']}, Adam",
                         "value": r["batch"] * r["n_vec"] * r["steps"] / r["seconds"], "unit": "tokens/s",
                         "ms_per_step": r["seconds"] * 1e3 / r["steps"], "device_ms_per_step": r["event_ms"] / r["steps"],
-                        "steps": r["steps"], "loss": r["loss"], "hip_graph": r["hip_graph"]}
+                        "steps": r["steps"], "loss": r["loss"], "hip_graph": r["hip_graph"],
+                        "eager_ms_per_step": eager["seconds"] * 1e3 / eager["steps"], "eager_loss": eager["loss"]}
     except Exception as exc:
         out["error"] = repr(exc)
     return out
