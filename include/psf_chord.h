@@ -261,6 +261,31 @@ int psf_mlp_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
                     float* const* Y, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * The mixer with W produced INSIDE the chain step: V_M from `data` without any W_m in memory.
+ * What PSFNet.forward does between the embedding and the head (SyntheticExperiments/psf.py:165-188, LRA/psf.py:214-240,
+ * Genome_Clf/psf.py:204-230, attention_block.py:148-174; dropout2 between g and the loop must be inactive):
+ *     V0 = g(X);   for m < M:  W_m = fs[m](X);  X_{m+1} = W_m (.) X_m [+ V0]            (X_0 = V0)
+ * Each step is ONE kernel that computes its tile's rows of W_m on chip — `data` rows straight into matrix-core operand
+ * order, the two layers of fs[m] on the bf16 matrix pipe at f32 accuracy (psf_mlp_fwd_f32's arithmetic), the W tile in LDS
+ * — and then gathers and accumulates as psf_chord_spmm_fwd_f32 does (same order, uncontracted multiply and add). The
+ * producer's W writes (4 M L bytes per token) and the chain's W reads never happen; a step reads the data row (4 E bytes)
+ * instead of the W row (4 L bytes).
+ *   X [B,N,E]; MLP 0 is g (E -> h[0] -> C), MLPs 1..M are fs[0..M) (E -> h[k] -> L): A, a, Bw, b, h are HOST tables of
+ *   M + 1 entries laid out as for psf_mlp_fwd_f32 (nn.Linear layouts).
+ *   V0 [B,N,C] receives g(X) (it is also the residual); out_steps as psf_chord_chain_fwd_f32 (may alternate two buffers);
+ *   the result is out_steps[M-1]. Chord offsets only.
+ *   Limits: E a multiple of 4, 4 <= E <= 32; 1 <= h[k] <= 128; C a multiple of 4, 4 <= C <= 32; 4 <= L <= 20; 1 <= M <= 31;
+ *   N at least two tiles (tile = 256, 256, 128, 64 rows for C <= 4, 8, 16, 32); X, V0 and out_steps 16-byte aligned.
+ *   psf_mixer_fwd_workspace returns the bytes of 16-byte-aligned device scratch needed (packed weight images), or -1 when
+ *   the fused path does not cover the shape — the caller then uses psf_mlp_fwd_f32 + psf_chord_chain_fwd_f32.
+ */
+int64_t psf_mixer_fwd_workspace(int64_t N, int32_t E, int32_t M, const int32_t* h, int64_t C, int32_t L);
+int psf_mixer_fwd_f32(const float* X, int64_t B, int64_t N, int32_t E, int32_t M, const float* const* A,
+                      const float* const* a, const float* const* Bw, const float* const* b, const int32_t* h, int64_t C,
+                      int32_t L, int32_t use_residual, float* V0, float* const* out_steps, void* workspace,
+                      int64_t workspace_bytes, void* stream);
+
+/*
  * Producer side, backward (training) of the same K MLPs, fused in one pass over the tokens. What autograd does
  * for MLPBlock (SyntheticExperiments/psf.py:35-60) with 4K GEMMs, K GELU-backward kernels and K-1 accumulations
  * of the input gradient:

@@ -55,6 +55,10 @@ SIGNATURES = {
     "psf_mlp_fwd_f32": ([c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                          ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_vp), c_vp,
                          c_i64, c_vp], ctypes.c_int),
+    "psf_mixer_fwd_workspace": ([c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), c_i64, c_i32], c_i64),
+    "psf_mixer_fwd_f32": ([c_vp, c_i64, c_i64, c_i32, c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+                           ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), c_i64, c_i32, c_i32, c_vp, ctypes.POINTER(c_vp), c_vp,
+                           c_i64, c_vp], ctypes.c_int),
     "psf_mlp_bwd_workspace": ([c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)], c_i64),
     "psf_mlp_bwd_f32": ([c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                          ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(c_vp),

@@ -25,14 +25,14 @@ ARCH = "gfx950"
 WIN_TGS = list(range(7))
 
 HEADERS = ["psf_common.h", "fwd_kernels.h", "fwd_window.h", "fwd_window_launch.h", "bwd_kernels.h",
-           "bwd_window.h", "bwd_dw_chunk.h", "bwd_window_launch.h", "fwd_chain_lds.h", "fwd_chain_lds_launch.h", "mlp_fwd_x3.h", "mlp_x3_common.h", "mlp_planes.h", "x3_gemm.h",
+           "bwd_window.h", "bwd_dw_chunk.h", "bwd_window_launch.h", "fwd_chain_lds.h", "fwd_chain_lds_launch.h", "fwd_mlp_step.h", "fwd_mlp_step_launch.h", "mlp_x3_image.h", "mlp_fwd_x3.h", "mlp_x3_common.h", "mlp_planes.h", "x3_gemm.h",
            os.path.join("..", "..", "include", "psf_chord.h")]
 SOURCES = ["psf_chord.hip", "fwd_window_inst.hip", "bwd_window_inst.hip", "linear_wgrad.hip",
-           "fwd_chain_lds_inst.hip", "embed.hip", "flat_head.hip", "sum_tensors.hip", "adam.hip", "mlp_fwd.hip", "mlp_fwd_x3.hip", "mlp_bwd.hip", "mlp_wide.hip"]
+           "fwd_chain_lds_inst.hip", "fwd_mlp_step_inst.hip", "embed.hip", "flat_head.hip", "sum_tensors.hip", "adam.hip", "mlp_fwd.hip", "mlp_fwd_x3.hip", "mlp_bwd.hip", "mlp_wide.hip"]
 
 # -ffp-contract=off: products and sums stay separate roundings (bitwise parity with the CPU oracle).
 HIPCC_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
-               "-Wno-pass-failed"]
+               "-Wno-pass-failed", *os.environ.get("PSF_HIPCC_EXTRA", "").split()]  # PSF_HIPCC_EXTRA: diagnostic builds
 
 
 def csrc_hash() -> str:
@@ -77,6 +77,10 @@ def _units():
                       [f"-DPSF_TGS={t}"]))
         units.append((os.path.join(OBJ_DIR, f"bwd_window_tgs{t}.o"), os.path.join(CSRC, "bwd_window_inst.hip"),
                       [f"-DPSF_TGS={t}"]))
+    # the forward step that computes its own W tile (fwd_mlp_step_launch.h: kMlpStepTgsMax)
+    for t in range(4):
+        units.append((os.path.join(OBJ_DIR, f"fwd_mlp_step_tgs{t}.o"), os.path.join(CSRC, "fwd_mlp_step_inst.hip"),
+                      [f"-DPSF_TGS={t}", *os.environ.get("PSF_MLP_STEP_EXTRA", "").split()]))
     # dV at 512 threads x 1 row per thread for narrow rows (bwd_window_launch.h: kDvMidThreads, kDvMidTgsMax)
     for t in range(4):
         units.append((os.path.join(OBJ_DIR, f"bwd_window_mid_tgs{t}.o"), os.path.join(CSRC, "bwd_window_inst.hip"),

@@ -1,0 +1,271 @@
+// fwd_mlp_step.h — forward chord step whose W tile is COMPUTED on chip from the tile's rows of `data`: W never exists in
+// memory (the reference produces W_m = fs[m](data) and hands it to spmm through memory,
+// SyntheticExperiments/psf.py:175-188, LRA/psf.py:227-240).
+//
+//   W[p,:] = B_m GELU(A_m x_p + a_m) + b_m            MLPBlock, psf.py:35-60 — on the bf16 matrix pipe at f32 accuracy
+//   out[b,p,:] = sum_k W[p,k] * V[b,(p+off_k) mod N,:] (+ res[b,p,:])          spmul/spmul_cuda.cu:20-27
+//
+// One workgroup = one tile of TR consecutive rows of one sequence, exactly the tile of fwd_window.h (LDS window for the near
+// links, far links from L2, residual fused into the store, links ascending with uncontracted multiply and add). What differs
+// is where the tile's W rows come from: instead of a DMA of TR*L floats, each wave takes TPW token tiles of 32 rows, loads
+// their `data` rows straight into MFMA operand order (lane = token, 8 consecutive features per lane and k-step), splits them
+// exactly into three bf16 terms and runs the two GEMMs of the step's MLP as mlp_fwd_x3.hip does (six-term products, GELU on
+// the accumulator registers, accumulator-as-operand for the second layer); the finished Y^T tile is written to LDS as W rows
+// of WS floats (16-byte aligned, conflict-free for the stores and for the row reads of the accumulate phase).
+//
+// Bytes per row-step: 4 (E + 2C + [res] C) instead of 4 (L + 2C + [res] C) — the step reads the 128-byte data row instead of
+// the 60-byte W row — but the producer kernel's 4 (E + M L) bytes per token (read data, write every W_m) disappear, and
+// its arithmetic now runs beside a kernel that is waiting for memory.
+//
+// Narrow rows only (C <= 32: TGS <= 3), E <= 32, h <= 128, L <= 20; tiles with rows >= N or missing channel groups take the
+// EDGE instance (clamped loads, predicated store).
+#pragma once
+
+#include "fwd_mlp_step_launch.h"
+#include "fwd_window.h"
+#include "mlp_x3_image.h"
+#include "psf_common.h"
+
+namespace psf {
+
+template <int L, int TGS>
+struct MlpStepCfg {
+  static constexpr int NT = 256, NW = 4;
+  static constexpr int R = mlp_step_rows(TGS);
+  static constexpr int TG = 1 << TGS;
+  static constexpr int RS = NT >> TGS;
+  static constexpr int TR = RS * R;
+  static constexpr int WR = 2 * TR;
+  static constexpr int KN = imin(L, ilog2_floor(TR) + 2);
+  static constexpr int NF = L - KN;
+  static constexpr int win_vecs = WR * TG;
+  static constexpr int win_bytes = win_vecs * 16;
+  static constexpr int WS = L <= 12 ? 12 : 20;  // floats per W row in LDS: 12 r and 20 r (mod 32 and mod 64) are conflict-free
+  static constexpr int w_bytes = TR * WS * 4;
+  static constexpr int TT = TR / 32;                     // token tiles per workgroup tile
+  static constexpr int G = TT >= NW ? 1 : NW / TT;       // waves per token tile: they share its hidden units
+  static constexpr int TPW = TT >= NW ? TT / NW : 1;     // token tiles per wave
+  static constexpr int part_bytes = G > 1 ? (G - 1) * TT * 32 * WS * 4 : 0;
+  static constexpr int img_off = win_bytes + w_bytes + part_bytes;
+  static_assert(TR % 32 == 0 && (TT >= NW ? TT % NW == 0 : NW % TT == 0), "token tiles divide among the waves");
+  static_assert(win_vecs % NT == 0, "window slots are a whole number of passes");
+  static_assert(L <= 20, "WS covers 20 links");
+};
+
+
+template <int L, int TGS, bool RES, bool EDGE>
+__global__ void __launch_bounds__(256, 2)
+chord_fwd_mlp_k(const float* __restrict__ X, const float* __restrict__ V, const float* __restrict__ res,
+                float* __restrict__ out, const unsigned char* __restrict__ images, const int nu, const int E, const Geom gm,
+                const Offsets offs
+                ) {
+  using namespace psf_x3;
+  using Cfg = MlpStepCfg<L, TGS>;
+  constexpr int NT = Cfg::NT, R = Cfg::R, TG = Cfg::TG, RS = Cfg::RS, TR = Cfg::TR, KN = Cfg::KN, NF = Cfg::NF;
+  constexpr int WS = Cfg::WS, TT = Cfg::TT, G = Cfg::G, TPW = Cfg::TPW;
+  using V4 = Vec<float, 4>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  V4* __restrict__ sWin = reinterpret_cast<V4*>(smem);
+  float* __restrict__ sW = reinterpret_cast<float*>(smem + Cfg::win_bytes);
+  float* __restrict__ sPart = reinterpret_cast<float*>(smem + Cfg::win_bytes + Cfg::w_bytes);
+  unsigned char* __restrict__ sImg = reinterpret_cast<unsigned char*>(smem + Cfg::img_off);
+
+  int b, tile, chunk;
+  decode_block(gm, b, tile, chunk);  // chunk == 0: rows of <= 32 channels are never split
+  const int p0 = tile * TR;
+  const int tid = threadIdx.x, lane = tid & 63, wave64 = tid & ~63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: the branches on it are scalar
+  const int c = lane & 31, half = lane >> 5;  // MLP phase: token column, k half
+  const int g = tid & (TG - 1), rs = tid >> TGS;  // accumulate phase: channel group, row slot
+  const int N = gm.N, C = gm.C;
+  const bool cg_ok = !EDGE || g < gm.CG;
+  const int cgc = cg_ok ? g : gm.CG - 1;
+  const float* __restrict__ Vb = V + (int64_t)b * gm.v_bstride;
+
+  // ---- (0a) this wave's rows of `data`, straight into B-operand order: k-step s covers e = 16 s + 8 half + (0..7) ----
+  const int grp = G == 1 ? 0 : wv / TT;  // which share of the hidden units this wave takes (wave-uniform)
+  float xv[TPW][2][8];
+#pragma unroll
+  for (int tp = 0; tp < TPW; ++tp) {
+    const int t = G == 1 ? wv * TPW + tp : wv % TT;
+    int row = p0 + 32 * t + c;
+    if (EDGE && row >= N) row = N - 1;
+    const float* __restrict__ xr = X + ((int64_t)b * N + row) * E;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int e0 = 16 * s + 8 * half;
+      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+      if (e0 < E) lo = *reinterpret_cast<const float4*>(xr + e0);
+      if (e0 + 4 < E) hi = *reinterpret_cast<const float4*>(xr + e0 + 4);
+      xv[tp][s][0] = lo.x, xv[tp][s][1] = lo.y, xv[tp][s][2] = lo.z, xv[tp][s][3] = lo.w;
+      xv[tp][s][4] = hi.x, xv[tp][s][5] = hi.y, xv[tp][s][6] = hi.z, xv[tp][s][7] = hi.w;
+    }
+  }
+
+  // ---- (0b) unit images of this step's MLP and the V window [p0, p0 + 2 TR) mod N, by LDS-DMA ----
+  const int img_vecs = nu * kImgVecs;
+  for (int v0 = 0; v0 < img_vecs; v0 += NT) {
+    const int v = v0 + tid;
+    if (v < img_vecs)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(images + 16 * (size_t)v),
+                                       (__attribute__((address_space(3))) void*)(sImg + 16 * (v0 + wave64)), 16, 0, 0);
+  }
+#pragma unroll
+  for (int n = 0; n < Cfg::win_vecs / NT; ++n) {
+    const int i = n * NT + tid;
+    const int wr = i >> TGS, gg = i & (TG - 1);
+    int src = p0 + wr;
+    if (src >= N) src -= N;
+    if (!EDGE || gg < gm.CG)
+      stage16<float, 4, true>(Vb + (int64_t)src * C + (int64_t)gg * 4, sWin + n * NT + wave64, lane);
+  }
+
+  // ---- (0c) far rows and residual -> registers ----
+  V4 far[R][NF > 0 ? NF : 1];
+  V4 rres[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int pr = p0 + j * RS + rs;
+    const int p = EDGE ? imin(pr, N - 1) : pr;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      int src = p + offs.v[KN + f];
+      if (src >= N) src -= N;
+      far[j][f] = ld<float, 4>(Vb + (int64_t)src * C + (int64_t)cgc * 4);
+    }
+    if constexpr (RES) rres[j] = ld<float, 4>(res + ((int64_t)b * N + p) * C + (int64_t)cgc * 4);
+  }
+
+  Frag3 xf[TPW][2];
+#pragma unroll
+  for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) xf[tp][s] = split_pack8(xv[tp][s]);
+
+  __syncthreads();  // images and window have landed (hipcc drains vmcnt before the barrier)
+
+  // ---- (1) the tile's W rows: W^T[o][tok] = b + sum over this wave's hidden units of B_u GELU(A_u X^T + a_u) ----
+  const int per = (nu + G - 1) / G;
+  const int u0 = imin(nu, grp * per), u1 = imin(nu, u0 + per);
+  f32x16 acc2[TPW];
+  {
+    const float* sb = reinterpret_cast<const float*>(sImg + kOffSb);  // the output bias is in every unit's image
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[tp][r] = grp == 0 ? sb[cd_row(r, half)] : 0.f;
+  }
+  for (int u = u0; u < u1; ++u) {
+    const unsigned char* img = sImg + u * kImgBytes;
+    const float* sa = reinterpret_cast<const float*>(img + kOffSa);
+    Frag3 wa[2], wb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const unsigned char* pa = img + c * kARow + 32 * s + 16 * half;
+      wa[s].t1 = *reinterpret_cast<const bf16x8*>(pa);
+      wa[s].t2 = *reinterpret_cast<const bf16x8*>(pa + kATerm);
+      wa[s].t3 = *reinterpret_cast<const bf16x8*>(pa + 2 * kATerm);
+      const unsigned char* pb = img + kOffB + ((s * 2 + half) * 32 + c) * 16;
+      wb[s].t1 = *reinterpret_cast<const bf16x8*>(pb);
+      wb[s].t2 = *reinterpret_cast<const bf16x8*>(pb + kBTerm);
+      wb[s].t3 = *reinterpret_cast<const bf16x8*>(pb + 2 * kBTerm);
+    }
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+      f32x16 acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[r] = sa[cd_row(r, half)];
+      acc1 = mfma6(wa[0], xf[tp][0], acc1);
+      acc1 = mfma6(wa[1], xf[tp][1], acc1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {  // GELU + split of registers 8s..8s+7: the B fragment of k-step s
+        float gl[8];
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+          const f32x2 y = gelu2(f32x2{acc1[8 * s + i], acc1[8 * s + i + 1]});
+          gl[i] = y.x;
+          gl[i + 1] = y.y;
+        }
+        acc2[tp] = mfma6(wb[s], split_pack8(gl), acc2[tp]);
+      }
+    }
+  }
+
+  // The lane holds W^T[o = 8 q + 4 half + (0..3)][tok = c] in registers 4 q .. 4 q + 3: one 16-byte LDS store per q.
+  constexpr int NQ = (L + 7) / 8;  // q groups that hold links < L (for either half)
+  if constexpr (G > 1) {           // several waves share a token tile: the others hand their partial sums over through LDS
+    if (grp > 0 && u0 < u1) {
+      float* dst = sPart + (((grp - 1) * TT + wv % TT) * 32 + c) * WS;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (8 * q + 4 * half < L)
+          *reinterpret_cast<float4*>(dst + 8 * q + 4 * half) =
+              make_float4(acc2[0][4 * q], acc2[0][4 * q + 1], acc2[0][4 * q + 2], acc2[0][4 * q + 3]);
+    }
+    __syncthreads();
+    if (grp == 0) {
+      for (int og = 1; og < G; ++og) {
+        if (og * per >= nu) break;  // that group had no units (wave-uniform)
+        const float* src = sPart + (((og - 1) * TT + wv % TT) * 32 + c) * WS;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (8 * q + 4 * half < L) {
+            const float4 v = *reinterpret_cast<const float4*>(src + 8 * q + 4 * half);
+            acc2[0][4 * q] += v.x, acc2[0][4 * q + 1] += v.y, acc2[0][4 * q + 2] += v.z, acc2[0][4 * q + 3] += v.w;
+          }
+      }
+    }
+  }
+  if (grp == 0) {
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+      const int t = G == 1 ? wv * TPW + tp : wv % TT;
+      float* dst = sW + (32 * t + c) * WS;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (8 * q + 4 * half < L)
+          *reinterpret_cast<float4*>(dst + 8 * q + 4 * half) =
+              make_float4(acc2[tp][4 * q], acc2[tp][4 * q + 1], acc2[tp][4 * q + 2], acc2[tp][4 * q + 3]);
+    }
+  }
+  __syncthreads();
+
+  // ---- (2) accumulate, links ascending (the arithmetic and order of fwd_window.h) ----
+  // (All R rows are finished before the stores are issued; the stores are the last instructions of the kernel.)
+  V4 acc[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int pl = j * RS + rs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j].e[i] = 0.f;
+    const float* __restrict__ wrow = sW + pl * WS;
+    // Every LDS operand of the row is in registers, and waited for in full, before the first multiply. With the reads
+    // consumed behind counted waits (s_waitcnt lgkmcnt(6), (4), ... as hipcc schedules them) this phase sporadically came out
+    // wrong in dword 0 or dword 2 of lanes 48..63 of one wave — 21 to 59 of 300 launches at N = 16384, C = 32, B = 16, with
+    // the LDS window, the W tile and the far rows all verified intact in the same launch (profiles/r04b_mixer_lds_wait.md).
+    V4 xs[KN];
+    float wk[L];
+#pragma unroll
+    for (int k = 0; k < KN; ++k) xs[k] = sWin[((pl + chord_off(k)) << TGS) + g];
+#pragma unroll
+    for (int k = 0; k < L; ++k) wk[k] = wrow[k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < KN; ++k) axpy_rn<float, 4>(acc[j], wk[k], xs[k]);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) axpy_rn<float, 4>(acc[j], wk[KN + f], far[j][f]);
+    if constexpr (RES) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j].e[i] = add_rn(acc[j].e[i], rres[j].e[i]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);  // nothing but the stores below this line: no later instruction can reuse their registers
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int p = p0 + j * RS + rs;
+    if (!EDGE || (p < N && cg_ok)) st<float, 4>(out + ((int64_t)b * N + p) * C + (int64_t)g * 4, acc[j]);
+  }
+}
+
+}  // namespace psf

@@ -1,0 +1,32 @@
+// fwd_mlp_step_launch.h — host-side interface of the forward step that computes its own W tile (fwd_mlp_step.h), for the
+// dispatcher in psf_chord.hip. The kernels are compiled per channel-group shift in fwd_mlp_step_inst.hip.
+#pragma once
+
+#include "psf_common.h"
+
+namespace psf {
+
+constexpr int kMlpStepTgsMax = 3;                                   // rows of <= 32 channels
+constexpr int kMlpStepLmin = 4, kMlpStepLmax = 20;                  // compiled link counts
+constexpr int mlp_step_rows(int tgs) { return tgs == 0 ? 1 : 2; }  // rows per thread: tiles of 256, 256, 128, 64 rows
+constexpr int mlp_step_tile_rows(int tgs) { return (256 >> tgs) * mlp_step_rows(tgs); }
+
+struct FwdMlpArgs {
+  const float* X;               // data [B, N, E]
+  const float* V;               // step input [B, N, C] (or [N, C] with gm.v_bstride == 0)
+  const float* res;             // residual [B, N, C] or nullptr
+  float* out;                   // [B, N, C]
+  const unsigned char* images;  // nu packed unit images of THIS step's MLP (mlp_x3_image.h)
+  int32_t nu, E;
+  Geom gm;
+  Offsets offs;
+  bool edge;
+  int wg_per_cu;
+  hipStream_t stream;
+};
+
+// Launch the instance (L, TGS). Returns hipErrorInvalidValue when it is not compiled.
+template <int TGS>
+hipError_t launch_fwd_mlp(int L, const FwdMlpArgs& a);
+
+}  // namespace psf

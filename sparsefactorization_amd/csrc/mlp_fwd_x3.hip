@@ -29,6 +29,7 @@
 #include "../../include/psf_chord.h"
 #include "mlp_fwd_x3.h"
 #include "mlp_x3_common.h"
+#include "mlp_x3_image.h"
 
 #include <atomic>
 extern std::atomic<int> psf_g_mlp_fwd_store;  // psf_chord.hip: tuning knob "mlp_fwd_store"
@@ -38,107 +39,13 @@ namespace {
 
 using namespace psf_x3;
 
-// unit image (bytes): A terms 3 x [32 j][80 B: 32 bf16 + pad] | sa 32 f32 | B' terms 3 x [2 s][2 half][32 o][8 bf16]
-// | sb 32 f32
-constexpr int kARow = 80;                  // bytes; 20-dword stride: ds_read_b128 conflict-free over 16 lanes
-constexpr int kATerm = 32 * kARow;         // 2560
-constexpr int kOffSa = 3 * kATerm;         // 7680
-constexpr int kOffB = kOffSa + 128;        // 7808
-constexpr int kBTerm = 2 * 2 * 32 * 16;    // 2048
-constexpr int kOffSb = kOffB + 3 * kBTerm; // 13952
-constexpr int kImgBytes = kOffSb + 128;    // 14080
-constexpr int kImgVecs = kImgBytes / 16;   // 880
 constexpr int kScr = 32 * 36;              // per-wave scratch floats: X staging [tok][36], Y transpose [tok][33]
-
-struct X3Mlp {
-  const float* A;
-  const float* a;
-  const float* B;
-  const float* b;
-  float* Y;
-  int32_t h, O;
-};
-
-struct X3Args {
-  X3Mlp m[32];
-  // unit -> MLP | hidden block << 8 | (last unit of its MLP) << 16. Dwords: a byte table indexed by the unit counter is read
-  // with global_load_ubyte + s_waitcnt vmcnt(0) (a full memory round trip per unit); a dword table with one s_load_dword.
-  uint32_t unit[128];
-  const float* X;
-  unsigned char* images;
-  int64_t T;
-  int32_t E, U;
-};
 
 // 4-byte-aligned vectors: hipcc emits global_store_dwordx4 / x3 / x2 for them (rows of O floats are 16-byte aligned only
 // when O is a multiple of 4; gfx950 stores unaligned vectors)
 struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
 struct __attribute__((packed, aligned(4))) F3u { float x, y, z; };
 struct __attribute__((packed, aligned(4))) F2u { float x, y; };
-
-// GELU(x) = x Phi(x) for a PAIR of values, on packed f32 math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two
-// elements per instruction — the kernel is VALU-issue-bound, rocprofv3: ~70 % VALU-busy, 22 % matrix-pipe-busy).
-// Phi by Abramowitz & Stegun 26.2.17 (the normal-CDF form of 7.1.26, |error| <= 7.5e-8):
-//   t = 1 / (1 + 0.2316419 |x|),  q = exp(-x^2/2)/sqrt(2 pi) * (b1 t + ... + b5 t^5),  Phi = x >= 0 ? 1 - q : q
-// with 1/sqrt(2 pi) folded into the b's and exp as exp2(x^2 * -0.5 log2 e): 19 instructions per pair.
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
-  f32x2 t;
-  t.x = __builtin_amdgcn_rcpf(fmaf(fabsf(x.x), 0.2316419f, 1.0f));
-  t.y = __builtin_amdgcn_rcpf(fmaf(fabsf(x.y), 0.2316419f, 1.0f));
-  const f32x2 B5 = {0.53070271f, 0.53070271f}, B4 = {-0.72657602f, -0.72657602f}, B3 = {0.71070687f, 0.71070687f},
-              B2 = {-0.14224837f, -0.14224837f}, B1 = {0.12741479f, 0.12741479f};
-  f32x2 p = __builtin_elementwise_fma(B5, t, B4);
-  p = __builtin_elementwise_fma(p, t, B3);
-  p = __builtin_elementwise_fma(p, t, B2);
-  p = __builtin_elementwise_fma(p, t, B1);
-  p = p * t;
-  const f32x2 c2 = {-0.72134752044448170368f, -0.72134752044448170368f};
-  const f32x2 arg = (x * x) * c2;
-  f32x2 e;
-  e.x = __builtin_amdgcn_exp2f(arg.x);
-  e.y = __builtin_amdgcn_exp2f(arg.y);
-  const f32x2 half2 = {0.5f, 0.5f};
-  f32x2 dlt = half2 - p * e;  // 0.5 - q >= 0
-  dlt.x = copysignf(dlt.x, x.x);
-  dlt.y = copysignf(dlt.y, x.y);
-  return x * (half2 + dlt);  // Phi = 0.5 + sign(x) (0.5 - q)
-}
-
-// One workgroup per unit: split the weights and write them in operand order.
-__global__ void __launch_bounds__(256) x3_pack_k(const X3Args a) {
-  const int u = blockIdx.x;
-  const X3Mlp d = a.m[a.unit[u] & 0xff];
-  const int ht = 32 * (int)((a.unit[u] >> 8) & 0xff), E = a.E;
-  unsigned char* img = a.images + (size_t)u * kImgBytes;
-  uint16_t* img16 = reinterpret_cast<uint16_t*>(img);
-  float* img32 = reinterpret_cast<float*>(img);
-  // A terms: [j][e]
-  for (int i = threadIdx.x; i < 32 * 40; i += 256) {
-    const int j = i / 40, e = i - j * 40;
-    const float v = (e < E && ht + j < d.h) ? d.A[(ht + j) * E + e] : 0.f;
-    uint32_t t1, t2, t3;
-    split3(v, t1, t2, t3);
-    img16[(0 * kATerm + j * kARow) / 2 + e] = bf16_bits(t1);
-    img16[(1 * kATerm + j * kARow) / 2 + e] = bf16_bits(t2);
-    img16[(2 * kATerm + j * kARow) / 2 + e] = bf16_bits(t3);
-  }
-  for (int j = threadIdx.x; j < 32; j += 256) {
-    img32[kOffSa / 4 + j] = ht + j < d.h ? d.a[ht + j] : 0.f;
-    img32[kOffSb / 4 + j] = j < d.O ? d.b[j] : 0.f;
-  }
-  // B' terms: [s][half][o][i] = B[o][ht + rho], rho = (i&3) + 16 s + 8 (i>>2) + 4 half
-  for (int q = threadIdx.x; q < 2 * 2 * 32 * 8; q += 256) {
-    const int i = q & 7, o = (q >> 3) & 31, hf = (q >> 8) & 1, s = q >> 9;
-    const int rho = (i & 3) + 16 * s + 8 * (i >> 2) + 4 * hf;
-    const float v = (o < d.O && ht + rho < d.h) ? d.B[o * d.h + ht + rho] : 0.f;
-    uint32_t t1, t2, t3;
-    split3(v, t1, t2, t3);
-    img16[(kOffB + 0 * kBTerm) / 2 + q] = bf16_bits(t1);
-    img16[(kOffB + 1 * kBTerm) / 2 + q] = bf16_bits(t2);
-    img16[(kOffB + 2 * kBTerm) / 2 + q] = bf16_bits(t3);
-  }
-}
 
 #ifdef PSF_X3F_TRACE  // profiles/x3flab.hip: shader-clock timestamps of one unit of one workgroup, per wave
 __device__ unsigned long long psf_x3f_trace[4][16];
@@ -414,54 +321,42 @@ x3_fwd_k(const X3Args a) {
   }
 }
 
-struct Plan {
-  int U;
-  uint8_t unit_k[128], unit_hb[128], unit_last[128];
-};
-
-bool make_plan(int32_t E, int32_t K, const int32_t* h, const int32_t* O, Plan* p) {
-  if (E < 4 || E > 32 || (E & 3) || K < 1 || K > 32 || !h || !O) return false;
-  p->U = 0;
-  for (int k = 0; k < K; ++k) {
-    if (h[k] < 1 || h[k] > 128 || O[k] < 1 || O[k] > 32) return false;
-    const int nb = (h[k] + 31) / 32;
-    for (int hb = 0; hb < nb; ++hb) {
-      p->unit_k[p->U] = (uint8_t)k;
-      p->unit_hb[p->U] = (uint8_t)hb;
-      p->unit_last[p->U] = hb == nb - 1;
-      ++p->U;
-    }
-  }
-  return true;
-}
+static_assert(kX3ImageBytes == kImgBytes, "mlp_fwd_x3.h states the image size for callers outside this file");
 
 }  // namespace
 
 int64_t psf_x3_mlp_fwd_workspace(int32_t E, int32_t K, const int32_t* h, const int32_t* O) {
-  Plan p;
-  if (!make_plan(E, K, h, O, &p)) return -1;
+  X3Plan p;
+  if (!x3_make_plan(E, K, h, O, &p)) return -1;
   return (int64_t)p.U * kImgBytes;
+}
+
+hipError_t psf_x3_pack_launch(int32_t E, int32_t K, const float* const* A, const float* const* a, const float* const* B,
+                              const float* const* b, const int32_t* h, const int32_t* O, void* workspace,
+                              int32_t* first_unit, hipStream_t s) {
+  X3Plan p;
+  if (!x3_make_plan(E, K, h, O, &p)) return hipErrorInvalidValue;
+  X3Args args;
+  x3_fill_args(p, nullptr, 0, E, K, A, a, B, b, h, O, nullptr, workspace, &args);
+  if (first_unit)
+    for (int k = 0; k <= K; ++k) first_unit[k] = p.first_unit[k];
+  hipLaunchKernelGGL(x3_pack_k, dim3(p.U), dim3(256), 0, s, args);
+  return hipGetLastError();
 }
 
 hipError_t psf_x3_mlp_fwd_launch(const float* X, int64_t T, int32_t E, int32_t K, const float* const* A,
                                  const float* const* a, const float* const* B, const float* const* b, const int32_t* h,
-                                 const int32_t* O, float* const* Y, void* workspace, hipStream_t s) {
-  Plan p;
-  if (!make_plan(E, K, h, O, &p)) return hipErrorInvalidValue;
+                                 const int32_t* O, float* const* Y, void* workspace, hipStream_t s, bool packed) {
+  X3Plan p;
+  if (!x3_make_plan(E, K, h, O, &p)) return hipErrorInvalidValue;
   X3Args args;
-  for (int k = 0; k < 32; ++k) args.m[k] = X3Mlp{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
-  for (int k = 0; k < K; ++k) args.m[k] = X3Mlp{A[k], a[k], B[k], b[k], Y[k], h[k], O[k]};
-  for (int u = 0; u < 128; ++u) {
-    args.unit[u] = u < p.U ? ((uint32_t)p.unit_k[u] | ((uint32_t)p.unit_hb[u] << 8) | ((uint32_t)p.unit_last[u] << 16)) : 0u;
+  x3_fill_args(p, X, T, E, K, A, a, B, b, h, O, Y, workspace, &args);
+  hipError_t e = hipSuccess;
+  if (!packed) {
+    hipLaunchKernelGGL(x3_pack_k, dim3(p.U), dim3(256), 0, s, args);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
   }
-  args.X = X;
-  args.images = reinterpret_cast<unsigned char*>(workspace);
-  args.T = T;
-  args.E = E;
-  args.U = p.U;
-  hipLaunchKernelGGL(x3_pack_k, dim3(p.U), dim3(256), 0, s, args);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
   const int64_t tiles = (T + 31) / 32;
   const int mode = psf_g_mlp_fwd_store.load();
   // Tiles per wave. With the direct stores (mode 1) the one-tile instance needs 146 registers, so THREE workgroups share a CU

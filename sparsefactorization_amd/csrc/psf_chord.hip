@@ -13,7 +13,9 @@
 #include "bwd_window_launch.h"
 #include "fwd_chain_lds_launch.h"
 #include "fwd_kernels.h"
+#include "fwd_mlp_step_launch.h"
 #include "fwd_window_launch.h"
+#include "mlp_fwd_x3.h"
 
 using namespace psf;
 
@@ -63,6 +65,7 @@ std::atomic<int> g_fwd_wg_limit{0};
 std::atomic<int> g_bwd_fused_wg_limit{0};  // fused backward step: 0 = whatever fits (five of 256 threads at C = 8), n = at most n
 // Per-step launches of a chain: 1 = alternate the direction in which each XCD walks its tile range
 std::atomic<int> g_chain_zigzag{1};
+std::atomic<int> g_mixer_wg_limit{0};  // step kernel that computes its own W (fwd_mlp_step.h): 0 = whatever fits, n = at most n per CU
 thread_local bool t_walk_backwards = false;  // set by chain_impl around the launches of odd steps
 
 }  // namespace
@@ -94,6 +97,7 @@ Knob g_knobs[] = {
     {"dw_tgs", &g_dw_tgs, 0, 5},
     {"fwd_wg_limit", &g_fwd_wg_limit, 0, 4},
     {"chain_zigzag", &g_chain_zigzag, 0, 1},
+    {"mixer_wg_limit", &g_mixer_wg_limit, 0, 4},
     {"chain_fused", &g_chain_fused, 0, 2},
     {"chain_cc", &g_chain_cc, 0, 1},
     {"mlp_variant", &psf_g_mlp_variant, 0, 3},
@@ -647,6 +651,50 @@ int chain_impl(const T* const* W_steps, const T* V0, T* const* out_steps, int32_
   return PSF_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// the mixer with W computed inside the step (fwd_mlp_step.h)
+// ------------------------------------------------------------------------------------------------------
+struct MixerPlan {
+  int tgs, TR, KN, units;  // units = packed images over all M + 1 MLPs
+};
+
+// Whether the fused-step path covers the shape; fills *mp. Mirrors the limits stated in include/psf_chord.h.
+bool plan_mixer(int64_t N, int32_t E, int32_t M, const int32_t* h, int64_t C, int32_t L, MixerPlan* mp) {
+  if (!h || M < 1 || M > 31 || E < 4 || E > 32 || (E & 3) || C < 4 || C > 32 || (C & 3) || L < kMlpStepLmin || L > kMlpStepLmax ||
+      N < 1 || N > (int64_t)1 << 30)
+    return false;
+  const int tgs = ceil_log2(C / 4);
+  if (tgs > kMlpStepTgsMax) return false;
+  const int TR = mlp_step_tile_rows(tgs);
+  if (N < 2 * (int64_t)TR) return false;  // the window may wrap at most once
+  int KN = 2;
+  for (int t = TR; t > 1; t >>= 1) ++KN;
+  if (KN > L) KN = L;
+  Offsets offs;
+  make_offsets(N, L, nullptr, &offs);
+  for (int k = 0; k < KN; ++k)
+    if (offs.v[k] != chord_off(k)) return false;  // near offsets are compile-time constants in the window kernels
+  int units = 0;
+  for (int k = 0; k <= M; ++k) {
+    if (h[k] < 1 || h[k] > 128) return false;
+    units += (h[k] + 31) / 32;
+  }
+  if (units > 128) return false;
+  mp->tgs = tgs, mp->TR = TR, mp->KN = KN, mp->units = units;
+  return true;
+}
+
+hipError_t launch_mlp_step(int tgs, int L, const FwdMlpArgs& a) {
+  switch (tgs) {
+    case 0: return launch_fwd_mlp<0>(L, a);
+    case 1: return launch_fwd_mlp<1>(L, a);
+    case 2: return launch_fwd_mlp<2>(L, a);
+    case 3: return launch_fwd_mlp<3>(L, a);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------
@@ -764,6 +812,77 @@ int psf_chord_spmm_bwd_far_f32(const float* dZ, const float* W, const float* V, 
                                const float* w_far, int32_t far_k0, void* stream) {
   if (w_far && !aligned_to(w_far, 4)) return fail(PSF_E_ALIGN, "w_far must be aligned to the element size");
   return bwd_impl<float>(dZ, W, V, dW, dV, B, N, L, C, v_batch_stride, offsets, stream, w_far, far_k0);
+}
+
+int64_t psf_mixer_fwd_workspace(int64_t N, int32_t E, int32_t M, const int32_t* h, int64_t C, int32_t L) {
+  MixerPlan mp;
+  if (!plan_mixer(N, E, M, h, C, L, &mp)) return -1;
+  return (int64_t)mp.units * kX3ImageBytes;
+}
+
+int psf_mixer_fwd_f32(const float* X, int64_t B, int64_t N, int32_t E, int32_t M, const float* const* A,
+                      const float* const* a, const float* const* Bw, const float* const* b, const int32_t* h, int64_t C,
+                      int32_t L, int32_t use_residual, float* V0, float* const* out_steps, void* workspace,
+                      int64_t workspace_bytes, void* stream) {
+  if (!X || !A || !a || !Bw || !b || !h || !V0 || !out_steps || !workspace) return fail(PSF_E_NULL, "psf_mixer_fwd: NULL argument");
+  MixerPlan mp;
+  if (!plan_mixer(N, E, M, h, C, L, &mp))
+    return fail(PSF_E_SHAPE, "psf_mixer_fwd: shape outside the fused path (N=%lld E=%d M=%d C=%lld L=%d; see psf_mixer_fwd_workspace)",
+                (long long)N, (int)E, (int)M, (long long)C, (int)L);
+  if (int rc = check_dims(B, N, L, C, N * C)) return rc;
+  if (B == 0) return PSF_OK;
+  if (workspace_bytes < (int64_t)mp.units * kX3ImageBytes || !aligned_to(workspace, 16))
+    return fail(PSF_E_SHAPE, "psf_mixer_fwd: workspace too small (psf_mixer_fwd_workspace) or not 16-byte aligned");
+  if (!aligned_to(X, 16) || !aligned_to(V0, 16)) return fail(PSF_E_ALIGN, "psf_mixer_fwd: X and V0 must be 16-byte aligned");
+  if (B * N > (int64_t)1 << 40) return fail(PSF_E_SHAPE, "psf_mixer_fwd: B*N too large");
+  for (int k = 0; k <= M; ++k)
+    if (!A[k] || !a[k] || !Bw[k] || !b[k]) return fail(PSF_E_NULL, "psf_mixer_fwd: NULL layer pointer (MLP %d)", k);
+  for (int m = 0; m < M; ++m) {
+    if (!out_steps[m]) return fail(PSF_E_NULL, "psf_mixer_fwd: step %d: NULL output", m);
+    if (!aligned_to(out_steps[m], 16)) return fail(PSF_E_ALIGN, "psf_mixer_fwd: step %d: output not 16-byte aligned", m);
+    if (out_steps[m] == V0) return fail(PSF_E_ALIAS, "psf_mixer_fwd: step %d: out aliases V0", m);
+    if (m > 0 && out_steps[m] == out_steps[m - 1]) return fail(PSF_E_ALIAS, "psf_mixer_fwd: step %d: out aliases the step's input", m);
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+
+  // (1) all M + 1 weight sets -> unit images (one launch); (2) V0 = g(X) from the first of them
+  int32_t O[32], first_unit[33];
+  O[0] = (int32_t)C;
+  for (int k = 1; k <= M; ++k) O[k] = L;
+  hipError_t e = psf_x3_pack_launch(E, M + 1, A, a, Bw, b, h, O, workspace, first_unit, s);
+  if (e != hipSuccess) return fail_hip(e, "psf_mixer_fwd: pack");
+  float* y0[1] = {V0};
+  e = psf_x3_mlp_fwd_launch(X, B * N, E, 1, A, a, Bw, b, h, O, y0, workspace, s, /*packed=*/true);
+  if (e != hipSuccess) return fail_hip(e, "psf_mixer_fwd: g");
+
+  // (3) the M steps
+  Offsets offs;
+  make_offsets(N, L, nullptr, &offs);
+  WinPick pk;
+  pk.tgs = mp.tgs, pk.rows = mlp_step_rows(mp.tgs), pk.nt = 256, pk.TR = mp.TR, pk.KN = mp.KN;
+  pk.tiles_full = (int)(N / mp.TR);
+  pk.ragged = (N % mp.TR) != 0;
+  const int TG = 1 << mp.tgs;
+  pk.all_edge = ((C / 4) % TG) != 0 || !g_fwd_split.load() || ragged_in_one_launch(pk.ragged, B, N, E, C);  // (E: this step moves the data row, not the W row)
+  for (int m = 0; m < M; ++m) {
+    FwdMlpArgs fa;
+    fa.X = X;
+    fa.V = m == 0 ? V0 : out_steps[m - 1];
+    fa.res = use_residual ? V0 : nullptr;
+    fa.out = out_steps[m];
+    fa.images = reinterpret_cast<const unsigned char*>(workspace) + (size_t)first_unit[m + 1] * kX3ImageBytes;
+    fa.nu = first_unit[m + 2] - first_unit[m + 1];
+    fa.E = E;
+    fa.offs = offs;
+    fa.wg_per_cu = g_mixer_wg_limit.load();
+    fa.stream = s;
+    t_walk_backwards = (m & 1) != 0;  // zigzag, as chain_impl
+    const int rc = window_launches(pk, pk.all_edge, B, N, L, C, N * C, false, &fa.gm, &fa.edge,
+                                   [&] { return launch_mlp_step(mp.tgs, L, fa); }, "chord_fwd_mlp launch");
+    t_walk_backwards = false;
+    if (rc) return rc;
+  }
+  return PSF_OK;
 }
 
 int psf_set_tuning(const char* key, int32_t value) {

@@ -30,7 +30,7 @@ from typing import List, Sequence, Union
 import torch
 from torch import nn
 
-from . import _lib, fused_mlp
+from . import _lib, fused_mixer, fused_mlp
 from .chord import chord_chain, chord_spmm, get_chord_indices_assym
 from .token_linear import TokenEmbedding, TokenLinear, embed_tokens
 
@@ -194,6 +194,14 @@ class _ChordMixer(nn.Module):
             return outs[0], outs[1:]
         return self.g(data), self.link_weights(data)
 
+    def mix_from_data(self, data: torch.Tensor, use_residuals: bool):
+        """V_M straight from ``data`` with every W_m computed inside its chain step and never written (fused_mixer.py,
+        csrc/fwd_mlp_step.h) — psf.py:165-188 in M + 2 launches. None when that path does not apply (a gradient is
+        needed, shapes outside its limits): the caller then runs ``produce`` + ``mix``."""
+        if self.fused_chain and fused_mixer.eligible(data, self.g, list(self.fs)):
+            return fused_mixer.mixer_forward(data, self.g, list(self.fs), use_residuals)
+        return None
+
     def mix(self, data: torch.Tensor, V: torch.Tensor, use_residuals: bool, links=None) -> torch.Tensor:
         """The hot loop of PSFNet.forward (SyntheticExperiments/psf.py:167-188). ``links`` may carry
         precomputed W_m (from ``link_weights``)."""
@@ -251,8 +259,10 @@ class SyntheticPSFNet(_ChordMixer):
             data = self.init_linear(data)
         if self.use_pos_embedding and not pos_done:
             data = data + self.pos_embedding.weight.unsqueeze(0)  # == pos_embedding(arange(n_vec)) per sample
-        V, links = self.produce(data)
-        V = self.mix(data, V, self.use_residuals, links)
+        V = self.mix_from_data(data, self.use_residuals)
+        if V is None:
+            V, links = self.produce(data)
+            V = self.mix(data, V, self.use_residuals, links)
         return _flat_head(self.final, V.reshape(V.size(0), -1))
 
 
@@ -312,6 +322,10 @@ class _TokenPSFNet(_ChordMixer):
         list it is filled with the W_m that were used."""
         data = embed_tokens(data, self.embedding, self.pos_embedding.weight if self.use_pos_embedding else None)
         data = self.dropout1(data)
+        if links is None and not (self.training and self.dropout2.p > 0):  # dropout2 sits between g and the loop
+            V = self.mix_from_data(data, self.use_residuals)
+            if V is not None:
+                return self.dropout3(V)
         V, produced = self.produce(data)
         V = self.dropout2(V)
         if links is not None:  # the caller wants the W_m (attention-map extraction)
@@ -395,8 +409,10 @@ class AttentionBlockPSF(_ChordMixer):
     def forward(self, data):
         data = embed_tokens(data, self.embedding, self.apc_embedding.weight)
         data = self.dropout1(data)
-        V, links = self.produce(data)
-        V = self.mix(data, self.dropout2(V), self.use_residuals, links)
+        V = None if (self.training and self.dropout2.p > 0) else self.mix_from_data(data, self.use_residuals)
+        if V is None:
+            V, links = self.produce(data)
+            V = self.mix(data, self.dropout2(V), self.use_residuals, links)
         return self.dropout3(V)
 
 

@@ -93,6 +93,35 @@ def test_argument_validation_returns_codes_not_crashes(lib):
     assert c(None, None, None, 0, 0, 1, 8, 4, 4, 32, None, None) == 0          # M == 0
 
 
+def test_mixer_entry_point_states_its_limits_without_touching_the_gpu(lib):
+    """psf_mixer_fwd_workspace returns -1 outside the fused path's limits (include/psf_chord.h); psf_mixer_fwd_f32 rejects
+    NULL tables, short workspaces, misaligned and aliased buffers before any HIP call."""
+    i32, vp = ctypes.c_int32, ctypes.c_void_p
+    h = (i32 * 3)(32, 32, 32)
+    assert lib.psf_mixer_fwd_workspace(16384, 32, 2, h, 8, 15) == 3 * 14080
+    assert lib.psf_mixer_fwd_workspace(1024, 32, 2, (i32 * 3)(128, 128, 128), 32, 12) == 12 * 14080
+    assert lib.psf_mixer_fwd_workspace(128, 32, 2, h, 8, 8) == -1      # N < two tiles of 256 rows
+    assert lib.psf_mixer_fwd_workspace(512, 32, 2, h, 8, 10) > 0       # exactly two tiles
+    assert lib.psf_mixer_fwd_workspace(16384, 48, 2, h, 8, 15) == -1   # E > 32
+    assert lib.psf_mixer_fwd_workspace(16384, 30, 2, h, 8, 15) == -1   # E not a multiple of 4
+    assert lib.psf_mixer_fwd_workspace(16384, 32, 2, h, 64, 15) == -1  # C > 32
+    assert lib.psf_mixer_fwd_workspace(16384, 32, 2, h, 8, 21) == -1   # L > 20
+    assert lib.psf_mixer_fwd_workspace(16384, 32, 2, (i32 * 3)(32, 200, 32), 8, 15) == -1  # hidden > 128
+    assert lib.psf_mixer_fwd_workspace(16384, 32, 2, None, 8, 15) == -1
+    one, two, three = vp(16), vp(32), vp(48)
+    tab = (vp * 3)(16, 16, 16)
+    outs = (vp * 2)(32, 48)
+    f = lib.psf_mixer_fwd_f32
+    ws = 3 * 14080
+    assert f(None, 1, 16384, 32, 2, tab, tab, tab, tab, h, 8, 15, 1, one, outs, three, ws, None) == -1
+    assert f(one, 1, 128, 32, 2, tab, tab, tab, tab, h, 8, 8, 1, two, outs, three, ws, None) == -2 and b"fused path" in lib.psf_last_error()
+    assert f(one, 1, 16384, 32, 2, tab, tab, tab, tab, h, 8, 15, 1, two, outs, three, ws - 16, None) == -2  # workspace too small
+    assert f(vp(20), 1, 16384, 32, 2, tab, tab, tab, tab, h, 8, 15, 1, two, outs, three, ws, None) == -4    # X misaligned
+    assert f(one, 1, 16384, 32, 2, tab, tab, tab, tab, h, 8, 15, 1, two, (vp * 2)(32, 32), three, ws, None) == -3  # out aliases V0
+    assert f(one, 1, 16384, 32, 2, tab, tab, tab, tab, h, 8, 15, 1, two, (vp * 2)(64, 64), three, ws, None) == -3  # step in == out
+    assert f(one, 0, 16384, 32, 2, tab, tab, tab, tab, h, 8, 15, 1, two, outs, three, ws, None) == 0        # empty batch
+
+
 def test_producer_entry_points_validate_before_touching_the_gpu(lib):
     """psf_mlp_fwd_f32 / psf_mlp_bwd_f32 / psf_linear_wgrad_strided_f32: sizes outside the kernels' limits, NULL
     tables and short workspaces come back as PSF_E_* codes (no HIP call has been made at that point)."""

@@ -1,0 +1,165 @@
+"""GPU: the mixer whose steps compute their own W tile (psf_mixer_fwd_f32, csrc/fwd_mlp_step.h)
+against the CPU oracle's chain fed with W_m = fs[m](data) evaluated in float64.
+
+What is compared: V_M of ``V = g(data); for m: V = spmm(idx, fs[m](data), V) (+ V0)`` (SyntheticExperiments/psf.py:165-188).
+Reference: the MLPs in float64 torch on the CPU, their outputs rounded to f32, then the oracle's f32 chain (links ascending).
+Tolerance: max|a - b| <= 1e-5 max|ref| (BASELINE.json) — the fused path's W carries the split-bf16 GEMMs' ~1e-7 relative
+error instead of the f32 rounding of a float64 result, everything after it is the oracle's arithmetic in the oracle's order.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from conftest import rel_inf
+from oracle import chord_oracle as oc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _blocks(E, h, C, L, M, seed):
+    from sparsefactorization_amd.psfnet import MLPBlock
+    torch.manual_seed(seed)
+    g = MLPBlock([h, 'GELU'], E, C)
+    fs = [MLPBlock([h, 'GELU'], E, L) for _ in range(M)]
+    return g, fs
+
+
+def _reference(x, g, fs, residual):
+    """float64 MLPs on the CPU -> f32 operands -> the oracle's chain."""
+    B, N, _ = x.shape
+    with torch.no_grad():
+        x64 = x.double()
+        V0 = g.double()(x64).float().numpy()
+        Ws = [f.double()(x64).float().numpy() for f in fs]
+        g.float()
+        for f in fs:
+            f.float()
+    L = Ws[0].shape[-1]
+    rows, cols = oc.chord_indices(N, L)
+    index = np.stack([rows, cols])
+    return oc.chain(index, np.stack(Ws), V0, residual)[-1], V0
+
+
+# (name, B, N, E, h, C, L, M, residual) — BASELINE configs[1] / [4] (Adding, Temporal Order), the Pathfinder, CIFAR-10, IMDb
+# (ragged N, residual) and genome networks, plus shapes that exercise partial feature groups, channel groups that are
+# not a power of two, a hidden layer that is not a multiple of 32 and the smallest legal N (two tiles)
+CASES = [
+    ("cfg2", 3, 16384, 32, 32, 8, 15, 14, True),
+    ("pathfinder", 3, 1024, 32, 128, 32, 12, 11, False),
+    ("cifar10", 3, 1024, 16, 16, 16, 11, 10, False),
+    ("imdb", 2, 4097, 32, 128, 32, 13, 12, True),
+    ("genome", 1, 16384, 32, 32, 32, 15, 14, False),
+    ("odd", 2, 600, 12, 40, 12, 9, 5, True),
+    ("c4", 2, 1000, 8, 24, 4, 10, 4, False),
+    ("two_tiles", 2, 512, 32, 32, 8, 10, 9, True),
+    ("h96", 2, 2048, 32, 96, 32, 12, 3, True),
+]
+
+
+@pytest.mark.parametrize("name,B,N,E,h,C,L,M,residual", CASES, ids=[c[0] for c in CASES])
+def test_mixer_matches_the_oracle_chain_fed_with_float64_mlp_w(gpu, name, B, N, E, h, C, L, M, residual):
+    from sparsefactorization_amd import fused_mixer
+    g, fs = _blocks(E, h, C, L, M, seed=11)
+    x = torch.randn(B, N, E, generator=torch.Generator().manual_seed(5))
+    want, _ = _reference(x, g, fs, residual)
+    g.to(gpu)
+    for f in fs:
+        f.to(gpu)
+    xd = x.to(gpu)
+    with torch.no_grad():
+        assert fused_mixer.eligible(xd, g, fs), "the fused path must cover this shape"
+        got = fused_mixer.mixer_forward(xd, g, fs, residual).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_inf(got, want) <= TOL, f"{name}: rel {rel_inf(got, want):.3e}"
+
+
+def test_mixer_equals_producer_plus_chain_closely(gpu):
+    """The same network through the two routes of this package: W_m written by psf_mlp_fwd_f32 and read by the chain, and W_m
+    computed inside the step. Same split-bf16 arithmetic for W, same chain order: they agree far below the parity bar."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import fused_mixer, fused_mlp
+    g, fs = _blocks(32, 32, 8, 15, 14, seed=3)
+    g.to(gpu)
+    for f in fs:
+        f.to(gpu)
+    x = torch.randn(2, 16384, 32, device=gpu)
+    with torch.no_grad():
+        outs = fused_mlp.fused_mlp_forward(x, [g, *fs])
+        ref = sfa.chord_chain(outs[1:], outs[0], True)
+        got = fused_mixer.mixer_forward(x, g, fs, True)
+    assert rel_inf(got.cpu().numpy(), ref.cpu().numpy()) <= 2e-6
+
+
+def test_mixer_step_is_bit_stable_under_repetition(gpu):
+    """The first build of the step kernel came out wrong in a few lanes of a few launches in a hundred at these shapes
+    (profiles/r04b_mixer_lds_wait.md): 200 launches each must be bit-identical, and equal to the W-through-memory route."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import fused_mixer, fused_mlp
+    for B, N, E, h, C, L, res in [(16, 16384, 32, 32, 32, 15, False), (64, 16384, 32, 32, 8, 15, True)]:
+        g, fs = _blocks(E, h, C, L, 1, seed=0)
+        g.to(gpu)
+        fs[0].to(gpu)
+        x = torch.randn(B, N, E, device=gpu)
+        with torch.no_grad():
+            outs = fused_mlp.fused_mlp_forward(x, [g, fs[0]])
+            ref = sfa.chord_chain([outs[1]], outs[0], res)
+            bad = sum(0 if torch.equal(fused_mixer.mixer_forward(x, g, fs, res), ref) else 1 for _ in range(200))
+        assert bad == 0, f"{bad} of 200 launches differ at N={N} C={C} B={B}"
+
+
+def test_mixer_is_deterministic_and_leaves_v0_intact(gpu):
+    from sparsefactorization_amd import fused_mixer
+    g, fs = _blocks(32, 128, 32, 12, 11, seed=9)
+    g.to(gpu)
+    for f in fs:
+        f.to(gpu)
+    x = torch.randn(4, 1024, 32, device=gpu)
+    with torch.no_grad():
+        a = fused_mixer.mixer_forward(x, g, fs, False).clone()
+        b = fused_mixer.mixer_forward(x, g, fs, False).clone()
+    assert torch.equal(a, b)
+
+
+def test_nets_take_the_fused_mixer_in_inference_and_agree_with_the_unfused_route(gpu):
+    """SyntheticPSFNet (Adding, N = 2048) and the LRA network (Pathfinder widths) under no_grad: with fused_mixer on, no
+    W_m is produced (the chain entry point is never called); logits agree with the unfused route to 1e-5."""
+    from sparsefactorization_amd import chord, fused_mixer
+    from sparsefactorization_amd.psfnet import LRAPSFNet, SyntheticPSFNet
+    torch.manual_seed(0)
+    nets = [
+        (SyntheticPSFNet(1, True, 32, 2048, 11, [32, 'GELU'], [32, 'GELU'], 8, 1, 'FLATTEN', ['linear'], True, True, False,
+                         'adding'), torch.rand(4, 2048, 2, device=gpu)),
+        (LRAPSFNet(225, 32, 1024, 11, [128, 'GELU'], [128, 'GELU'], 32, 2, 'FLATTEN', ['linear'], True, False, 0.1, 0.1, 0.1,
+                   False, True, 'pathfinder'), torch.randint(0, 225, (4, 1024), device=gpu)),
+    ]
+    calls = []
+    orig = chord.chord_chain
+
+    def spy(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+
+    for net, x in nets:
+        net = net.to(gpu).eval()
+        with torch.no_grad():
+            fused_mixer.enabled = False
+            try:
+                want = net(x)
+            finally:
+                fused_mixer.enabled = True
+            import sparsefactorization_amd.psfnet as pn
+            pn.chord_chain = spy
+            try:
+                got = net(x)
+            finally:
+                pn.chord_chain = orig
+        assert not calls, "the fused mixer path must not run the W-from-memory chain"
+        assert rel_inf(got.cpu().numpy(), want.cpu().numpy()) <= 1e-5
+        net.train()  # dropout active / gradients wanted: the fused inference path must step aside
+        out = net(x)
+        assert out.requires_grad
