@@ -24,8 +24,13 @@ cpu_baseline = the reference's CPU op sequence (index_select -> mul -> scatter_a
   torch_sparse.spmm executes on CPU tensors) restated in torch CPU ops (oracle/), timed on this host's cores on a
   bounded sample of the same workload, best of a thread-count sweep; cpu_baseline_cfg1 = the same at BASELINE.json
   configs[0] (Adding N = 128, M = 7, B = 40 — the reference's own CPU-runnable case). Reported, not targeted.
-roofline.peak_measured / frac_of_measured = the same achieved rate against what a plain triad sustains on this box
-  (measured in this run, outside the timed region) — the spec peak is a datasheet figure.
+roofline.peak_measured / frac_of_measured = the same achieved rate against what the library's plain streaming kernel with
+  the step's byte mix (psf_stream_mix_f32) sustains on this box with the operands where the chain has them, measured in this
+  run outside the timed region; peak_measured_hbm_only = the same kernel with every operand beyond the Infinity Cache.
+e2e_forward = SURVEY.md §8(d)'s end-to-end variant (one GPU): the real PSFNet (seed 42) on generated Adding / Temporal-Order
+  batches at N = 16384, B = 64, both routes of the mixer (W through memory; W computed inside each chain step).
+shapes = the other timed shapes of SURVEY.md §8(d) (cfg1, cfg3 reference and BASELINE wording, cfg4 chain and attention map,
+  genome-like): us per step and algorithmic-bytes fraction, forward and fused backward (one GPU).
 train = the data-parallel leg (BASELINE.json configs[4]): Temporal Order N = 16384, B = 40 per
   GPU, full training step of the reference loop (psf_utils.py:62-71) with ONE flat RCCL gradient all-reduce;
   tokens/s over all ranks and the mean device time of the all-reduce. Not part of the headline's timed region.
@@ -51,6 +56,7 @@ L_LINKS = M_FACTORS + 1
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the rate this box sustains is measured below
 # several ranks: the data-parallel training leg is abandoned after this long (see main); the variable exists for the test of it
 TRAIN_DEADLINE_S = float(os.environ.get("PSF_BENCH_TRAIN_DEADLINE_S", "300"))
+TRAIN_ABANDONED_RC = 4  # exit code of every rank when that deadline passes (the headline line is still printed by rank 0)
 PREHEAT_S = 0.3        # seconds of untimed chains before the warm-up steps (brings the clocks up; printed in the line)
 TRAIN_PROBLEM, TRAIN_N, TRAIN_B = "order", 16384, 40  # SyntheticExperiments/synthetic_training_config.py:72-86
 
@@ -70,6 +76,7 @@ def parse_args(argv=None):
                          "Adam stay eager). Default: on when --gpus > 1 — ~150 launches per step from each of N host "
                          "processes is where the scaling of a 2.4 ms step is decided — off on one GPU")
     ap.add_argument("--no-train-graph", dest="train_graph", action="store_false")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the e2e_forward and shapes legs (one GPU only)")
     return ap.parse_args(argv)
 
 
@@ -208,18 +215,30 @@ def gpu_cfg1(device):
 
 
 def measured_bandwidth(device):
-    """What this GPU sustains on plain streaming kernels, outside the headline's timed region: a triad a = b + s*c over
-    three 384 MiB fp32 arrays (1.2 GB per pass, far beyond the 256 MiB Infinity Cache) and a copy of 512 MiB (1.07 GB read +
-    written), HIP events over 20 passes each. GB/s of bytes read + written."""
-    import torch
-    n = 96 * 1024 * 1024
-    a, b, c = (torch.empty(n, dtype=torch.float32, device=device) for _ in range(3))
-    b.fill_(1.0), c.fill_(2.0)
-    src, dst = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device=device).fill_(3.0), None
-    dst = torch.empty_like(src)
+    """What this GPU's memory system gives the forward step's byte mix, measured with the library's plain streaming kernel
+    (psf_stream_mix_f32, csrc/stream_mix.hip: reads W : V : residual = 2 : 1 : 1 and writes 1, the step's 15 : 8 : 8 : 8),
+    outside the headline's timed region, HIP events over the launches:
 
-    def timed(fn, nbytes, reps=20):
-        for _ in range(3):
+    * ``stream_hbm``: every operand beyond the 256 MiB Infinity Cache (2.5 GB footprint: W 1 GiB, the other three 512 MiB
+      each) — what HBM alone sustains for the mix;
+    * ``stream_chain_residency``: the operands placed as the chain places them — 14 steps, each with its own 63 MB W
+      slab (881 MB, streamed from HBM once per chain) and the three V-sized streams (33.5 MB each: input = the previous
+      step's output, residual, output) re-used from step to step, i.e. resident in the Infinity Cache. This is the
+      denominator of ``frac_of_measured``: the same bytes from the same places, with no gather and no LDS.
+    GB/s of bytes read + written."""
+    import ctypes
+
+    import torch
+    from sparsefactorization_amd import _lib
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    def launch(w, v, r, o, n):
+        rc = lib.psf_stream_mix_f32(w.data_ptr(), v.data_ptr(), r.data_ptr(), o.data_ptr(), n, stream)
+        _lib.check(rc, "psf_stream_mix_f32")
+
+    def timed(fn, nbytes, reps):
+        for _ in range(2):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(device)
@@ -230,11 +249,26 @@ def measured_bandwidth(device):
         torch.cuda.synchronize(device)
         return nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
-    triad = timed(lambda: torch.add(b, c, alpha=0.5, out=a), 3 * 4 * n)
-    copy = timed(lambda: dst.copy_(src), 2 * 4 * src.numel())
-    del a, b, c, src, dst
-    torch.cuda.empty_cache()
-    return {"triad": triad, "copy": copy}
+    out = {}
+    with torch.cuda.device(device):
+        n = 32 * 1024 * 1024  # vectors of 16 bytes: V-sized streams of 512 MiB, W of 1 GiB
+        w = torch.empty(8 * n, dtype=torch.float32, device=device).fill_(0.5)
+        v, r, o = (torch.empty(4 * n, dtype=torch.float32, device=device).fill_(1.0) for _ in range(3))
+        out["stream_hbm"] = timed(lambda: launch(w, v, r, o, n), 80 * n, 10)
+        del w, v, r, o
+        torch.cuda.empty_cache()
+        nv = B_PER_GPU * N_SEQ * C_CH // 4  # vectors per V-sized stream at the headline shape (33.5 MB)
+        ws = [torch.empty(8 * nv, dtype=torch.float32, device=device).fill_(0.5) for _ in range(M_FACTORS)]
+        v0, pa, pb = (torch.empty(4 * nv, dtype=torch.float32, device=device).fill_(1.0) for _ in range(3))
+
+        def chain():
+            for m in range(M_FACTORS):
+                launch(ws[m], v0 if m == 0 else (pa, pb)[(m - 1) & 1], v0, (pa, pb)[m & 1], nv)
+
+        out["stream_chain_residency"] = timed(chain, 80 * nv * M_FACTORS, 20)
+        del ws, v0, pa, pb
+        torch.cuda.empty_cache()
+    return out
 
 
 def pmc_traffic():
@@ -389,12 +423,20 @@ def run_rank(args) -> int:
                 "launch_us": launch_s * 1e6,
                 "launches": launches,
                 "frac_per_gpu": [bytes_per_launch / (ms * 1e-3 / launches) / 1e9 / HBM_PEAK_GBS for ms in per_rank_ms],
-                # the second denominator: what plain streaming kernels sustain on THIS box
-                "peak_measured": bw.get("triad") if bw else None,
-                "peak_measured_copy": bw.get("copy") if bw else None,
-                "peak_measured_how": "torch triad a = b + s*c over 3 x 384 MiB fp32 / copy of 512 MiB; bytes read + written "
-                                     "per second, HIP events over 20 passes, rank 0, outside the timed region",
-                "frac_of_measured": (achieved / bw["triad"]) if bw and bw.get("triad") else None,
+                # the second denominator: what a plain streaming kernel with the same byte mix
+                # sustains on THIS box with the operands where the chain has them (measured_bandwidth)
+                "peak_measured": bw.get("stream_chain_residency") if bw else None,
+                "peak_measured_hbm_only": bw.get("stream_hbm") if bw else None,
+                "peak_measured_how": "psf_stream_mix_f32 (in-tree, W : V : res : out = 2 : 1 : 1 : 1, no gather): "
+                                     "peak_measured = 14 steps with a 63 MB W slab each from HBM and the three 33.5 MB V-sized "
+                                     "streams re-used step to step (Infinity-Cache resident, as in the chain); "
+                                     "peak_measured_hbm_only = every operand beyond the Infinity Cache (2.5 GB footprint); "
+                                     "bytes read + written per second, HIP events, rank 0, outside the timed region",
+                "frac_of_measured": (achieved / bw["stream_chain_residency"]) if bw and bw.get("stream_chain_residency") else None,
+                "frac_of_measured_hbm_only": (achieved / bw["stream_hbm"]) if bw and bw.get("stream_hbm") else None,
+                # of the step's algorithmic bytes, the part that is re-used within 235 MB of traffic and therefore served by
+                # the 256 MiB Infinity Cache rather than HBM: input row + residual row of the 4 (L + 3C) bytes per row
+                "infinity_cache_resident_read_fraction": 2 * C_CH / (L_LINKS + 2 * C_CH),
             },
             "preheat_s": PREHEAT_S,
             "rank_ms_per_step": {"min": min(per_rank_ms) / args.steps, "max": max(per_rank_ms) / args.steps},
@@ -404,8 +446,10 @@ def run_rank(args) -> int:
 
     # The secondary legs run AFTER the headline is complete. With several ranks the training leg contains collectives
     # that no box with more than one GPU has ever run: a rank that fails inside one leaves the others
-    # waiting. A deadline guards the headline: when it passes, rank 0 prints the line with the leg marked as abandoned and
-    # every rank leaves with code 0.
+    # waiting. A deadline guards the headline: when it passes, rank 0 prints the finished line with the leg marked as
+    # abandoned — and every rank then leaves with TRAIN_ABANDONED_RC, NOT 0: a rank that is stuck in a kernel or a collective
+    # must not be recorded as a success (torch.distributed.run, self_launch and the driver all see the non-zero code; the
+    # line carries it too, as train.rc). If a real multi-GPU run ever trips this, read its records; do not re-run to see it again.
     train = None
     train_listops = None
     if args.train:
@@ -416,9 +460,10 @@ def run_rank(args) -> int:
             def abandon():
                 if rank == 0 and line is not None:
                     line["train"] = {"error": f"the training leg did not finish within {TRAIN_DEADLINE_S} s on {world} ranks; "
-                                              "abandoned so that the headline line is kept"}
+                                              "abandoned so that the headline line is kept",
+                                     "rc": TRAIN_ABANDONED_RC}
                     print(json.dumps(line), flush=True)
-                os._exit(0)
+                os._exit(TRAIN_ABANDONED_RC)
 
             guard = threading.Timer(TRAIN_DEADLINE_S, abandon)
             guard.daemon = True
@@ -428,12 +473,20 @@ def run_rank(args) -> int:
             guard.cancel()
         if world == 1:
             train_listops = listops_leg(args, device)
+    e2e, shapes = None, None
+    if world == 1 and rank == 0 and not args.no_extra_legs:
+        e2e = e2e_forward_leg(device)
+        shapes = shapes_leg(device)
 
     if rank == 0:
         if train is not None:
             line["train"] = train
         if train_listops is not None:
             line["train_listops"] = train_listops
+        if e2e is not None:
+            line["e2e_forward"] = e2e
+        if shapes is not None:
+            line["shapes"] = shapes
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             cfg1 = cpu_baseline_cfg1()
@@ -520,6 +573,144 @@ def listops_leg(args, device):
                         "ms_per_step": r["seconds"] * 1e3 / r["steps"], "device_ms_per_step": r["event_ms"] / r["steps"],
                         "steps": r["steps"], "loss": r["loss"], "hip_graph": r["hip_graph"],
                         "eager_ms_per_step": eager["seconds"] * 1e3 / eager["steps"], "eager_loss": eager["loss"]}
+    except Exception as exc:
+        out["error"] = repr(exc)
+    return out
+
+
+def e2e_forward_leg(device, reps=20):
+    """SURVEY.md §8(d) end-to-end variant: the real PSFNet (seed 42, SyntheticExperiments/psf_training.py:16,29-45) on generated
+    Adding and Temporal-Order batches (synth_data_generation.py:8-70), N = 16384, B = 64, no_grad, whole ``net(x)``:
+    tokens/s for the two routes of the mixer — W_m written by the producer kernel and read by the chain
+    (``w_through_memory``) and W_m computed inside each chain step, never in memory (``w_in_step``, psf_mixer_fwd_f32) — their
+    HBM bytes per token by the algorithmic model, the device time of the parts of the first route, and the largest relative
+    difference between the two routes' logits. One GPU, outside the headline's timed region."""
+    import torch
+    out = {}
+    try:
+        from sparsefactorization_amd import fused_mixer
+        from sparsefactorization_amd.psf_training import build_model, make_split
+        from sparsefactorization_amd.psfnet import _flat_head
+        from sparsefactorization_amd.token_linear import embed_tokens
+        from sparsefactorization_amd.train import seed_everything
+
+        def timed(fn, n=reps):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(device)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(device)
+            return e0.elapsed_time(e1) / n  # ms
+
+        B, N = B_PER_GPU, N_SEQ
+        for problem in ("adding", "order"):
+            seed_everything(42)
+            net = build_model(problem, N).to(device).eval()
+            x, _ = make_split(problem, B, N, device, 42)
+            E, C, M, L = net.embedding_size, net.n_channels_V, net.n_W, net.n_links
+            n_cls = net.n_class
+            in_bytes = 8 if problem == "adding" else 8  # [x, marker] f32 / one int64 token
+            with torch.no_grad():
+                def embed():
+                    if problem == "order":
+                        return embed_tokens(x.squeeze(-1), net.embedding, net.pos_embedding.weight)
+                    return net.init_linear(x)
+
+                data = embed()
+                V0, links = net.produce(data)
+                VM = net.mix(data, V0, net.use_residuals, links)
+                parts = {"embed": timed(embed), "producer_mlps": timed(lambda: net.produce(data)),
+                         "chain": timed(lambda: net.mix(data, V0, net.use_residuals, links)),
+                         "head": timed(lambda: _flat_head(net.final, VM.reshape(B, -1)))}
+                res = {}
+                logits = {}
+                for route, tag in (("never", "w_through_memory"), ("always", "w_in_step")):
+                    fused_mixer.route = route
+                    try:
+                        logits[tag] = net(x).float().clone()
+                        ms = timed(lambda: net(x))
+                    finally:
+                        fused_mixer.route = "auto"
+                    # algorithmic HBM bytes per token: input, data written + read, [W written + read,] V traffic of the M steps, head
+                    common = in_bytes + 4 * E + 4 * C
+                    if tag == "w_through_memory":
+                        model = common + 4 * E + 4 * (C + M * L) + M * 4 * (L + 3 * C if net.use_residuals else L + 2 * C)
+                    else:
+                        model = common + 4 * E + 4 * C + M * 4 * (E + (3 if net.use_residuals else 2) * C)
+                    res[tag] = {"ms_per_forward": ms, "tokens_per_s": B * N / (ms * 1e-3), "hbm_bytes_per_token_model": model,
+                                "achieved_GBps_of_model_bytes": model * B * N / (ms * 1e-3) / 1e9,
+                                "frac_of_hbm_peak": model * B * N / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                ref = logits["w_through_memory"]
+                rel = float((logits["w_in_step"] - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+            out[problem] = {"metric": f"PSFNet forward tokens/s, {problem} N={N} B={B} (E={E}, C={C}, M={M}, n_class={n_cls})",
+                            "unit": "tokens/s", **res, "w_through_memory_parts_ms": parts,
+                            "speedup_w_in_step": res["w_through_memory"]["ms_per_forward"] / res["w_in_step"]["ms_per_forward"],
+                            "logits_rel_diff_between_routes": rel}
+            del net, x, data, V0, links, VM
+            torch.cuda.empty_cache()
+    except Exception as exc:
+        out["error"] = repr(exc)
+    return out
+
+
+def shapes_leg(device):
+    """SURVEY.md §8(d) "other timed shapes" (reference shapes: LRA/psf_training_config.py:2-30,60-88, Genome_Clf/
+    genome_training_config.py:6-16): us per step and the fraction of 8 TB/s that the step's ALGORITHMIC bytes amount to, for
+    the forward chain (bytes 4 B N (L + 2C [+ C residual]) per step) and for one backward step with both gradients (bytes
+    4 B N (2L + 3C)). HIP events over back-to-back calls on one operand set (warm caches); ~1 s of GPU time."""
+    import torch
+    out = {}
+    try:
+        import sparsefactorization_amd as sfa
+        from sparsefactorization_amd import _lib
+        from sparsefactorization_amd.chord import _launch_bwd
+        # name, B, N, L, C, residual, attention-map mode (first operand eye(N), unbatched)
+        shapes = [("cfg1_adding_n128", 40, 128, 8, 8, True, False),
+                  ("cfg3_listops_reference", 32, 2000, 12, 128, False, False),
+                  ("cfg3_listops_baseline_wording", 32, 2048, 12, 64, False, False),
+                  ("cfg4_pathfinder_chain", 64, 1024, 12, 32, False, False),
+                  ("cfg4_pathfinder_attention_map", 8, 1024, 12, 1024, False, True),
+                  ("genome_like", 16, 16384, 15, 32, False, False)]
+
+        def timed(fn, n):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(device)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(device)
+            return e0.elapsed_time(e1) * 1e3 / n  # us
+
+        for name, B, N, L, C, res, amap in shapes:
+            M = L - 1
+            g = torch.Generator(device=device).manual_seed(7)
+            Ws = [0.1 * torch.randn(B, N, L, device=device, generator=g) for _ in range(M)]
+            V0 = torch.eye(N, device=device) if amap else torch.randn(B, N, C, device=device, generator=g)
+            with torch.no_grad():
+                t_chain = timed(lambda: sfa.chord_chain(Ws, V0, res), 20)
+                fwd_bytes = 4 * B * N * (L + 2 * C + (C if res else 0))
+                entry = {"B": B, "N": N, "L": L, "C": C, "M": M, "residual": res,
+                         "fwd_us_per_step": t_chain / M, "fwd_bytes_per_step": fwd_bytes,
+                         "fwd_frac_of_hbm_peak": fwd_bytes / (t_chain / M * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "fwd_kernel": _lib.describe_chain_fwd(B, N, L, C, M)}
+                if not amap:
+                    V = torch.randn(B, N, C, device=device, generator=g)
+                    dZ = torch.randn(B, N, C, device=device, generator=g)
+                    dW, dV = torch.empty_like(Ws[0]), torch.empty_like(V)
+                    t_bwd = timed(lambda: _launch_bwd(dZ, Ws[0], V, dW, dV, B, N, L, C, N * C, None, None, 0), 40)
+                    bwd_bytes = 4 * B * N * (2 * L + 3 * C)
+                    entry.update({"bwd_us_per_step": t_bwd, "bwd_bytes_per_step": bwd_bytes,
+                                  "bwd_frac_of_hbm_peak": bwd_bytes / (t_bwd * 1e-6) / 1e9 / HBM_PEAK_GBS})
+            out[name] = entry
+            del Ws, V0
+            torch.cuda.empty_cache()
     except Exception as exc:
         out["error"] = repr(exc)
     return out

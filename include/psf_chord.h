@@ -335,6 +335,14 @@ int psf_mlp_wide_bwd_f32(const void* saved, int64_t saved_bytes, int64_t T, int3
                          float* const* db, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * A plain streaming kernel with the forward step's byte mix, for measuring what the memory system of a box gives that
+ * mix (bench.py's second denominator; no reference counterpart). Per 16-byte output vector i it reads w[2i], w[2i+1], v[i]
+ * and r[i] and writes out[i]: W : V : residual : out = 2 : 1 : 1 : 1 (the step kernel at L = 15, C = 8 moves 15 : 8 : 8 : 8).
+ *   w [2 n_vec4] float4, v / r / out [n_vec4] float4, all 16-byte aligned; bytes moved = 80 n_vec4.
+ */
+int psf_stream_mix_f32(const float* w, const float* v, const float* r, float* out, int64_t n_vec4, void* stream);
+
+/*
  * Process-wide tuning knobs (benchmark / test use; defaults are the shipped configuration).
  *   key "fwd_variant": 0 = auto, 1 = generic direct-gather kernel, 2 = LDS-window kernel
  *   key "bwd_variant": 0 = auto (LDS-window dV / dW kernels where they apply), 1 = generic kernels
@@ -398,6 +406,8 @@ int psf_get_tuning(const char* key);
  */
 int psf_describe_fwd(int64_t B, int64_t N, int32_t L, int64_t C, int32_t elem_bytes,
                      char* buf, int32_t cap);
+/* The same for a whole f32 forward chain of M steps: names the single-launch LDS-resident kernel when the chain takes it. */
+int psf_describe_chain_fwd(int64_t B, int64_t N, int32_t L, int64_t C, int32_t M, char* buf, int32_t cap);
 
 #ifdef __cplusplus
 }

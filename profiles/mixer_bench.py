@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--limits", default="0")
     ap.add_argument("--only", default="")
+    ap.add_argument("--ablate", default="", help="comma list of mixer_ablate masks to time as extra arms (results are wrong)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     limits = [int(v) for v in args.limits.split(",")]
@@ -72,6 +73,8 @@ def main():
             arms = {"unfused": unfused, "producer": producer, "chain": chain}
             for lim in limits:
                 arms[f"fused_wg{lim}"] = (lambda lim=lim: (sfa.set_tuning("mixer_wg_limit", lim), fused())[1])
+            for ab in [int(v) for v in args.ablate.split(",") if v]:
+                arms[f"ablate{ab}"] = (lambda ab=ab: (sfa.set_tuning("mixer_ablate", ab), fused(), sfa.set_tuning("mixer_ablate", 0))[1])
             a, b = unfused(), fused()
             rel = float((a - b).abs().max() / a.abs().max())
             for fn in arms.values():

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_<tag>_mixer/ (profiles/collect_mixer.sh) -> a markdown table per route: calls, average duration and
+memory-side bytes per forward of every kernel (FETCH_SIZE x 2 per MI355X_MICROARCH.md "HBM": on gfx950 the counter reports
+half of a wide coalesced read; WRITE_SIZE as it is; both in KiB)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04e"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_mixer")
+FORWARDS = 20
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name[:name.index("(")] if "(" in name else name
+
+
+def counters(d, counter):
+    tot = defaultdict(float)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") == counter:
+                    tot[short(row["Kernel_Name"])] += float(row["Counter_Value"])
+    return tot
+
+
+print(f"# {tag} — the Adding forward (PSFNet seed 42, N = 16384, B = 64, no_grad) through the two routes of the mixer\n")
+print("Per forward; memory-side bytes = L2 <-> fabric (Infinity-Cache hits included), FETCH_SIZE doubled per the guide.\n")
+summary = {}
+for route, title in (("never", "W through memory: psf_mlp_fwd_f32 + psf_chord_chain_fwd_f32"),
+                     ("always", "W computed inside the step: psf_mixer_fwd_f32")):
+    stats = glob.glob(os.path.join(src, f"stats_{route}", "**", "*kernel_stats.csv"), recursive=True)
+    fetch = counters(os.path.join(src, f"fetch_{route}"), "FETCH_SIZE")
+    write = counters(os.path.join(src, f"write_{route}"), "WRITE_SIZE")
+    print(f"## {title}\n")
+    print("| kernel | calls / forward | avg us | us / forward | read MB / forward | written MB / forward |")
+    print("|---|---|---|---|---|---|")
+    tot_us = tot_r = tot_w = 0.0
+    if stats:
+        with open(stats[0]) as fh:
+            for row in csv.DictReader(fh):
+                k = short(row["Name"])
+                calls = float(row["Calls"]) / FORWARDS
+                avg = float(row["AverageNs"]) / 1e3
+                r = 2 * fetch.get(k, 0.0) * 1024 / FORWARDS / 1e6
+                w = write.get(k, 0.0) * 1024 / FORWARDS / 1e6
+                if calls * avg < 1.0:
+                    continue
+                tot_us += calls * avg
+                tot_r += r
+                tot_w += w
+                print(f"| `{k[:90]}` | {calls:.2f} | {avg:.1f} | {calls * avg:.1f} | {r:.0f} | {w:.0f} |")
+    print(f"| **total** | | | **{tot_us:.0f}** | **{tot_r:.0f}** | **{tot_w:.0f}** |\n")
+    summary[route] = (tot_us, tot_r, tot_w)
+if len(summary) == 2:
+    a, b = summary["never"], summary["always"]
+    print(f"Written per forward: {a[2]:.0f} MB -> {b[2]:.0f} MB; read: {a[1]:.0f} MB -> {b[1]:.0f} MB; kernel time {a[0]:.0f} us -> {b[0]:.0f} us. "
+          "The 14 W_m of this forward are 14 x 62.9 MB = 881 MB: written once and read once on the first route, absent from the second.")

@@ -72,9 +72,11 @@ SIGNATURES = {
     "psf_mlp_wide_bwd_f32": ([c_vp, c_i64, c_i64, c_i32, c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                               ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(c_vp),
                               ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp, c_i64, c_vp], ctypes.c_int),
+    "psf_stream_mix_f32": ([c_vp, c_vp, c_vp, c_vp, c_i64, c_vp], ctypes.c_int),
     "psf_set_tuning": ([ctypes.c_char_p, c_i32], ctypes.c_int),
     "psf_get_tuning": ([ctypes.c_char_p], ctypes.c_int),
     "psf_describe_fwd": ([c_i64, c_i64, c_i32, c_i64, c_i32, ctypes.c_char_p, c_i32], ctypes.c_int),
+    "psf_describe_chain_fwd": ([c_i64, c_i64, c_i32, c_i64, c_i32, ctypes.c_char_p, c_i32], ctypes.c_int),
 }
 
 
@@ -172,6 +174,12 @@ def get_tuning(key: str) -> int:
 def describe_fwd(B: int, N: int, L: int, C: int, elem_bytes: int = 4) -> str:
     buf = ctypes.create_string_buffer(256)
     check(load().psf_describe_fwd(B, N, L, C, elem_bytes, buf, 256), "psf_describe_fwd")
+    return buf.value.decode()
+
+
+def describe_chain_fwd(B: int, N: int, L: int, C: int, M: int) -> str:
+    buf = ctypes.create_string_buffer(256)
+    check(load().psf_describe_chain_fwd(B, N, L, C, M, buf, 256), "psf_describe_chain_fwd")
     return buf.value.decode()
 
 

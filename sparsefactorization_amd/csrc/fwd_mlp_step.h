@@ -57,8 +57,7 @@ template <int L, int TGS, bool RES, bool EDGE>
 __global__ void __launch_bounds__(256, 2)
 chord_fwd_mlp_k(const float* __restrict__ X, const float* __restrict__ V, const float* __restrict__ res,
                 float* __restrict__ out, const unsigned char* __restrict__ images, const int nu, const int E, const Geom gm,
-                const Offsets offs
-                ) {
+                const Offsets offs, const int ablate) {
   using namespace psf_x3;
   using Cfg = MlpStepCfg<L, TGS>;
   constexpr int NT = Cfg::NT, R = Cfg::R, TG = Cfg::TG, RS = Cfg::RS, TR = Cfg::TR, KN = Cfg::KN, NF = Cfg::NF;
@@ -95,8 +94,8 @@ chord_fwd_mlp_k(const float* __restrict__ X, const float* __restrict__ V, const 
     for (int s = 0; s < 2; ++s) {
       const int e0 = 16 * s + 8 * half;
       float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-      if (e0 < E) lo = *reinterpret_cast<const float4*>(xr + e0);
-      if (e0 + 4 < E) hi = *reinterpret_cast<const float4*>(xr + e0 + 4);
+      if (e0 < E && !(ablate & 8)) lo = *reinterpret_cast<const float4*>(xr + e0);
+      if (e0 + 4 < E && !(ablate & 8)) hi = *reinterpret_cast<const float4*>(xr + e0 + 4);
       xv[tp][s][0] = lo.x, xv[tp][s][1] = lo.y, xv[tp][s][2] = lo.z, xv[tp][s][3] = lo.w;
       xv[tp][s][4] = hi.x, xv[tp][s][5] = hi.y, xv[tp][s][6] = hi.z, xv[tp][s][7] = hi.w;
     }
@@ -131,6 +130,7 @@ chord_fwd_mlp_k(const float* __restrict__ X, const float* __restrict__ V, const 
     for (int f = 0; f < NF; ++f) {
       int src = p + offs.v[KN + f];
       if (src >= N) src -= N;
+      if (ablate & 4) src = p;  // timing only: the row itself (an L2 / window hit) instead of the far row
       far[j][f] = ld<float, 4>(Vb + (int64_t)src * C + (int64_t)cgc * 4);
     }
     if constexpr (RES) rres[j] = ld<float, 4>(res + ((int64_t)b * N + p) * C + (int64_t)cgc * 4);
@@ -155,7 +155,7 @@ chord_fwd_mlp_k(const float* __restrict__ X, const float* __restrict__ V, const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[tp][r] = grp == 0 ? sb[cd_row(r, half)] : 0.f;
   }
-  for (int u = u0; u < u1; ++u) {
+  for (int u = (ablate & 1) ? u1 : u0; u < u1; ++u) {  // ablate & 1 (timing only): no MLP arithmetic, W = bias
     const unsigned char* img = sImg + u * kImgBytes;
     const float* sa = reinterpret_cast<const float*>(img + kOffSa);
     Frag3 wa[2], wb[2];
@@ -251,6 +251,10 @@ chord_fwd_mlp_k(const float* __restrict__ X, const float* __restrict__ V, const 
     for (int k = 0; k < L; ++k) wk[k] = wrow[k];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    if (ablate & 2) {  // timing only: operands consumed, no multiply-add chain
+#pragma unroll
+      for (int k = 0; k < KN; ++k) acc[j].e[k & 3] += xs[k].e[k & 3] + wk[k];
+    } else
 #pragma unroll
     for (int k = 0; k < KN; ++k) axpy_rn<float, 4>(acc[j], wk[k], xs[k]);
 #pragma unroll

@@ -32,7 +32,7 @@ hipError_t launch_one(const FwdMlpArgs& a) {
     }
   }
   hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(256), lds, a.stream, a.X, a.V, a.res, a.out, a.images, a.nu, a.E, a.gm,
-                     a.offs);
+                     a.offs, a.ablate);
   return hipGetLastError();
 }
 

@@ -22,6 +22,7 @@ struct FwdMlpArgs {
   Offsets offs;
   bool edge;
   int wg_per_cu;
+  int ablate;  // knob "mixer_ablate": timing experiments only (non-zero gives wrong results), see fwd_mlp_step.h
   hipStream_t stream;
 };
 

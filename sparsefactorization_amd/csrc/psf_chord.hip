@@ -65,6 +65,7 @@ std::atomic<int> g_fwd_wg_limit{0};
 std::atomic<int> g_bwd_fused_wg_limit{0};  // fused backward step: 0 = whatever fits (five of 256 threads at C = 8), n = at most n
 // Per-step launches of a chain: 1 = alternate the direction in which each XCD walks its tile range
 std::atomic<int> g_chain_zigzag{1};
+std::atomic<int> g_mixer_ablate{0};    // timing experiments on that kernel: bit 0 no MLP arithmetic, 1 no multiply-add chain, 2 no far rows, 3 no data rows
 std::atomic<int> g_mixer_wg_limit{0};  // step kernel that computes its own W (fwd_mlp_step.h): 0 = whatever fits, n = at most n per CU
 thread_local bool t_walk_backwards = false;  // set by chain_impl around the launches of odd steps
 
@@ -98,6 +99,7 @@ Knob g_knobs[] = {
     {"fwd_wg_limit", &g_fwd_wg_limit, 0, 4},
     {"chain_zigzag", &g_chain_zigzag, 0, 1},
     {"mixer_wg_limit", &g_mixer_wg_limit, 0, 4},
+    {"mixer_ablate", &g_mixer_ablate, 0, 15},
     {"chain_fused", &g_chain_fused, 0, 2},
     {"chain_cc", &g_chain_cc, 0, 1},
     {"mlp_variant", &psf_g_mlp_variant, 0, 3},
@@ -875,6 +877,7 @@ int psf_mixer_fwd_f32(const float* X, int64_t B, int64_t N, int32_t E, int32_t M
     fa.E = E;
     fa.offs = offs;
     fa.wg_per_cu = g_mixer_wg_limit.load();
+    fa.ablate = g_mixer_ablate.load();
     fa.stream = s;
     t_walk_backwards = (m & 1) != 0;  // zigzag, as chain_impl
     const int rc = window_launches(pk, pk.all_edge, B, N, L, C, N * C, false, &fa.gm, &fa.edge,
@@ -922,6 +925,20 @@ int psf_describe_fwd(int64_t B, int64_t N, int32_t L, int64_t C, int32_t elem_by
     snprintf(buf, cap, "chord_fwd_generic_k<%s,VEC=%d>", elem_bytes == 4 ? "f32" : "f64", vec_ok ? vecw : 1);
   }
   return PSF_OK;
+}
+
+int psf_describe_chain_fwd(int64_t B, int64_t N, int32_t L, int64_t C, int32_t M, char* buf, int32_t cap) {
+  if (!buf || cap < 1) return fail(PSF_E_NULL, "buf is NULL");
+  if (int rc = check_dims(B, N, L, C, N * C)) return rc;
+  ChainLdsPlan plan;
+  const int cf = g_chain_fused.load();
+  if (cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, g_chain_cc.load()) &&
+      (cf == 2 || plan.chunks <= 8)) {
+    snprintf(buf, cap, "chord_chain_lds_k<f32,L=%d,CC=%d,R=%d> one launch for all %d steps, %d threads, %d workgroup(s) per sequence",
+             (int)L, plan.cc, plan.rows, (int)M, plan.threads, plan.chunks);
+    return PSF_OK;
+  }
+  return psf_describe_fwd(B, N, L, C, 4, buf, cap);
 }
 
 }  // extern "C"

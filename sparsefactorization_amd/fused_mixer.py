@@ -17,6 +17,11 @@ from . import _lib
 from .fused_mlp import _needs_grad, _params_of, _ptrs, _two_layer
 
 enabled = True  # module-level switch (tests / A-B timing)
+#: "auto": take the fused path where it is measured faster than psf_mlp_fwd_f32 + psf_chord_chain_fwd_f32 end to end
+#: (profiles/r04c_mixer_ablate.log: long sequences of narrow rows with one hidden unit — the step kernel stages its MLP's
+#: weight image per tile, 14 KB per 32 hidden rows, which short tiles (C = 32: 64 rows) and 128-wide hidden layers do not
+#: amortise); "always": wherever the shape is covered; "never".
+route = "auto"
 
 
 def _sizes(x: torch.Tensor, g: nn.Module, fs: Sequence[nn.Module]):
@@ -43,7 +48,15 @@ def eligible(x: torch.Tensor, g: nn.Module, fs: Sequence[nn.Module]) -> bool:
     if sz is None:
         return False
     N, E, M, h, C, L = sz
+    if route == "never" or (route == "auto" and not (N >= 8192 and C <= 16 and max(h) <= 32)):
+        return False
     return _lib.load().psf_mixer_fwd_workspace(N, E, M, h, C, L) >= 0
+
+
+def covered(x: torch.Tensor, g: nn.Module, fs: Sequence[nn.Module]) -> bool:
+    """The shape is inside the fused path's limits (whatever ``route`` says about using it)."""
+    sz = _sizes(x, g, fs)
+    return sz is not None and x.is_cuda and x.dtype == torch.float32 and _lib.load().psf_mixer_fwd_workspace(*sz) >= 0
 
 
 def mixer_forward(x: torch.Tensor, g: nn.Module, fs: Sequence[nn.Module], use_residual: bool) -> torch.Tensor:

@@ -94,7 +94,8 @@ def test_bench_two_rank_rehearsal_replays_the_step_from_a_graph(gpu):
 
 def test_bench_keeps_the_headline_when_a_rank_stalls_in_the_training_leg(gpu):
     """Several ranks: the training leg's collectives have never run on real multi-GPU hardware. If a rank never arrives, a
-    deadline makes rank 0 print the finished headline with the leg marked as abandoned, and every rank exits with code 0."""
+    deadline makes rank 0 print the finished headline with the leg marked as abandoned — and every rank exits NON-zero (4):
+    a rank stuck in a kernel or a collective must not be recorded as a success by torch.distributed.run or the driver."""
     import json
     import subprocess
     import sys
@@ -102,12 +103,12 @@ def test_bench_keeps_the_headline_when_a_rank_stalls_in_the_training_leg(gpu):
     env = dict(os.environ, PSF_BENCH_REHEARSAL="1", PSF_BENCH_TEST_STALL_RANK="1", PSF_BENCH_TRAIN_DEADLINE_S="20")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                           "--train-steps", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.returncode != 0, "a stalled rank must not end as rc 0"
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
-    assert len(lines) == 1, out.stdout[-2000:]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["roofline"]["frac"] > 0
-    assert "did not finish" in line["train"]["error"]
+    assert "did not finish" in line["train"]["error"] and line["train"]["rc"] == 4
 
 
 def test_rccl_group_beside_a_gloo_default_group(gpu):

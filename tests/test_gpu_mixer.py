@@ -72,7 +72,7 @@ def test_mixer_matches_the_oracle_chain_fed_with_float64_mlp_w(gpu, name, B, N, 
         f.to(gpu)
     xd = x.to(gpu)
     with torch.no_grad():
-        assert fused_mixer.eligible(xd, g, fs), "the fused path must cover this shape"
+        assert fused_mixer.covered(xd, g, fs), "the fused path must cover this shape"
         got = fused_mixer.mixer_forward(xd, g, fs, residual).cpu().numpy()
     assert np.isfinite(got).all()
     assert rel_inf(got, want) <= TOL, f"{name}: rel {rel_inf(got, want):.3e}"
@@ -132,8 +132,8 @@ def test_nets_take_the_fused_mixer_in_inference_and_agree_with_the_unfused_route
     from sparsefactorization_amd.psfnet import LRAPSFNet, SyntheticPSFNet
     torch.manual_seed(0)
     nets = [
-        (SyntheticPSFNet(1, True, 32, 2048, 11, [32, 'GELU'], [32, 'GELU'], 8, 1, 'FLATTEN', ['linear'], True, True, False,
-                         'adding'), torch.rand(4, 2048, 2, device=gpu)),
+        (SyntheticPSFNet(1, True, 32, 8192, 13, [32, 'GELU'], [32, 'GELU'], 8, 1, 'FLATTEN', ['linear'], True, True, False,
+                         'adding'), torch.rand(4, 8192, 2, device=gpu)),
         (LRAPSFNet(225, 32, 1024, 11, [128, 'GELU'], [128, 'GELU'], 32, 2, 'FLATTEN', ['linear'], True, False, 0.1, 0.1, 0.1,
                    False, True, 'pathfinder'), torch.randint(0, 225, (4, 1024), device=gpu)),
     ]
@@ -147,17 +147,16 @@ def test_nets_take_the_fused_mixer_in_inference_and_agree_with_the_unfused_route
     for net, x in nets:
         net = net.to(gpu).eval()
         with torch.no_grad():
-            fused_mixer.enabled = False
-            try:
-                want = net(x)
-            finally:
-                fused_mixer.enabled = True
+            fused_mixer.route = "never"
+            want = net(x)
             import sparsefactorization_amd.psfnet as pn
             pn.chord_chain = spy
+            fused_mixer.route = "always"  # (the automatic rule keeps the Pathfinder widths on the W-through-memory route)
             try:
                 got = net(x)
             finally:
                 pn.chord_chain = orig
+                fused_mixer.route = "auto"
         assert not calls, "the fused mixer path must not run the W-from-memory chain"
         assert rel_inf(got.cpu().numpy(), want.cpu().numpy()) <= 1e-5
         net.train()  # dropout active / gradients wanted: the fused inference path must step aside
