@@ -229,7 +229,10 @@ int psf_embed_tokens_bwd_f32(const int64_t* idx, const float* dOut, int64_t T, i
  * (SyntheticExperiments/psf.py:129-134,189-190):  out[b,j] = bias[j] + sum_i X[b,i] * W[j,i]
  *   X [B,K] (K = N*C, a multiple of 4), W [J,K] (nn.Linear.weight), bias [J] or NULL, out [B,J]; 1 <= J <= 8;
  *   X and W 16-byte aligned. `workspace`: at least psf_flat_head_workspace(B, K, J) bytes (-1 for unsupported
- *   sizes). One read of X; per-chunk partial sums are added in a fixed order (bit-reproducible).
+ *   sizes). One read of X; per-chunk partial sums are added in a fixed order: bit-reproducible run to run FOR A GIVEN
+ *   (B, K). The chunk length (4096 floats, or 1024 when 4096 would leave fewer than 1024 workgroups) depends on B and K, so
+ *   the logits of one sample differ in their last bits between batch sizes that fall on different sides of that rule
+ *   (evaluation at another batch size than training agrees to ~1e-6 relative, not to the bit).
  */
 int64_t psf_flat_head_workspace(int32_t B, int64_t K, int32_t J);
 /*

@@ -126,7 +126,11 @@ def _flat_head(final: nn.Module, flat: torch.Tensor) -> torch.Tensor:
         return final[1:](_flat_head(final[0], flat))
     if (isinstance(final, nn.Linear) and final.out_features <= 16 and flat.is_cuda and flat.dim() == 2
             and flat.dtype == torch.float32 and final.weight.dtype == torch.float32 and flat.shape[1] % 4 == 0
-            and flat.shape[1] >= 4096):
+            and flat.shape[1] >= 4096
+            # psf_flat_head_f32 reads 16-byte vectors and returns PSF_E_ALIGN otherwise: a view at an odd storage offset (or
+            # a weight view) takes the library GEMM instead of raising
+            and flat.is_contiguous() and flat.data_ptr() % 16 == 0 and final.weight.is_contiguous()
+            and final.weight.data_ptr() % 16 == 0):
         return _FlatHeadFn.apply(flat, final.weight, final.bias)
     return final(flat)
 

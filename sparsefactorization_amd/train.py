@@ -344,38 +344,47 @@ class GraphedStep:
                       for p in optimizer.state}
         # warm-up and capture draw random numbers (dropout): the generator states are restored below too
         rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(X.device)
+        # Whatever happens below — a refused capture included — the warm-up's optimisation steps and random draws are undone
+        # (try / finally): a caller that falls back to eager stepping after a failed capture (psf_training.train_benchmark
+        # with several ranks) then continues from the same state as the ranks whose capture worked.
         side = torch.cuda.Stream(device=X.device)
-        side.wait_stream(torch.cuda.current_stream(X.device))
-        with torch.cuda.stream(side):  # eager warm-up on a side stream (allocator, lazy initialisations, autotuning)
-            for _ in range(warmup_steps):
-                self._step()
-        torch.cuda.current_stream(X.device).wait_stream(side)
-        for h in hooks:
-            h.remove()
-        if called:
-            raise RuntimeError(f"GraphedStep: nn.Embedding module(s) {sorted(set(called))} are looked up in forward; their "
-                               "gradient (aten::embedding_dense_backward) cannot be captured in a HIP graph. Use "
-                               "token_linear.TokenEmbedding (same parameters and state_dict) or train eagerly.")
-        self.graph = torch.cuda.CUDAGraph()
-        optimizer.zero_grad(set_to_none=True)
-        if capture_error_mode is None:
-            capture_error_mode = "thread_local" if reducer is not None else "global"
-        self.capture_error_mode = capture_error_mode
-        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
-            self.output = self._step(zero=False, eager_tail=False)
-        self.warmup_steps = warmup_steps
-        with torch.no_grad():
-            for t, s0 in zip(tensors, snapshot):
-                t.copy_(s0)
-            for p, st in optimizer.state.items():
-                before = opt_before.get(id(p), {})
-                for k, v in list(st.items()):
-                    if torch.is_tensor(v):
-                        v.copy_(before[k]) if k in before else v.zero_()
-                    elif k == "step":  # a host-side step count (ChunkedAdam, not capturable)
-                        st[k] = before.get(k, 0.0)
-        torch.set_rng_state(rng_cpu)
-        torch.cuda.set_rng_state(rng_dev, X.device)
+        try:
+            side.wait_stream(torch.cuda.current_stream(X.device))
+            with torch.cuda.stream(side):  # eager warm-up on a side stream (allocator, lazy initialisations, autotuning)
+                for _ in range(warmup_steps):
+                    self._step()
+            torch.cuda.current_stream(X.device).wait_stream(side)
+            for h in hooks:
+                h.remove()
+            hooks = []
+            if called:
+                raise RuntimeError(f"GraphedStep: nn.Embedding module(s) {sorted(set(called))} are looked up in forward; their "
+                                   "gradient (aten::embedding_dense_backward) cannot be captured in a HIP graph. Use "
+                                   "token_linear.TokenEmbedding (same parameters and state_dict) or train eagerly.")
+            self.graph = torch.cuda.CUDAGraph()
+            optimizer.zero_grad(set_to_none=True)
+            if capture_error_mode is None:
+                capture_error_mode = "thread_local" if reducer is not None else "global"
+            self.capture_error_mode = capture_error_mode
+            with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
+                self.output = self._step(zero=False, eager_tail=False)
+            self.warmup_steps = warmup_steps
+        finally:
+            for h in hooks:
+                h.remove()
+            torch.cuda.current_stream(X.device).wait_stream(side)  # (a warm-up step that raised left work on the side stream)
+            with torch.no_grad():
+                for t, s0 in zip(tensors, snapshot):
+                    t.copy_(s0)
+                for p, st in optimizer.state.items():
+                    before = opt_before.get(id(p), {})
+                    for k, v in list(st.items()):
+                        if torch.is_tensor(v):
+                            v.copy_(before[k]) if k in before else v.zero_()
+                        elif k == "step":  # a host-side step count (ChunkedAdam, not capturable)
+                            st[k] = before.get(k, 0.0)
+            torch.set_rng_state(rng_cpu)
+            torch.cuda.set_rng_state(rng_dev, X.device)
 
     def _step(self, zero: bool = True, eager_tail: bool = True):
         if zero:
