@@ -54,7 +54,7 @@ struct MlpStepCfg {
 
 
 template <int L, int TGS, bool RES, bool EDGE>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 3)
 chord_fwd_mlp_k(const float* __restrict__ X, const float* __restrict__ V, const float* __restrict__ res,
                 float* __restrict__ out, const unsigned char* __restrict__ images, const int nu, const int E, const Geom gm,
                 const Offsets offs, const int ablate) {
@@ -133,50 +133,52 @@ chord_fwd_mlp_k(const float* __restrict__ X, const float* __restrict__ V, const 
       if (ablate & 4) src = p;  // timing only: the row itself (an L2 / window hit) instead of the far row
       far[j][f] = ld<float, 4>(Vb + (int64_t)src * C + (int64_t)cgc * 4);
     }
-    if constexpr (RES) rres[j] = ld<float, 4>(res + ((int64_t)b * N + p) * C + (int64_t)cgc * 4);
   }
-
-  Frag3 xf[TPW][2];
-#pragma unroll
-  for (int tp = 0; tp < TPW; ++tp)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) xf[tp][s] = split_pack8(xv[tp][s]);
 
   __syncthreads();  // images and window have landed (hipcc drains vmcnt before the barrier)
 
   // ---- (1) the tile's W rows: W^T[o][tok] = b + sum over this wave's hidden units of B_u GELU(A_u X^T + a_u) ----
+  // One token tile at a time, weight fragments read from the LDS image where they are used: the phase then needs ~100
+  // registers beside the far rows it keeps alive, which is what lets three workgroups share a CU (<= 168 registers) —
+  // two tiles in flight with the fragments hoisted took 228 (two workgroups per CU: profiles/r04c_mixer_ablate.log shows
+  // the memory, data-row and matrix phases of the step adding up instead of overlapping).
   const int per = (nu + G - 1) / G;
   const int u0 = imin(nu, grp * per), u1 = imin(nu, u0 + per);
+  auto bias4 = [&](const float* base, int q) {  // registers 4q..4q+3 are rows 8q + 4 half + (0..3)
+    return *reinterpret_cast<const float4*>(base + 8 * q + 4 * half);
+  };
   f32x16 acc2[TPW];
-  {
-    const float* sb = reinterpret_cast<const float*>(sImg + kOffSb);  // the output bias is in every unit's image
 #pragma unroll
-    for (int tp = 0; tp < TPW; ++tp)
+  for (int tp = 0; tp < TPW; ++tp) {
+    Frag3 xf[2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[tp][r] = grp == 0 ? sb[cd_row(r, half)] : 0.f;
-  }
-  for (int u = (ablate & 1) ? u1 : u0; u < u1; ++u) {  // ablate & 1 (timing only): no MLP arithmetic, W = bias
-    const unsigned char* img = sImg + u * kImgBytes;
-    const float* sa = reinterpret_cast<const float*>(img + kOffSa);
-    Frag3 wa[2], wb[2];
+    for (int s = 0; s < 2; ++s) xf[s] = split_pack8_pk(xv[tp][s]);
+    {
+      const float* sb = reinterpret_cast<const float*>(sImg + kOffSb);  // the output bias is in every unit's image
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const unsigned char* pa = img + c * kARow + 32 * s + 16 * half;
-      wa[s].t1 = *reinterpret_cast<const bf16x8*>(pa);
-      wa[s].t2 = *reinterpret_cast<const bf16x8*>(pa + kATerm);
-      wa[s].t3 = *reinterpret_cast<const bf16x8*>(pa + 2 * kATerm);
-      const unsigned char* pb = img + kOffB + ((s * 2 + half) * 32 + c) * 16;
-      wb[s].t1 = *reinterpret_cast<const bf16x8*>(pb);
-      wb[s].t2 = *reinterpret_cast<const bf16x8*>(pb + kBTerm);
-      wb[s].t3 = *reinterpret_cast<const bf16x8*>(pb + 2 * kBTerm);
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = grp == 0 ? bias4(sb, q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc2[tp][4 * q] = v.x, acc2[tp][4 * q + 1] = v.y, acc2[tp][4 * q + 2] = v.z, acc2[tp][4 * q + 3] = v.w;
+      }
     }
-#pragma unroll
-    for (int tp = 0; tp < TPW; ++tp) {
+    for (int u = (ablate & 1) ? u1 : u0; u < u1; ++u) {  // ablate & 1 (timing only): no MLP arithmetic, W = bias
+      const unsigned char* img = sImg + u * kImgBytes;
+      const float* sa = reinterpret_cast<const float*>(img + kOffSa);
       f32x16 acc1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[r] = sa[cd_row(r, half)];
-      acc1 = mfma6(wa[0], xf[tp][0], acc1);
-      acc1 = mfma6(wa[1], xf[tp][1], acc1);
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = bias4(sa, q);
+        acc1[4 * q] = v.x, acc1[4 * q + 1] = v.y, acc1[4 * q + 2] = v.z, acc1[4 * q + 3] = v.w;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const unsigned char* pa = img + c * kARow + 32 * s + 16 * half;
+        Frag3 wa;
+        wa.t1 = *reinterpret_cast<const bf16x8*>(pa);
+        wa.t2 = *reinterpret_cast<const bf16x8*>(pa + kATerm);
+        wa.t3 = *reinterpret_cast<const bf16x8*>(pa + 2 * kATerm);
+        acc1 = mfma6(wa, xf[s], acc1);
+      }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {  // GELU + split of registers 8s..8s+7: the B fragment of k-step s
         float gl[8];
@@ -186,8 +188,23 @@ chord_fwd_mlp_k(const float* __restrict__ X, const float* __restrict__ V, const 
           gl[i] = y.x;
           gl[i + 1] = y.y;
         }
-        acc2[tp] = mfma6(wb[s], split_pack8(gl), acc2[tp]);
+        const unsigned char* pb = img + kOffB + ((s * 2 + half) * 32 + c) * 16;
+        Frag3 wb;
+        wb.t1 = *reinterpret_cast<const bf16x8*>(pb);
+        wb.t2 = *reinterpret_cast<const bf16x8*>(pb + kBTerm);
+        wb.t3 = *reinterpret_cast<const bf16x8*>(pb + 2 * kBTerm);
+        acc2[tp] = mfma6(wb, split_pack8_pk(gl), acc2[tp]);
       }
+    }
+    if constexpr (G == 1) {  // the finished tile goes to LDS at once (its registers are free for the next tile)
+      constexpr int NQ1 = (L + 7) / 8;
+      float* dst = sW + (32 * (wv * TPW + tp) + c) * WS;
+#pragma unroll
+      for (int q = 0; q < NQ1; ++q)
+        if (8 * q + 4 * half < L)
+          *reinterpret_cast<float4*>(dst + 8 * q + 4 * half) =
+              make_float4(acc2[tp][4 * q], acc2[tp][4 * q + 1], acc2[tp][4 * q + 2], acc2[tp][4 * q + 3]);
+      asm volatile("" ::: "memory");  // the next tile's LDS reads stay behind this tile's stores (no hoisting across tiles)
     }
   }
 
@@ -215,17 +232,21 @@ chord_fwd_mlp_k(const float* __restrict__ X, const float* __restrict__ V, const 
           }
       }
     }
-  }
-  if (grp == 0) {
-#pragma unroll
-    for (int tp = 0; tp < TPW; ++tp) {
-      const int t = G == 1 ? wv * TPW + tp : wv % TT;
-      float* dst = sW + (32 * t + c) * WS;
+    if (grp == 0) {  // (G > 1 means one token tile per wave)
+      float* dst = sW + (32 * (wv % TT) + c) * WS;
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
         if (8 * q + 4 * half < L)
           *reinterpret_cast<float4*>(dst + 8 * q + 4 * half) =
-              make_float4(acc2[tp][4 * q], acc2[tp][4 * q + 1], acc2[tp][4 * q + 2], acc2[tp][4 * q + 3]);
+              make_float4(acc2[0][4 * q], acc2[0][4 * q + 1], acc2[0][4 * q + 2], acc2[0][4 * q + 3]);
+    }
+  }
+  if constexpr (RES) {  // the residual rows: requested here, behind the matrix phase (8 registers it does not have to carry)
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int pr = p0 + j * RS + rs;
+      const int p = EDGE ? imin(pr, N - 1) : pr;
+      rres[j] = ld<float, 4>(res + ((int64_t)b * N + p) * C + (int64_t)cgc * 4);
     }
   }
   __syncthreads();
