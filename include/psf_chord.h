@@ -33,6 +33,14 @@
  *   - return value: 0 = success; < 0 = invalid argument (PSF_E_*); > 0 = hipError_t of the failed HIP call.
  *     No C++ exception crosses this boundary. psf_last_error() describes the last failure on this thread.
  *
+ * Threads.  Every entry point may be called from several host threads at once, on the same or on different streams
+ * and devices: a call reads its arguments, takes ONE snapshot of the tuning knobs at entry (a psf_set_tuning from another
+ * thread changes the next call, never the middle of one), enqueues its kernels and returns; the error string is
+ * thread-local; nothing else is written. What the library does NOT do for the caller: order two calls that touch the same
+ * buffers (that is the streams' job), or make psf_set_tuning atomic across several knobs (set them before starting the
+ * worker threads). The first launch of a kernel instance that needs more than 48 KB of LDS raises that function's limit
+ * (hipFuncSetAttribute, idempotent; two threads racing there both succeed).
+ *
  * Reference binding this replaces: pybind11 module `spmul_cuda` {forward_host, backward_host}
  * (spmul/spmul_cuda.cu:163-166) and the Python call torch_sparse.spmm (SyntheticExperiments/psf.py:5,178).
  * See INTEGRATION.md for the ctypes stub a maintainer of the reference would add.
@@ -397,6 +405,9 @@ int psf_stream_mix_f32(const float* w, const float* v, const float* r, float* ou
  *                      stores — three workgroups per CU —, round 2's length rule otherwise), 1, 2 = forced (equal bits)
  *   key "wide_fuse"  : psf_mlp_wide_fwd_f32: 1 = the second layers of the MLPs with <= 32 outputs run inside the first
  *                      layers' GEMM epilogue when every MLP has 97..128 hidden rows (default), 0 = always the separate kernel
+ *   key "mixer_wg_limit": psf_mixer_fwd_f32's step kernel, workgroups per CU: 0 = as many as fit (default: three), n = at most n
+ *   key "mixer_ablate": TIMING EXPERIMENTS ONLY (non-zero gives wrong results): bit 0 no MLP arithmetic, bit 1 no multiply-add
+ *                      chain, bit 2 no far rows, bit 3 no data rows in psf_mixer_fwd_f32's step kernel (profiles/mixer_bench.py)
  *   key "xcd_remap"  : 1 = keep a batch element's tiles on one XCD group (default), 0 = linear
  * psf_get_tuning returns the value (>= 0) or PSF_E_TUNING.
  */

@@ -67,7 +67,6 @@ std::atomic<int> g_bwd_fused_wg_limit{0};  // fused backward step: 0 = whatever 
 std::atomic<int> g_chain_zigzag{1};
 std::atomic<int> g_mixer_ablate{0};    // timing experiments on that kernel: bit 0 no MLP arithmetic, 1 no multiply-add chain, 2 no far rows, 3 no data rows
 std::atomic<int> g_mixer_wg_limit{0};  // step kernel that computes its own W (fwd_mlp_step.h): 0 = whatever fits, n = at most n per CU
-thread_local bool t_walk_backwards = false;  // set by chain_impl around the launches of odd steps
 
 }  // namespace
 // Fused producer MLPs: 0 = auto (split-bf16 kernel of mlp_fwd_x3.hip where it applies, else the f32-MFMA kernel of
@@ -108,6 +107,28 @@ Knob g_knobs[] = {
     {"mlp_fwd_store", &psf_g_mlp_fwd_store, 0, 1},
     {"mlp_fwd_tpw", &psf_g_mlp_fwd_tpw, 0, 2},
 };
+
+// One consistent view of the knobs per entry-point call: every extern "C" function takes ONE snapshot and hands it down, so
+// a psf_set_tuning from another thread changes the next call, never the middle of one; `walk_backwards` (zigzag of a chain's
+// odd steps) travels in it too instead of in thread-local state.
+struct Tuning {
+  int fwd_variant, bwd_variant, xcd_remap, fwd_rows, fwd_split, bwd_rows, dv_threads, bwd_fused_nt, bwd_fused, dw_variant,
+      dw_tgs, chain_fused, chain_cc, fwd_wide, fwd_wg_limit, bwd_fused_wg_limit, chain_zigzag, mixer_wg_limit, mixer_ablate;
+  bool walk_backwards;
+};
+
+Tuning snapshot() {
+  Tuning t;
+  t.fwd_variant = g_fwd_variant.load(), t.bwd_variant = g_bwd_variant.load(), t.xcd_remap = g_xcd_remap.load();
+  t.fwd_rows = g_fwd_rows.load(), t.fwd_split = g_fwd_split.load(), t.bwd_rows = g_bwd_rows.load();
+  t.dv_threads = g_dv_threads.load(), t.bwd_fused_nt = g_bwd_fused_nt.load(), t.bwd_fused = g_bwd_fused.load();
+  t.dw_variant = g_dw_variant.load(), t.dw_tgs = g_dw_tgs.load(), t.chain_fused = g_chain_fused.load();
+  t.chain_cc = g_chain_cc.load(), t.fwd_wide = g_fwd_wide.load(), t.fwd_wg_limit = g_fwd_wg_limit.load();
+  t.bwd_fused_wg_limit = g_bwd_fused_wg_limit.load(), t.chain_zigzag = g_chain_zigzag.load();
+  t.mixer_wg_limit = g_mixer_wg_limit.load(), t.mixer_ablate = g_mixer_ablate.load();
+  t.walk_backwards = false;
+  return t;
+}
 
 int ceil_log2(int64_t x) {
   int s = 0;
@@ -152,7 +173,7 @@ int check_dims(int64_t B, int64_t N, int32_t L, int64_t C, int64_t v_batch_strid
 bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 // Geometry of a launch over row tiles [tile0, tile0 + tiles) of every batch element.
-int make_geom(int64_t B, int64_t N, int32_t L, int64_t C, int vec, int tg_shift, int TR, bool split_channels,
+int make_geom(const Tuning& tn, int64_t B, int64_t N, int32_t L, int64_t C, int vec, int tg_shift, int TR, bool split_channels,
               int64_t v_bstride, int tile0, int tiles, Geom* gm) {
   gm->N = (int32_t)N;
   gm->L = L;
@@ -171,17 +192,17 @@ int make_geom(int64_t B, int64_t N, int32_t L, int64_t C, int vec, int tg_shift,
   gm->nblocks = (uint32_t)nb;
   gm->xq = gm->nblocks / kXcds;
   gm->xr = gm->nblocks % kXcds;
-  gm->remap = g_xcd_remap.load() ? (t_walk_backwards && g_chain_zigzag.load() ? 2 : 1) : 0;
+  gm->remap = tn.xcd_remap ? (tn.walk_backwards && tn.chain_zigzag ? 2 : 1) : 0;
   gm->v_bstride = v_bstride;
   return PSF_OK;
 }
 
-int generic_geom(int64_t B, int64_t N, int32_t L, int64_t C, int vec, bool split_channels, int64_t v_bstride,
+int generic_geom(const Tuning& tn, int64_t B, int64_t N, int32_t L, int64_t C, int vec, bool split_channels, int64_t v_bstride,
                  Geom* gm) {
   const int64_t CG = (C + vec - 1) / vec;
   const int tgs = ceil_log2(CG) > 6 ? 6 : ceil_log2(CG);
   const int TR = kBlock >> tgs;
-  return make_geom(B, N, L, C, vec, tgs, TR, split_channels, v_bstride, 0, (int)((N + TR - 1) / TR), gm);
+  return make_geom(tn, B, N, L, C, vec, tgs, TR, split_channels, v_bstride, 0, (int)((N + TR - 1) / TR), gm);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -238,12 +259,12 @@ hipError_t launch_fused_step(int tgs, int L, const BwdWinArgs& a, int nt) {
 
 // The fused dV + dW step (bwd_fused.h) applies to full tiles of narrow rows: C = 4 << tgs with tgs <= 3, N a multiple of
 // the tile (512 >> tgs rows) and at least two tiles, chord near offsets, everything 16-byte aligned and chunk-clean.
-bool pick_fused_step(const void* dZ, const void* W, const void* V, const void* dW, const void* dV, int64_t B, int64_t N,
+bool pick_fused_step(const Tuning& tn, const void* dZ, const void* W, const void* V, const void* dW, const void* dV, int64_t B, int64_t N,
                      int32_t L, int64_t C, int64_t v_bstride, const Offsets& offs, WinPick* pk) {
-  const int knob = g_bwd_fused.load();
+  const int knob = tn.bwd_fused;
   if (!knob || L < kWinLmin || L > kWinLmax || (C != 4 && C != 8 && C != 16 && C != 32)) return false;
   const int tgs = C == 4 ? 0 : C == 8 ? 1 : C == 16 ? 2 : 3;
-  const int nt = g_bwd_fused_nt.load() ? 256 : kDvMidThreads;
+  const int nt = tn.bwd_fused_nt ? 256 : kDvMidThreads;
   const int TR = nt >> tgs;
   if (N % TR != 0 || N < 2 * (int64_t)TR) return false;
   if (!aligned_to(dZ, 16) || !aligned_to(W, 16) || !aligned_to(V, 16) || !aligned_to(dW, 16) || !aligned_to(dV, 16)) return false;
@@ -263,8 +284,8 @@ bool pick_fused_step(const void* dZ, const void* W, const void* V, const void* d
 // launch; N = 2000, C = 16: 7.7 vs 5.0; dW at N = 2000, C = 128: 21.9 vs 16.1); predicating EVERY tile costs 0-5 % of the
 // launch (r01c: cfg2 27.6 -> 28.9 us). So: one predicated launch unless the launch is long enough for 5 % to exceed the
 // boundary, i.e. beyond ~300 MB of algorithmic bytes.
-bool ragged_in_one_launch(bool ragged, int64_t B, int64_t N, int32_t L, int64_t C) {
-  return ragged && g_fwd_split.load() == 1 && 4 * B * N * (L + 3 * C) <= (int64_t)300 * 1000 * 1000;
+bool ragged_in_one_launch(const Tuning& tn, bool ragged, int64_t B, int64_t N, int32_t L, int64_t C) {
+  return ragged && tn.fwd_split == 1 && 4 * B * N * (L + 3 * C) <= (int64_t)300 * 1000 * 1000;
 }
 
 hipError_t launch_dwc(const WinPick& pk, int L, const BwdWinArgs& a) {
@@ -277,13 +298,13 @@ hipError_t launch_dwc(const WinPick& pk, int L, const BwdWinArgs& a) {
 
 // Chunk-looping dW (bwd_dw_chunk.h), rows of >= 32 channels whose channel groups split into chunks of 8 (or 16) lanes:
 // 256 threads x 1 row, so tiles of 32 (16) rows. Fills `pick` when the kernel applies.
-bool pick_dw_chunk(const void* dW, int64_t B, int64_t N, int32_t L, int64_t C, const Offsets& offs, bool vec_ok,
+bool pick_dw_chunk(const Tuning& tn, const void* dW, int64_t B, int64_t N, int32_t L, int64_t C, const Offsets& offs, bool vec_ok,
                    WinPick* pick) {
   if (!vec_ok || L < kWinLmin || L > kWinLmax) return false;
   const int64_t CG = C / 4;
   if (CG % 8 != 0 || CG / 8 > 4096) return false;
   int tgs = 3;
-  const int knob = g_dw_tgs.load();
+  const int knob = tn.dw_tgs;
   // 16 lanes per row chunk (16-row tiles) when that spares the launch its ragged last tile (ListOps: N = 2000 = 125 * 16)
   if (knob == 5 || (knob == 0 && CG % 16 == 0 && N % 32 != 0 && N % 16 == 0)) tgs = CG % 16 == 0 ? 4 : 3;
   const int TR = win_tile_rows(tgs, 1, 256);
@@ -301,7 +322,7 @@ bool pick_dw_chunk(const void* dW, int64_t B, int64_t N, int32_t L, int64_t C, c
   pick->KN = KN;
   pick->tiles_full = (int)(N / TR);
   pick->ragged = (N % TR) != 0;
-  pick->all_edge = ragged_in_one_launch(pick->ragged, B, N, L, C) || !aligned_to(dW, 16) || ((N * (int64_t)L) % 4) != 0 || !g_fwd_split.load();
+  pick->all_edge = ragged_in_one_launch(tn, pick->ragged, B, N, L, C) || !aligned_to(dW, 16) || ((N * (int64_t)L) % 4) != 0 || !tn.fwd_split;
   return true;
 }
 
@@ -322,7 +343,7 @@ hipError_t launch_dw(const WinPick& pk, int L, const BwdWinArgs& a) {
 // `W` is the flat [B,N,L] array the kernel copies in 16-byte chunks (W itself, or dW for the dW kernel).
 // `chunk_channels`: the kernel may split a row's channels over several workgroups (forward, dV) — then wide rows
 // (C >= 64) use the wide-row configuration: 32-channel chunks, 1024 threads, 256-row tiles.
-bool pick_window(const void* W, int64_t B, int64_t N, int32_t L, int64_t C, const Offsets& offs, bool vec_ok,
+bool pick_window(const Tuning& tn, const void* W, int64_t B, int64_t N, int32_t L, int64_t C, const Offsets& offs, bool vec_ok,
                  WinPick* pick, int rows_pref, bool chunk_channels, int nt_pref = 0) {
   if (!vec_ok || L < kWinLmin || L > kWinLmax) return false;
   const int64_t CG = C / 4;
@@ -330,7 +351,7 @@ bool pick_window(const void* W, int64_t B, int64_t N, int32_t L, int64_t C, cons
   int nt = 256;
   int rows = rows_pref;
   if (rows <= 0 || !win_rows_compiled(rows)) rows = win_default_rows(tgs);
-  const int wide = g_fwd_wide.load();
+  const int wide = tn.fwd_wide;
   if (chunk_channels && wide == 1 && CG >= 16 && N >= 2 * (int64_t)win_tile_rows(kWideTgs, rows, kWideThreads)) {
     tgs = kWideTgs;  // 32-channel chunks on 1024-thread workgroups
     nt = kWideThreads;
@@ -355,19 +376,19 @@ bool pick_window(const void* W, int64_t B, int64_t N, int32_t L, int64_t C, cons
   pick->tiles_full = (int)(N / TR);
   pick->ragged = (N % TR) != 0;
   const int TG = 1 << tgs;
-  pick->all_edge = (CG % TG) != 0 || !aligned_to(W, 16) || ((B * N * (int64_t)L) % 4) != 0 || !g_fwd_split.load() ||
-                   ragged_in_one_launch(pick->ragged, B, N, L, C);
+  pick->all_edge = (CG % TG) != 0 || !aligned_to(W, 16) || ((B * N * (int64_t)L) % 4) != 0 || !tn.fwd_split ||
+                   ragged_in_one_launch(tn, pick->ragged, B, N, L, C);
   return true;
 }
 
 // The dV window kernel's configuration for a shape (also what psf_chord_bwd_far_first_link reports).
 // default rows per thread (r01 sweep, us at cfg2): dV R=2 31.3 vs R=1 32.7; 512 threads x 1 row per thread instead of
 // 256 x 2 is the same tile at C <= 8 (r02 lab 28.65 vs 29.05 us at cfg2)
-bool pick_dv(const void* W, int64_t B, int64_t N, int32_t L, int64_t C, const Offsets& offs, bool vec_ok, WinPick* pk) {
-  const int knob = g_bwd_rows.load();
-  const int dvt = g_dv_threads.load();
+bool pick_dv(const Tuning& tn, const void* W, int64_t B, int64_t N, int32_t L, int64_t C, const Offsets& offs, bool vec_ok, WinPick* pk) {
+  const int knob = tn.bwd_rows;
+  const int dvt = tn.dv_threads;
   const int nt_dv = (dvt == 2 || (dvt == 0 && !knob && C <= 8)) ? kDvMidThreads : 0;
-  return pick_window(W, B, N, L, C, offs, vec_ok, pk, knob ? knob : 2, true, nt_dv);
+  return pick_window(tn, W, B, N, L, C, offs, vec_ok, pk, knob ? knob : 2, true, nt_dv);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -377,7 +398,7 @@ bool pick_dv(const void* W, int64_t B, int64_t N, int32_t L, int64_t C, const Of
 // tile of every sequence (if any) on the EDGE instance; everything on the EDGE instance when `all_edge`.
 // `launch` reads *gm and *edge, which are filled in before each call.
 template <typename F>
-int window_launches(const WinPick& pk, bool all_edge, int64_t B, int64_t N, int32_t L, int64_t C,
+int window_launches(const Tuning& tn, const WinPick& pk, bool all_edge, int64_t B, int64_t N, int32_t L, int64_t C,
                     int64_t v_bstride, bool split_channels, Geom* gm, bool* edge, F launch, const char* what) {
   const int tiles_all = pk.tiles_full + (pk.ragged ? 1 : 0);
   struct Part {
@@ -393,7 +414,7 @@ int window_launches(const WinPick& pk, bool all_edge, int64_t B, int64_t N, int3
     if (pk.ragged) parts[np++] = {pk.tiles_full, 1, true};
   }
   for (int i = 0; i < np; ++i) {
-    if (int rc = make_geom(B, N, L, C, 4, pk.tgs, pk.TR, split_channels, v_bstride, parts[i].tile0, parts[i].tiles, gm))
+    if (int rc = make_geom(tn, B, N, L, C, 4, pk.tgs, pk.TR, split_channels, v_bstride, parts[i].tile0, parts[i].tiles, gm))
       return rc;
     *edge = parts[i].edge;
     hipError_t e = launch();
@@ -402,7 +423,7 @@ int window_launches(const WinPick& pk, bool all_edge, int64_t B, int64_t N, int3
   return PSF_OK;
 }
 
-int fwd_window_f32(const WinPick& pk, const float* W, const float* V, const float* res, float* out, int64_t B,
+int fwd_window_f32(const Tuning& tn, const WinPick& pk, const float* W, const float* V, const float* res, float* out, int64_t B,
                    int64_t N, int32_t L, int64_t C, int64_t v_batch_stride, const Offsets& offs, hipStream_t s,
                    float* wfar, int far_k0) {
   FwdWinArgs a;
@@ -420,17 +441,17 @@ int fwd_window_f32(const WinPick& pk, const float* W, const float* V, const floa
   // 8.9 / 9.2; 2 per CU: 30.0 at cfg2. Round 3, chains that keep every step's output (training; N = 16384, C = 8, no limit /
   // three per CU, profiles/r03al_fwd_wg_limit_sweep.log): B = 16 (1024 tiles) 9.4 / 9.7; B = 24 13.5 / 13.2; B = 32 16.5 /
   // 16.1; B = 40 19.9 / 19.0; B = 48 22.8 / 21.8. So: three for narrow rows on launches of >= 1536 tiles, no limit otherwise.
-  const int knob = g_fwd_wg_limit.load();
+  const int knob = tn.fwd_wg_limit;
   const int64_t tiles_total = B * (int64_t)(pk.tiles_full + (pk.ragged ? 1 : 0));
   a.wg_per_cu = knob == 0 ? ((pk.tgs <= 1 && pk.nt == 256 && tiles_total >= 1536) ? 3 : 0) : (knob == 1 ? 0 : knob);
-  return window_launches(pk, pk.all_edge, B, N, L, C, v_batch_stride, true, &a.gm, &a.edge,
+  return window_launches(tn, pk, pk.all_edge, B, N, L, C, v_batch_stride, true, &a.gm, &a.edge,
                          [&] { return launch_win(pk, L, a); }, "chord_fwd_win launch");
 }
 
 // `wfar` (f32 only): ask the step to leave the link-major side copy of W's columns >= far_k0; *copied reports
 // whether the kernel that ran could write it.
 template <typename T>
-int fwd_impl(const T* W, const T* V, const T* res, T* out, int64_t B, int64_t N, int32_t L, int64_t C,
+int fwd_impl(const Tuning& tn, const T* W, const T* V, const T* res, T* out, int64_t B, int64_t N, int32_t L, int64_t C,
              int64_t v_batch_stride, const int64_t* offsets, void* stream, T* wfar = nullptr, int far_k0 = 0,
              bool* copied = nullptr) {
   if (copied) *copied = false;
@@ -449,13 +470,13 @@ int fwd_impl(const T* W, const T* V, const T* res, T* out, int64_t B, int64_t N,
   const bool vec_ok =
       (C % VECW == 0) && aligned_to(V, 16) && aligned_to(out, 16) && (!res || aligned_to(res, 16));
 
-  const int variant = g_fwd_variant.load();
+  const int variant = tn.fwd_variant;
   if constexpr (sizeof(T) == 4) {  // the window kernels are compiled for f32 only (f64 exists for gradcheck)
     WinPick pk;
-    if (variant != 1 && pick_window(W, B, N, L, C, offs, vec_ok, &pk, g_fwd_rows.load(), true)) {
+    if (variant != 1 && pick_window(tn, W, B, N, L, C, offs, vec_ok, &pk, tn.fwd_rows, true)) {
       const bool emit = wfar != nullptr && far_k0 >= 0 && far_k0 < L;
       if (copied) *copied = emit;
-      return fwd_window_f32(pk, W, V, res, out, B, N, L, C, v_batch_stride, offs, s, emit ? wfar : nullptr, far_k0);
+      return fwd_window_f32(tn, pk, W, V, res, out, B, N, L, C, v_batch_stride, offs, s, emit ? wfar : nullptr, far_k0);
     }
   }
   if (variant == 2)
@@ -463,7 +484,7 @@ int fwd_impl(const T* W, const T* V, const T* res, T* out, int64_t B, int64_t N,
                 (long long)N, (int)L, (long long)C);
 
   Geom gm;
-  if (int rc = generic_geom(B, N, L, C, vec_ok ? VECW : 1, true, v_batch_stride, &gm)) return rc;
+  if (int rc = generic_geom(tn, B, N, L, C, vec_ok ? VECW : 1, true, v_batch_stride, &gm)) return rc;
   if (vec_ok)
     hipLaunchKernelGGL((chord_fwd_generic_k<T, VECW>), dim3(gm.nblocks), dim3(kBlock), 0, s, W, V, res, out, gm, offs);
   else
@@ -474,7 +495,7 @@ int fwd_impl(const T* W, const T* V, const T* res, T* out, int64_t B, int64_t N,
 }
 
 template <typename T>
-int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64_t N, int32_t L, int64_t C,
+int bwd_impl(const Tuning& tn, const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64_t N, int32_t L, int64_t C,
              int64_t v_batch_stride, const int64_t* offsets, void* stream, const T* wfar = nullptr, int far_k0 = 0) {
   if (int rc = check_dims(B, N, L, C, v_batch_stride)) return rc;
   if (B == 0) return PSF_OK;
@@ -491,35 +512,35 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
   constexpr int VECW = 16 / (int)sizeof(T);
 
   if constexpr (sizeof(T) == 4) {  // LDS-window kernels (f32). Whatever they handle is cleared below.
-    if (g_bwd_variant.load() != 1) {
+    if (tn.bwd_variant != 1) {
       const int64_t w_total = B * N * (int64_t)L;
       const int TGmax = 1 << kWinTgsMax;
       WinPick pk;
       // default rows per thread (r01 sweep, us at cfg2): dV R=2 31.3 vs R=1 32.7; dW R=1 22.9 vs R=2 28.7
-      const int knob = g_bwd_rows.load();
+      const int knob = tn.bwd_rows;
       const int rows_dw = knob ? knob : 1;
       // dW before dV: dV's output is the next (earlier) step's dZ, read first thing by that step's kernels; writing
       // it last leaves it cache-hot (dV 27.4 -> 26.9 us, dW 20.5 -> 20.4 us in the Order training step)
-      const int dwv = g_dw_variant.load();
-      if (dW && dV && pick_fused_step(dZ, W, V, dW, dV, B, N, L, C, v_batch_stride, offs, &pk)) {
+      const int dwv = tn.dw_variant;
+      if (dW && dV && pick_fused_step(tn, dZ, W, V, dW, dV, B, N, L, C, v_batch_stride, offs, &pk)) {
         BwdWinArgs a{dZ, W, dV, Geom{}, offs, w_total, false, s};
         a.V2 = V;
         a.out2 = dW;
-        a.wg_per_cu = g_bwd_fused_wg_limit.load();
+        a.wg_per_cu = tn.bwd_fused_wg_limit;
         if (wfar != nullptr && far_k0 >= 0 && far_k0 <= pk.KN && pk.KN < L) {
           a.wfar = wfar;
           a.far_k0 = far_k0;
         }
-        if (int rc = make_geom(B, N, L, C, 4, pk.tgs, pk.TR, false, v_batch_stride, 0, pk.tiles_full, &a.gm)) return rc;
+        if (int rc = make_geom(tn, B, N, L, C, 4, pk.tgs, pk.TR, false, v_batch_stride, 0, pk.tiles_full, &a.gm)) return rc;
         hipError_t e = launch_fused_step(pk.tgs, L, a, pk.nt);
         if (e != hipSuccess) return fail_hip(e, "chord_bwd_fused");
         dW = nullptr;
         dV = nullptr;
       }
       if (dW && dwv != 1 &&
-          pick_dw_chunk(dW, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(V, 16), &pk)) {
+          pick_dw_chunk(tn, dW, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(V, 16), &pk)) {
         BwdWinArgs a{dZ, V, dW, Geom{}, offs, w_total, false, s};
-        int rc = window_launches(pk, pk.all_edge, B, N, L, C, v_batch_stride, false, &a.gm, &a.edge,
+        int rc = window_launches(tn, pk, pk.all_edge, B, N, L, C, v_batch_stride, false, &a.gm, &a.edge,
                                  [&] { return launch_dwc(pk, L, a); }, "chord_dw_chunk");
         if (rc) return rc;
         dW = nullptr;
@@ -528,23 +549,23 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
                     (long long)N, (int)L, (long long)C);
       }
       if (dW && C / 4 <= TGmax &&
-          pick_window(dW, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(V, 16), &pk,
+          pick_window(tn, dW, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(V, 16), &pk,
                       rows_dw, false)) {
         // the dW tile store is chunk-clean only if every sequence starts on a 16-byte boundary
         const bool all_edge = pk.all_edge || ((N * (int64_t)L) % 4) != 0;
         BwdWinArgs a{dZ, V, dW, Geom{}, offs, w_total, false, s};
-        int rc = window_launches(pk, all_edge, B, N, L, C, v_batch_stride, false, &a.gm, &a.edge,
+        int rc = window_launches(tn, pk, all_edge, B, N, L, C, v_batch_stride, false, &a.gm, &a.edge,
                                  [&] { return launch_dw(pk, L, a); }, "chord_dw_win");
         if (rc) return rc;
         dW = nullptr;
       }
-      if (dV && pick_dv(W, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(dV, 16), &pk)) {
+      if (dV && pick_dv(tn, W, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(dV, 16), &pk)) {
         BwdWinArgs a{dZ, W, dV, Geom{}, offs, w_total, false, s};
         if (wfar != nullptr && far_k0 >= 0 && far_k0 <= pk.KN && pk.KN < L) {  // the copy covers every far link
           a.wfar = wfar;
           a.far_k0 = far_k0;
         }
-        int rc = window_launches(pk, pk.all_edge, B, N, L, C, N * C, true, &a.gm, &a.edge,
+        int rc = window_launches(tn, pk, pk.all_edge, B, N, L, C, N * C, true, &a.gm, &a.edge,
                                  [&] { return launch_dv(pk, L, a); }, "chord_dv_win");
         if (rc) return rc;
         dV = nullptr;
@@ -555,7 +576,7 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
   if (dV) {
     const bool vec_ok = (C % VECW == 0) && aligned_to(dZ, 16) && aligned_to(dV, 16);
     Geom gm;
-    if (int rc = generic_geom(B, N, L, C, vec_ok ? VECW : 1, true, N * C, &gm)) return rc;
+    if (int rc = generic_geom(tn, B, N, L, C, vec_ok ? VECW : 1, true, N * C, &gm)) return rc;
     if (vec_ok)
       hipLaunchKernelGGL((chord_dv_generic_k<T, VECW>), dim3(gm.nblocks), dim3(kBlock), 0, s, dZ, W, dV, gm, offs);
     else
@@ -566,7 +587,7 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
   if (dW) {
     const bool vec_ok = (C % VECW == 0) && aligned_to(dZ, 16) && aligned_to(V, 16);
     Geom gm;
-    if (int rc = generic_geom(B, N, L, C, vec_ok ? VECW : 1, false, v_batch_stride, &gm)) return rc;
+    if (int rc = generic_geom(tn, B, N, L, C, vec_ok ? VECW : 1, false, v_batch_stride, &gm)) return rc;
     if (vec_ok)
       hipLaunchKernelGGL((chord_dw_generic_k<T, VECW>), dim3(gm.nblocks), dim3(kBlock), 0, s, dZ, V, dW, gm, offs);
     else
@@ -578,7 +599,7 @@ int bwd_impl(const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64
 }
 
 template <typename T>
-int chain_impl(const T* const* W_steps, const T* V0, T* const* out_steps, int32_t M, int32_t use_residual,
+int chain_impl(Tuning tn, const T* const* W_steps, const T* V0, T* const* out_steps, int32_t M, int32_t use_residual,
                int64_t B, int64_t N, int32_t L, int64_t C, int64_t v0_batch_stride, const int64_t* offsets,
                void* stream, T* const* wfar_steps = nullptr, int far_k0 = 0, uint64_t* copied_mask = nullptr) {
   if (copied_mask) *copied_mask = 0;
@@ -602,8 +623,8 @@ int chain_impl(const T* const* W_steps, const T* V0, T* const* out_steps, int32_
     // L2 -> CU `chunks` times and every output row is stored in `chunks` pieces. Past ~8 the per-step kernels win
     // (profiles/r03n_chain_train_sweep.log, us per chain one launch / per step: ListOps N = 2000, C = 128, 32 chunks:
     // 361 / 223; N = 2048, C = 64, 16 chunks: 184 / 119; Pathfinder C = 32, 4 chunks: 72 / 78). chain_fused = 2 forces it.
-    const int cf = g_chain_fused.load();
-    bool ok = cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, g_chain_cc.load()) &&
+    const int cf = tn.chain_fused;
+    bool ok = cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, tn.chain_cc) &&
               (cf == 2 || plan.chunks <= 8) &&
               aligned_to(V0, 16) && B * (int64_t)plan.chunks <= 0x7fffffff;
     for (int m = 0; ok && m < M; ++m) ok = aligned_to(W_steps[m], 4) && aligned_to(out_steps[m], 16);
@@ -642,11 +663,10 @@ int chain_impl(const T* const* W_steps, const T* V0, T* const* out_steps, int32_
     const int64_t stride = m == 0 ? v0_batch_stride : N * C;
     // zigzag: every XCD walks its tile range forwards on even steps and backwards on odd ones, so a launch begins
     // with the tiles whose inputs the previous launch wrote LAST (still in that XCD's L2), not first
-    t_walk_backwards = (m & 1) != 0;
+    tn.walk_backwards = (m & 1) != 0;
     bool copied = false;
-    int rc = fwd_impl<T>(W_steps[m], in, use_residual ? V0 : nullptr, out_steps[m], B, N, L, C, stride, offsets,
+    int rc = fwd_impl<T>(tn, W_steps[m], in, use_residual ? V0 : nullptr, out_steps[m], B, N, L, C, stride, offsets,
                          stream, wfar_steps ? wfar_steps[m] : nullptr, far_k0, &copied);
-    t_walk_backwards = false;
     if (rc) return rc;
     if (copied && copied_mask && m < 64) *copied_mask |= (uint64_t)1 << m;
   }
@@ -754,47 +774,48 @@ int psf_chord_indices(int64_t N, int32_t L, int64_t* rows_out, int64_t* cols_out
 
 int psf_chord_spmm_fwd_f32(const float* W, const float* V, const float* res, float* out, int64_t B, int64_t N,
                            int32_t L, int64_t C, int64_t v_batch_stride, const int64_t* offsets, void* stream) {
-  return fwd_impl<float>(W, V, res, out, B, N, L, C, v_batch_stride, offsets, stream);
+  return fwd_impl<float>(snapshot(), W, V, res, out, B, N, L, C, v_batch_stride, offsets, stream);
 }
 int psf_chord_spmm_fwd_f64(const double* W, const double* V, const double* res, double* out, int64_t B,
                            int64_t N, int32_t L, int64_t C, int64_t v_batch_stride, const int64_t* offsets,
                            void* stream) {
-  return fwd_impl<double>(W, V, res, out, B, N, L, C, v_batch_stride, offsets, stream);
+  return fwd_impl<double>(snapshot(), W, V, res, out, B, N, L, C, v_batch_stride, offsets, stream);
 }
 
 int psf_chord_spmm_bwd_f32(const float* dZ, const float* W, const float* V, float* dW, float* dV, int64_t B,
                            int64_t N, int32_t L, int64_t C, int64_t v_batch_stride, const int64_t* offsets,
                            void* stream) {
-  return bwd_impl<float>(dZ, W, V, dW, dV, B, N, L, C, v_batch_stride, offsets, stream);
+  return bwd_impl<float>(snapshot(), dZ, W, V, dW, dV, B, N, L, C, v_batch_stride, offsets, stream);
 }
 int psf_chord_spmm_bwd_f64(const double* dZ, const double* W, const double* V, double* dW, double* dV,
                            int64_t B, int64_t N, int32_t L, int64_t C, int64_t v_batch_stride,
                            const int64_t* offsets, void* stream) {
-  return bwd_impl<double>(dZ, W, V, dW, dV, B, N, L, C, v_batch_stride, offsets, stream);
+  return bwd_impl<double>(snapshot(), dZ, W, V, dW, dV, B, N, L, C, v_batch_stride, offsets, stream);
 }
 
 int psf_chord_chain_fwd_f32(const float* const* W_steps, const float* V0, float* const* out_steps, int32_t M,
                             int32_t use_residual, int64_t B, int64_t N, int32_t L, int64_t C,
                             int64_t v0_batch_stride, const int64_t* offsets, void* stream) {
-  return chain_impl<float>(W_steps, V0, out_steps, M, use_residual, B, N, L, C, v0_batch_stride, offsets, stream);
+  return chain_impl<float>(snapshot(), W_steps, V0, out_steps, M, use_residual, B, N, L, C, v0_batch_stride, offsets, stream);
 }
 int psf_chord_chain_fwd_f64(const double* const* W_steps, const double* V0, double* const* out_steps, int32_t M,
                             int32_t use_residual, int64_t B, int64_t N, int32_t L, int64_t C,
                             int64_t v0_batch_stride, const int64_t* offsets, void* stream) {
-  return chain_impl<double>(W_steps, V0, out_steps, M, use_residual, B, N, L, C, v0_batch_stride, offsets, stream);
+  return chain_impl<double>(snapshot(), W_steps, V0, out_steps, M, use_residual, B, N, L, C, v0_batch_stride, offsets, stream);
 }
 
 int32_t psf_chord_bwd_far_first_link(int64_t B, int64_t N, int32_t L, int64_t C) {
   if (int rc = check_dims(B, N, L, C, N * C)) return rc;
-  if (g_bwd_variant.load() == 1 || C % 4 != 0) return L;
+  const Tuning tn = snapshot();
+  if (tn.bwd_variant == 1 || C % 4 != 0) return L;
   Offsets offs;
   make_offsets(N, L, nullptr, &offs);
   WinPick pk;
   // a step that wants both gradients may run the fused kernel, whose tile (and first far link) can be shorter than the
   // dV kernel's: the copy must cover the far links of either
   int k0 = L;
-  if (pick_fused_step(nullptr, nullptr, nullptr, nullptr, nullptr, B, N, L, C, N * C, offs, &pk) && pk.KN < k0) k0 = pk.KN;
-  if (pick_dv(nullptr, B, N, L, C, offs, true, &pk) && pk.KN < k0) k0 = pk.KN;
+  if (pick_fused_step(tn, nullptr, nullptr, nullptr, nullptr, nullptr, B, N, L, C, N * C, offs, &pk) && pk.KN < k0) k0 = pk.KN;
+  if (pick_dv(tn, nullptr, B, N, L, C, offs, true, &pk) && pk.KN < k0) k0 = pk.KN;
   return k0;
 }
 
@@ -805,7 +826,7 @@ int psf_chord_chain_fwd_far_f32(const float* const* W_steps, const float* V0, fl
   if (wfar_steps && (far_k0 < 0 || far_k0 > L)) return fail(PSF_E_SHAPE, "far_k0 must be in [0, L]");
   if (wfar_steps && M > 64) return fail(PSF_E_SHAPE, "the far-column side copy is reported for at most 64 steps");
   // short sequences still take the single-launch LDS chain (forward speed first); it writes no copy: mask stays 0
-  return chain_impl<float>(W_steps, V0, out_steps, M, use_residual, B, N, L, C, v0_batch_stride, offsets, stream,
+  return chain_impl<float>(snapshot(), W_steps, V0, out_steps, M, use_residual, B, N, L, C, v0_batch_stride, offsets, stream,
                            (wfar_steps && far_k0 < L) ? wfar_steps : nullptr, far_k0, copied_mask);
 }
 
@@ -813,7 +834,7 @@ int psf_chord_spmm_bwd_far_f32(const float* dZ, const float* W, const float* V, 
                                int64_t N, int32_t L, int64_t C, int64_t v_batch_stride, const int64_t* offsets,
                                const float* w_far, int32_t far_k0, void* stream) {
   if (w_far && !aligned_to(w_far, 4)) return fail(PSF_E_ALIGN, "w_far must be aligned to the element size");
-  return bwd_impl<float>(dZ, W, V, dW, dV, B, N, L, C, v_batch_stride, offsets, stream, w_far, far_k0);
+  return bwd_impl<float>(snapshot(), dZ, W, V, dW, dV, B, N, L, C, v_batch_stride, offsets, stream, w_far, far_k0);
 }
 
 int64_t psf_mixer_fwd_workspace(int64_t N, int32_t E, int32_t M, const int32_t* h, int64_t C, int32_t L) {
@@ -846,6 +867,7 @@ int psf_mixer_fwd_f32(const float* X, int64_t B, int64_t N, int32_t E, int32_t M
     if (m > 0 && out_steps[m] == out_steps[m - 1]) return fail(PSF_E_ALIAS, "psf_mixer_fwd: step %d: out aliases the step's input", m);
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Tuning tn = snapshot();
 
   // (1) all M + 1 weight sets -> unit images (one launch); (2) V0 = g(X) from the first of them
   int32_t O[32], first_unit[33];
@@ -865,7 +887,7 @@ int psf_mixer_fwd_f32(const float* X, int64_t B, int64_t N, int32_t E, int32_t M
   pk.tiles_full = (int)(N / mp.TR);
   pk.ragged = (N % mp.TR) != 0;
   const int TG = 1 << mp.tgs;
-  pk.all_edge = ((C / 4) % TG) != 0 || !g_fwd_split.load() || ragged_in_one_launch(pk.ragged, B, N, E, C);  // (E: this step moves the data row, not the W row)
+  pk.all_edge = ((C / 4) % TG) != 0 || !tn.fwd_split || ragged_in_one_launch(tn, pk.ragged, B, N, E, C);  // (E: this step moves the data row, not the W row)
   for (int m = 0; m < M; ++m) {
     FwdMlpArgs fa;
     fa.X = X;
@@ -876,13 +898,12 @@ int psf_mixer_fwd_f32(const float* X, int64_t B, int64_t N, int32_t E, int32_t M
     fa.nu = first_unit[m + 2] - first_unit[m + 1];
     fa.E = E;
     fa.offs = offs;
-    fa.wg_per_cu = g_mixer_wg_limit.load();
-    fa.ablate = g_mixer_ablate.load();
+    fa.wg_per_cu = tn.mixer_wg_limit;
+    fa.ablate = tn.mixer_ablate;
     fa.stream = s;
-    t_walk_backwards = (m & 1) != 0;  // zigzag, as chain_impl
-    const int rc = window_launches(pk, pk.all_edge, B, N, L, C, N * C, false, &fa.gm, &fa.edge,
+    tn.walk_backwards = (m & 1) != 0;  // zigzag, as chain_impl
+    const int rc = window_launches(tn, pk, pk.all_edge, B, N, L, C, N * C, false, &fa.gm, &fa.edge,
                                    [&] { return launch_mlp_step(mp.tgs, L, fa); }, "chord_fwd_mlp launch");
-    t_walk_backwards = false;
     if (rc) return rc;
   }
   return PSF_OK;
@@ -916,8 +937,9 @@ int psf_describe_fwd(int64_t B, int64_t N, int32_t L, int64_t C, int32_t elem_by
   const int vecw = 16 / elem_bytes;
   const bool vec_ok = C % vecw == 0;
   WinPick pk;
-  const int variant = g_fwd_variant.load();
-  if (variant != 1 && elem_bytes == 4 && pick_window(nullptr, B, N, L, C, offs, vec_ok, &pk, g_fwd_rows.load(), true)) {
+  const Tuning tn = snapshot();
+  const int variant = tn.fwd_variant;
+  if (variant != 1 && elem_bytes == 4 && pick_window(tn, nullptr, B, N, L, C, offs, vec_ok, &pk, tn.fwd_rows, true)) {
     snprintf(buf, cap, "chord_fwd_win_k<f32,L=%d,TG=%d,R=%d,NT=%d> TR=%d near=%d far=%d tiles=%s", (int)L,
              1 << pk.tgs, pk.rows, pk.nt, pk.TR, pk.KN, (int)L - pk.KN,
              pk.all_edge ? "edge" : (pk.ragged ? "full+ragged" : "full"));
@@ -931,8 +953,9 @@ int psf_describe_chain_fwd(int64_t B, int64_t N, int32_t L, int64_t C, int32_t M
   if (!buf || cap < 1) return fail(PSF_E_NULL, "buf is NULL");
   if (int rc = check_dims(B, N, L, C, N * C)) return rc;
   ChainLdsPlan plan;
-  const int cf = g_chain_fused.load();
-  if (cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, g_chain_cc.load()) &&
+  const Tuning tn = snapshot();
+  const int cf = tn.chain_fused;
+  if (cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, tn.chain_cc) &&
       (cf == 2 || plan.chunks <= 8)) {
     snprintf(buf, cap, "chord_chain_lds_k<f32,L=%d,CC=%d,R=%d> one launch for all %d steps, %d threads, %d workgroup(s) per sequence",
              (int)L, plan.cc, plan.rows, (int)M, plan.threads, plan.chunks);

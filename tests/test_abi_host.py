@@ -93,6 +93,48 @@ def test_argument_validation_returns_codes_not_crashes(lib):
     assert c(None, None, None, 0, 0, 1, 8, 4, 4, 32, None, None) == 0          # M == 0
 
 
+def test_entry_points_are_callable_from_two_threads_at_once(lib):
+    """include/psf_chord.h, "Threads": host-only entry points and the validation paths of the device entry points hammered
+    from two threads while a third flips a knob; every call must return what it returns single-threaded, and each thread
+    keeps its own error string."""
+    import threading
+    one, two = ctypes.c_void_p(16), ctypes.c_void_p(32)
+    want = [0] + [2 ** k for k in range(14)]
+    errors = []
+
+    def offsets_worker():
+        buf = (ctypes.c_int64 * 15)()
+        for _ in range(3000):
+            if lib.psf_chord_offsets(16384, 15, buf) != 0 or list(buf) != want:
+                errors.append("offsets")
+            if lib.psf_describe_fwd(64, 16384, 15, 8, 4, ctypes.create_string_buffer(128), 128) != 0:
+                errors.append("describe")
+
+    def validation_worker():
+        for _ in range(3000):
+            if lib.psf_chord_spmm_fwd_f32(one, two, None, two, 1, 8, 4, 4, 32, None, None) != -3:   # PSF_E_ALIAS
+                errors.append("alias code")
+            if b"alias" not in lib.psf_last_error():
+                errors.append("alias message")
+            if lib.psf_chord_chain_fwd_f32(None, None, None, 0, 0, 1, 8, 4, 4, 32, None, None) != 0:
+                errors.append("empty chain")
+
+    def knob_worker():
+        for i in range(3000):
+            if lib.psf_set_tuning(b"fwd_rows", i & 1) != 0:
+                errors.append("set_tuning")
+            if lib.psf_chord_spmm_fwd_f32(None, one, None, two, 1, 8, 4, 4, 32, None, None) != -1 or b"non-NULL" not in lib.psf_last_error():
+                errors.append("null message")
+        lib.psf_set_tuning(b"fwd_rows", 0)
+
+    threads = [threading.Thread(target=f) for f in (offsets_worker, validation_worker, knob_worker)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, sorted(set(errors))
+
+
 def test_mixer_entry_point_states_its_limits_without_touching_the_gpu(lib):
     """psf_mixer_fwd_workspace returns -1 outside the fused path's limits (include/psf_chord.h); psf_mixer_fwd_f32 rejects
     NULL tables, short workspaces, misaligned and aliased buffers before any HIP call."""
