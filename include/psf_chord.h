@@ -297,6 +297,33 @@ int psf_mixer_fwd_f32(const float* X, int64_t B, int64_t N, int32_t E, int32_t M
                       int64_t workspace_bytes, void* stream);
 
 /*
+ * The same with `data` itself never in memory: X is replaced by the recipe PSFNet.forward computes it by, and every kernel
+ * of the mixer evaluates the rows it needs from that recipe (a step then reads 8 bytes per position instead of 4 E).
+ *   PSF_MIXER_IN_DATA    src = float X [B,N,E]                                        (psf_mixer_fwd_f32)
+ *   PSF_MIXER_IN_AFFINE  src = float in [B,N,K], K <= 3;  X = in * weight^T + bias  (+ pos[p])
+ *                        weight [E,K], bias [E] or NULL — `init_linear` of the Adding network,
+ *                        SyntheticExperiments/psf.py:136-141,153-154; the K products are summed first, then the bias
+ *   PSF_MIXER_IN_TOKENS  src = int64 tokens [B,N] in [0, K);  X = weight[token] (+ pos[p])
+ *                        weight = the embedding table [K,E], pos [N,E] or NULL — psf.py:151-152,157-162, LRA/psf.py:204-209,
+ *                        attention_block.py:150-152; one rounded add, as psf_embed_tokens_f32. Tokens are not range-checked
+ *                        (device data): an index outside [0, K) reads outside the table, as it would in nn.Embedding.
+ *   weight and pos 16-byte aligned, src aligned to its element type. Everything else as psf_mixer_fwd_f32.
+ */
+enum { PSF_MIXER_IN_DATA = 0, PSF_MIXER_IN_AFFINE = 1, PSF_MIXER_IN_TOKENS = 2 };
+typedef struct psf_mixer_input {
+  int32_t kind; /* PSF_MIXER_IN_* */
+  int32_t K;    /* AFFINE: inputs per position (1..3); TOKENS: vocabulary size; DATA: ignored */
+  const void* src;
+  const float* weight;
+  const float* bias;
+  const float* pos;
+} psf_mixer_input;
+int psf_mixer_fwd_in_f32(const psf_mixer_input* in, int64_t B, int64_t N, int32_t E, int32_t M, const float* const* A,
+                         const float* const* a, const float* const* Bw, const float* const* b, const int32_t* h, int64_t C,
+                         int32_t L, int32_t use_residual, float* V0, float* const* out_steps, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+
+/*
  * Producer side, backward (training) of the same K MLPs, fused in one pass over the tokens. What autograd does
  * for MLPBlock (SyntheticExperiments/psf.py:35-60) with 4K GEMMs, K GELU-backward kernels and K-1 accumulations
  * of the input gradient:

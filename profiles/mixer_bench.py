@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--limits", default="0")
     ap.add_argument("--only", default="")
+    ap.add_argument("--alt-lib", default="", help="a second build of the library: its mixer is timed as arm `alt` in the same process")
     ap.add_argument("--ablate", default="", help="comma list of mixer_ablate masks to time as extra arms (results are wrong)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -70,9 +71,42 @@ def main():
             def fused():
                 return fused_mixer.mixer_forward(x, g, fs, res)
 
-            arms = {"unfused": unfused, "producer": producer, "chain": chain}
+            # the same with `data` itself computed in the kernels: x = table[token] + pos (the recipe of the token networks)
+            vocab = 32
+            table = torch.randn(vocab, E, device=dev)
+            pos = torch.randn(N, E, device=dev)
+            tok = torch.randint(0, vocab, (B, N), device=dev)
+            rec = fused_mixer.Recipe.tokens(tok, table, pos)
+
+            def embed_then_unfused():
+                d = sfa.token_linear.embed_tokens(tok, _Emb(table), pos) if False else (table[tok] + pos)
+                outs_ = fused_mlp.fused_mlp_forward(d, [g, *fs])
+                return sfa.chord_chain(outs_[1:], outs_[0], res)
+
+            def fused_recipe():
+                return fused_mixer.mixer_forward_in(rec, g, fs, res)
+
+            arms = {"unfused": unfused, "producer": producer, "chain": chain, "embed+unfused": embed_then_unfused,
+                    "fused_from_tokens": fused_recipe}
             for lim in limits:
                 arms[f"fused_wg{lim}"] = (lambda lim=lim: (sfa.set_tuning("mixer_wg_limit", lim), fused())[1])
+            if args.alt_lib:
+                import ctypes
+                from sparsefactorization_amd import _lib
+                main_lib = _lib.load()
+                alt = ctypes.CDLL(os.path.abspath(args.alt_lib))
+                for fname, (argtypes, restype) in _lib.SIGNATURES.items():
+                    fn = getattr(alt, fname)
+                    fn.argtypes, fn.restype = argtypes, restype
+
+                def fused_alt():
+                    _lib._lib = alt
+                    try:
+                        return fused_mixer.mixer_forward(x, g, fs, res)
+                    finally:
+                        _lib._lib = main_lib
+
+                arms["alt"] = fused_alt
             for ab in [int(v) for v in args.ablate.split(",") if v]:
                 arms[f"ablate{ab}"] = (lambda ab=ab: (sfa.set_tuning("mixer_ablate", ab), fused(), sfa.set_tuning("mixer_ablate", 0))[1])
             a, b = unfused(), fused()

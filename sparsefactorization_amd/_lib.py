@@ -59,6 +59,9 @@ SIGNATURES = {
     "psf_mixer_fwd_f32": ([c_vp, c_i64, c_i64, c_i32, c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                            ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), c_i64, c_i32, c_i32, c_vp, ctypes.POINTER(c_vp), c_vp,
                            c_i64, c_vp], ctypes.c_int),
+    "psf_mixer_fwd_in_f32": ([c_vp, c_i64, c_i64, c_i32, c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+                              ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), c_i64, c_i32, c_i32, c_vp, ctypes.POINTER(c_vp), c_vp,
+                              c_i64, c_vp], ctypes.c_int),
     "psf_mlp_bwd_workspace": ([c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)], c_i64),
     "psf_mlp_bwd_f32": ([c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                          ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(c_vp),
@@ -78,6 +81,14 @@ SIGNATURES = {
     "psf_describe_fwd": ([c_i64, c_i64, c_i32, c_i64, c_i32, ctypes.c_char_p, c_i32], ctypes.c_int),
     "psf_describe_chain_fwd": ([c_i64, c_i64, c_i32, c_i64, c_i32, ctypes.c_char_p, c_i32], ctypes.c_int),
 }
+
+
+class MixerInput(ctypes.Structure):
+    """``psf_mixer_input`` of include/psf_chord.h."""
+    _fields_ = [("kind", c_i32), ("K", c_i32), ("src", c_vp), ("weight", c_vp), ("bias", c_vp), ("pos", c_vp)]
+
+
+MIXER_IN_DATA, MIXER_IN_AFFINE, MIXER_IN_TOKENS = 0, 1, 2
 
 
 class PSFLibraryError(RuntimeError):

@@ -53,9 +53,140 @@ struct MlpStepCfg {
 };
 
 
-template <int L, int TGS, bool RES, bool EDGE>
+
+// A lane's eight consecutive features e0 .. e0+7 of row `row` of `data` for sequence b, by the input recipe (MixerIn,
+// fwd_mlp_step_launch.h): read from X, or computed from what X itself was computed from — the affine layer of the Adding /
+// Temporal-Order networks (SyntheticExperiments/psf.py:153-154: init_linear) or the token embedding plus positional row
+// (psf.py:151-152,157-162; LRA/psf.py:204-209) — so that `data` does not have to exist in memory either.
+template <int KIND>  // compiled per recipe: with the three of them behind a run-time branch in one kernel the step took 7 % longer
+__device__ __forceinline__ void data_row8(const MixerIn& in, const float* sAff, int b, int row, int N, int E, int e0, bool skip,
+                                          float (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  if (skip) return;
+  constexpr int kind = KIND;  // (profiles/r04k_mixer_kind_ab.log: 884 us with in.kind read at run time, 826 compiled in)
+  if constexpr (kind == 0) {
+    const float* __restrict__ xr = reinterpret_cast<const float*>(in.src) + ((int64_t)b * N + row) * E;
+    if (e0 < E) {
+      const float4 lo = *reinterpret_cast<const float4*>(xr + e0);
+      v[0] = lo.x, v[1] = lo.y, v[2] = lo.z, v[3] = lo.w;
+    }
+    if (e0 + 4 < E) {
+      const float4 hi = *reinterpret_cast<const float4*>(xr + e0 + 4);
+      v[4] = hi.x, v[5] = hi.y, v[6] = hi.z, v[7] = hi.w;
+    }
+    return;
+  }
+  if constexpr (kind == 1) {  // x W_i^T + b_i with K <= 3 inputs per position; sAff[e] = {w_e0, w_e1, w_e2, b_e}
+    const float* __restrict__ xin = reinterpret_cast<const float*>(in.src) + ((int64_t)b * N + row) * in.K;
+    const float x0 = xin[0], x1 = in.K > 1 ? xin[1] : 0.f, x2 = in.K > 2 ? xin[2] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (e0 + i < E) {
+        const float4 w = *reinterpret_cast<const float4*>(sAff + 4 * (e0 + i));
+        v[i] = __fadd_rn(fmaf(x2, w.z, fmaf(x1, w.y, __fmul_rn(x0, w.x))), w.w);  // the products summed, then the bias
+      }
+  } else {  // table[token]
+    const int64_t tok = reinterpret_cast<const int64_t*>(in.src)[(int64_t)b * N + row];
+    const float* __restrict__ tr = in.weight + tok * E;
+    if (e0 < E) {
+      const float4 lo = *reinterpret_cast<const float4*>(tr + e0);
+      v[0] = lo.x, v[1] = lo.y, v[2] = lo.z, v[3] = lo.w;
+    }
+    if (e0 + 4 < E) {
+      const float4 hi = *reinterpret_cast<const float4*>(tr + e0 + 4);
+      v[4] = hi.x, v[5] = hi.y, v[6] = hi.z, v[7] = hi.w;
+    }
+  }
+  if (in.pos != nullptr) {  // + pos[p] (one rounded add, as psf_embed_tokens_f32)
+    const float* __restrict__ pr = in.pos + (int64_t)row * E;
+    if (e0 < E) {
+      const float4 lo = *reinterpret_cast<const float4*>(pr + e0);
+      v[0] = __fadd_rn(v[0], lo.x), v[1] = __fadd_rn(v[1], lo.y), v[2] = __fadd_rn(v[2], lo.z), v[3] = __fadd_rn(v[3], lo.w);
+    }
+    if (e0 + 4 < E) {
+      const float4 hi = *reinterpret_cast<const float4*>(pr + e0 + 4);
+      v[4] = __fadd_rn(v[4], hi.x), v[5] = __fadd_rn(v[5], hi.y), v[6] = __fadd_rn(v[6], hi.z), v[7] = __fadd_rn(v[7], hi.w);
+    }
+  }
+}
+
+// the affine recipe's table {w_e0, w_e1, w_e2, b_e} per feature e, 512 bytes of LDS (written before the first barrier)
+__device__ __forceinline__ void stage_affine(const MixerIn& in, float* sAff, int E, int tid) {
+  if (in.kind == 1 && tid < 32) {
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < E) {
+      w.x = in.weight[tid * in.K];
+      if (in.K > 1) w.y = in.weight[tid * in.K + 1];
+      if (in.K > 2) w.z = in.weight[tid * in.K + 2];
+      w.w = in.bias ? in.bias[tid] : 0.f;
+    }
+    *reinterpret_cast<float4*>(sAff + 4 * tid) = w;
+  }
+}
+
+// One token tile through the hidden units [u0, u1) of the MLP whose images sit at sImg: returns Y^T[o][tok] (register r of
+// lane (tok = c, half) is output o = (r & 3) + 8 (r >> 2) + 4 half), starting from the output bias when `with_bias`.
+// Weight fragments are read from the LDS image where they are used (registers: see the kernel's note on occupancy).
+__device__ __forceinline__ psf_x3::f32x16 mlp_tile(const unsigned char* sImg, int u0, int u1, bool with_bias,
+                                                   const float (&xv)[2][8], int c, int half) {
+  using namespace psf_x3;
+  auto bias4 = [&](const float* base, int q) {  // registers 4q..4q+3 are rows 8q + 4 half + (0..3)
+    return *reinterpret_cast<const float4*>(base + 8 * q + 4 * half);
+  };
+  Frag3 xf[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) xf[s] = split_pack8_pk(xv[s]);
+  f32x16 acc2;
+  {
+    const float* sb = reinterpret_cast<const float*>(sImg + kOffSb);  // the output bias is in every unit's image
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = with_bias ? bias4(sb, q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      acc2[4 * q] = v.x, acc2[4 * q + 1] = v.y, acc2[4 * q + 2] = v.z, acc2[4 * q + 3] = v.w;
+    }
+  }
+  for (int u = u0; u < u1; ++u) {
+    const unsigned char* img = sImg + u * kImgBytes;
+    const float* sa = reinterpret_cast<const float*>(img + kOffSa);
+    f32x16 acc1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = bias4(sa, q);
+      acc1[4 * q] = v.x, acc1[4 * q + 1] = v.y, acc1[4 * q + 2] = v.z, acc1[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const unsigned char* pa = img + c * kARow + 32 * s + 16 * half;
+      Frag3 wa;
+      wa.t1 = *reinterpret_cast<const bf16x8*>(pa);
+      wa.t2 = *reinterpret_cast<const bf16x8*>(pa + kATerm);
+      wa.t3 = *reinterpret_cast<const bf16x8*>(pa + 2 * kATerm);
+      acc1 = mfma6(wa, xf[s], acc1);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {  // GELU + split of registers 8s..8s+7: the B fragment of k-step s
+      float gl[8];
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        const f32x2 y = gelu2(f32x2{acc1[8 * s + i], acc1[8 * s + i + 1]});
+        gl[i] = y.x;
+        gl[i + 1] = y.y;
+      }
+      const unsigned char* pb = img + kOffB + ((s * 2 + half) * 32 + c) * 16;
+      Frag3 wb;
+      wb.t1 = *reinterpret_cast<const bf16x8*>(pb);
+      wb.t2 = *reinterpret_cast<const bf16x8*>(pb + kBTerm);
+      wb.t3 = *reinterpret_cast<const bf16x8*>(pb + 2 * kBTerm);
+      acc2 = mfma6(wb, split_pack8_pk(gl), acc2);
+    }
+  }
+  return acc2;
+}
+
+template <int L, int TGS, bool RES, bool EDGE, int KIND>
 __global__ void __launch_bounds__(256, 3)
-chord_fwd_mlp_k(const float* __restrict__ X, const float* __restrict__ V, const float* __restrict__ res,
+chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __restrict__ res,
                 float* __restrict__ out, const unsigned char* __restrict__ images, const int nu, const int E, const Geom gm,
                 const Offsets offs, const int ablate) {
   using namespace psf_x3;
@@ -68,6 +199,7 @@ chord_fwd_mlp_k(const float* __restrict__ X, const float* __restrict__ V, const 
   float* __restrict__ sW = reinterpret_cast<float*>(smem + Cfg::win_bytes);
   float* __restrict__ sPart = reinterpret_cast<float*>(smem + Cfg::win_bytes + Cfg::w_bytes);
   unsigned char* __restrict__ sImg = reinterpret_cast<unsigned char*>(smem + Cfg::img_off);
+  float* __restrict__ sAff = reinterpret_cast<float*>(smem + Cfg::img_off + nu * kImgBytes);  // 512 bytes: stage_affine
 
   int b, tile, chunk;
   decode_block(gm, b, tile, chunk);  // chunk == 0: rows of <= 32 channels are never split
@@ -83,22 +215,18 @@ chord_fwd_mlp_k(const float* __restrict__ X, const float* __restrict__ V, const 
 
   // ---- (0a) this wave's rows of `data`, straight into B-operand order: k-step s covers e = 16 s + 8 half + (0..7) ----
   const int grp = G == 1 ? 0 : wv / TT;  // which share of the hidden units this wave takes (wave-uniform)
+  if constexpr (KIND == 1) {  // the affine recipe reads its 512-byte table from LDS
+    stage_affine(in, sAff, E, tid);
+    __syncthreads();
+  }
   float xv[TPW][2][8];
 #pragma unroll
   for (int tp = 0; tp < TPW; ++tp) {
     const int t = G == 1 ? wv * TPW + tp : wv % TT;
     int row = p0 + 32 * t + c;
     if (EDGE && row >= N) row = N - 1;
-    const float* __restrict__ xr = X + ((int64_t)b * N + row) * E;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int e0 = 16 * s + 8 * half;
-      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-      if (e0 < E && !(ablate & 8)) lo = *reinterpret_cast<const float4*>(xr + e0);
-      if (e0 + 4 < E && !(ablate & 8)) hi = *reinterpret_cast<const float4*>(xr + e0 + 4);
-      xv[tp][s][0] = lo.x, xv[tp][s][1] = lo.y, xv[tp][s][2] = lo.z, xv[tp][s][3] = lo.w;
-      xv[tp][s][4] = hi.x, xv[tp][s][5] = hi.y, xv[tp][s][6] = hi.z, xv[tp][s][7] = hi.w;
-    }
+    for (int s = 0; s < 2; ++s) data_row8<KIND>(in, sAff, b, row, N, E, 16 * s + 8 * half, (ablate & 8) != 0, xv[tp][s]);
   }
 
   // ---- (0b) unit images of this step's MLP and the V window [p0, p0 + 2 TR) mod N, by LDS-DMA ----
@@ -144,58 +272,10 @@ chord_fwd_mlp_k(const float* __restrict__ X, const float* __restrict__ V, const 
   // the memory, data-row and matrix phases of the step adding up instead of overlapping).
   const int per = (nu + G - 1) / G;
   const int u0 = imin(nu, grp * per), u1 = imin(nu, u0 + per);
-  auto bias4 = [&](const float* base, int q) {  // registers 4q..4q+3 are rows 8q + 4 half + (0..3)
-    return *reinterpret_cast<const float4*>(base + 8 * q + 4 * half);
-  };
   f32x16 acc2[TPW];
 #pragma unroll
   for (int tp = 0; tp < TPW; ++tp) {
-    Frag3 xf[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) xf[s] = split_pack8_pk(xv[tp][s]);
-    {
-      const float* sb = reinterpret_cast<const float*>(sImg + kOffSb);  // the output bias is in every unit's image
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = grp == 0 ? bias4(sb, q) : make_float4(0.f, 0.f, 0.f, 0.f);
-        acc2[tp][4 * q] = v.x, acc2[tp][4 * q + 1] = v.y, acc2[tp][4 * q + 2] = v.z, acc2[tp][4 * q + 3] = v.w;
-      }
-    }
-    for (int u = (ablate & 1) ? u1 : u0; u < u1; ++u) {  // ablate & 1 (timing only): no MLP arithmetic, W = bias
-      const unsigned char* img = sImg + u * kImgBytes;
-      const float* sa = reinterpret_cast<const float*>(img + kOffSa);
-      f32x16 acc1;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = bias4(sa, q);
-        acc1[4 * q] = v.x, acc1[4 * q + 1] = v.y, acc1[4 * q + 2] = v.z, acc1[4 * q + 3] = v.w;
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const unsigned char* pa = img + c * kARow + 32 * s + 16 * half;
-        Frag3 wa;
-        wa.t1 = *reinterpret_cast<const bf16x8*>(pa);
-        wa.t2 = *reinterpret_cast<const bf16x8*>(pa + kATerm);
-        wa.t3 = *reinterpret_cast<const bf16x8*>(pa + 2 * kATerm);
-        acc1 = mfma6(wa, xf[s], acc1);
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {  // GELU + split of registers 8s..8s+7: the B fragment of k-step s
-        float gl[8];
-#pragma unroll
-        for (int i = 0; i < 8; i += 2) {
-          const f32x2 y = gelu2(f32x2{acc1[8 * s + i], acc1[8 * s + i + 1]});
-          gl[i] = y.x;
-          gl[i + 1] = y.y;
-        }
-        const unsigned char* pb = img + kOffB + ((s * 2 + half) * 32 + c) * 16;
-        Frag3 wb;
-        wb.t1 = *reinterpret_cast<const bf16x8*>(pb);
-        wb.t2 = *reinterpret_cast<const bf16x8*>(pb + kBTerm);
-        wb.t3 = *reinterpret_cast<const bf16x8*>(pb + 2 * kBTerm);
-        acc2[tp] = mfma6(wb, split_pack8_pk(gl), acc2[tp]);
-      }
-    }
+    acc2[tp] = mlp_tile(sImg, (ablate & 1) ? u1 : u0, u1, grp == 0, xv[tp], c, half);  // ablate & 1 (timing only): W = bias
     if constexpr (G == 1) {  // the finished tile goes to LDS at once (its registers are free for the next tile)
       constexpr int NQ1 = (L + 7) / 8;
       float* dst = sW + (32 * (wv * TPW + tp) + c) * WS;
@@ -290,6 +370,49 @@ chord_fwd_mlp_k(const float* __restrict__ X, const float* __restrict__ V, const 
   for (int j = 0; j < R; ++j) {
     const int p = p0 + j * RS + rs;
     if (!EDGE || (p < N && cg_ok)) st<float, 4>(out + ((int64_t)b * N + p) * C + (int64_t)g * 4, acc[j]);
+  }
+}
+
+// V0 = g(data) on the same tiles: the matrix phase only (MLP 0: E -> h -> C), its Y^T tiles stored as rows of V0. A wave takes
+// whole token tiles with all hidden units (waves beyond the tile count idle: one launch per forward, not the hot kernel).
+template <int TGS, bool EDGE, int KIND>
+__global__ void __launch_bounds__(256, 3)
+chord_mixer_g_k(const MixerIn in, float* __restrict__ out, const unsigned char* __restrict__ images, const int nu, const int E,
+                const Geom gm) {
+  using namespace psf_x3;
+  constexpr int TR = mlp_step_tile_rows(TGS), TT = TR / 32, NW = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned char* __restrict__ sImg = reinterpret_cast<unsigned char*>(smem);
+  float* __restrict__ sAff = reinterpret_cast<float*>(smem + nu * kImgBytes);
+  int b, tile, chunk;
+  decode_block(gm, b, tile, chunk);
+  const int p0 = tile * TR, N = gm.N, C = gm.C;
+  const int tid = threadIdx.x, lane = tid & 63, wave64 = tid & ~63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, half = lane >> 5;
+  const int img_vecs = nu * kImgVecs;
+  for (int v0 = 0; v0 < img_vecs; v0 += 256) {
+    const int v = v0 + tid;
+    if (v < img_vecs)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(images + 16 * (size_t)v),
+                                       (__attribute__((address_space(3))) void*)(sImg + 16 * (v0 + wave64)), 16, 0, 0);
+  }
+  stage_affine(in, sAff, E, tid);
+  __syncthreads();
+  for (int t = wv; t < TT; t += NW) {  // wave-uniform
+    const int row = p0 + 32 * t + c;
+    const int rowc = (EDGE && row >= N) ? N - 1 : row;
+    float xv[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) data_row8<KIND>(in, sAff, b, rowc, N, E, 16 * s + 8 * half, false, xv[s]);
+    const f32x16 y = mlp_tile(sImg, 0, nu, true, xv, c, half);
+    if (!EDGE || row < N) {
+      float* __restrict__ orow = out + ((int64_t)b * N + row) * C;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (8 * q + 4 * half < C)  // C is a multiple of 4: whole 16-byte groups
+          *reinterpret_cast<float4*>(orow + 8 * q + 4 * half) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+    }
   }
 }
 

@@ -77,7 +77,7 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
 }
 
 // One workgroup per unit: split the weights and write them in operand order.
-__global__ void __launch_bounds__(256) x3_pack_k(const X3Args a) {
+__attribute__((unused)) __global__ void __launch_bounds__(256) x3_pack_k(const X3Args a) {  // (not every includer packs)
   using namespace psf_x3;
   const int u = blockIdx.x;
   const X3Mlp d = a.m[a.unit[u] & 0xff];

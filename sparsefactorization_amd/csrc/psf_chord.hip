@@ -707,6 +707,16 @@ bool plan_mixer(int64_t N, int32_t E, int32_t M, const int32_t* h, int64_t C, in
   return true;
 }
 
+hipError_t launch_g(int tgs, const FwdMlpArgs& a) {
+  switch (tgs) {
+    case 0: return launch_mixer_g<0>(a);
+    case 1: return launch_mixer_g<1>(a);
+    case 2: return launch_mixer_g<2>(a);
+    case 3: return launch_mixer_g<3>(a);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_mlp_step(int tgs, int L, const FwdMlpArgs& a) {
   switch (tgs) {
     case 0: return launch_fwd_mlp<0>(L, a);
@@ -843,11 +853,32 @@ int64_t psf_mixer_fwd_workspace(int64_t N, int32_t E, int32_t M, const int32_t* 
   return (int64_t)mp.units * kX3ImageBytes;
 }
 
-int psf_mixer_fwd_f32(const float* X, int64_t B, int64_t N, int32_t E, int32_t M, const float* const* A,
-                      const float* const* a, const float* const* Bw, const float* const* b, const int32_t* h, int64_t C,
-                      int32_t L, int32_t use_residual, float* V0, float* const* out_steps, void* workspace,
-                      int64_t workspace_bytes, void* stream) {
-  if (!X || !A || !a || !Bw || !b || !h || !V0 || !out_steps || !workspace) return fail(PSF_E_NULL, "psf_mixer_fwd: NULL argument");
+int psf_mixer_fwd_in_f32(const psf_mixer_input* in, int64_t B, int64_t N, int32_t E, int32_t M, const float* const* A,
+                         const float* const* a, const float* const* Bw, const float* const* b, const int32_t* h, int64_t C,
+                         int32_t L, int32_t use_residual, float* V0, float* const* out_steps, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+  if (!in || !in->src || !A || !a || !Bw || !b || !h || !V0 || !out_steps || !workspace)
+    return fail(PSF_E_NULL, "psf_mixer_fwd: NULL argument");
+  MixerIn mi;
+  mi.src = in->src, mi.weight = in->weight, mi.bias = in->bias, mi.pos = in->pos, mi.kind = in->kind, mi.K = in->K;
+  if (in->kind == PSF_MIXER_IN_DATA) {
+    mi.weight = mi.bias = mi.pos = nullptr, mi.K = 0;
+    if (!aligned_to(in->src, 16)) return fail(PSF_E_ALIGN, "psf_mixer_fwd: X must be 16-byte aligned");
+  } else if (in->kind == PSF_MIXER_IN_AFFINE) {
+    if (in->K < 1 || in->K > 3) return fail(PSF_E_SHAPE, "psf_mixer_fwd: the affine input takes 1..3 values per position (K=%d)", (int)in->K);
+    if (!in->weight) return fail(PSF_E_NULL, "psf_mixer_fwd: affine input without a weight");
+    if (!aligned_to(in->src, 4) || !aligned_to(in->weight, 4) || (in->bias && !aligned_to(in->bias, 4)))
+      return fail(PSF_E_ALIGN, "psf_mixer_fwd: affine input pointers must be 4-byte aligned");
+  } else if (in->kind == PSF_MIXER_IN_TOKENS) {
+    if (in->K < 1) return fail(PSF_E_SHAPE, "psf_mixer_fwd: empty vocabulary");
+    if (!in->weight) return fail(PSF_E_NULL, "psf_mixer_fwd: token input without a table");
+    if (!aligned_to(in->src, 8) || !aligned_to(in->weight, 16))
+      return fail(PSF_E_ALIGN, "psf_mixer_fwd: tokens must be 8-byte, the table 16-byte aligned");
+    mi.bias = nullptr;
+  } else {
+    return fail(PSF_E_SHAPE, "psf_mixer_fwd: unknown input kind %d", (int)in->kind);
+  }
+  if (mi.pos && !aligned_to(mi.pos, 16)) return fail(PSF_E_ALIGN, "psf_mixer_fwd: pos must be 16-byte aligned");
   MixerPlan mp;
   if (!plan_mixer(N, E, M, h, C, L, &mp))
     return fail(PSF_E_SHAPE, "psf_mixer_fwd: shape outside the fused path (N=%lld E=%d M=%d C=%lld L=%d; see psf_mixer_fwd_workspace)",
@@ -856,7 +887,7 @@ int psf_mixer_fwd_f32(const float* X, int64_t B, int64_t N, int32_t E, int32_t M
   if (B == 0) return PSF_OK;
   if (workspace_bytes < (int64_t)mp.units * kX3ImageBytes || !aligned_to(workspace, 16))
     return fail(PSF_E_SHAPE, "psf_mixer_fwd: workspace too small (psf_mixer_fwd_workspace) or not 16-byte aligned");
-  if (!aligned_to(X, 16) || !aligned_to(V0, 16)) return fail(PSF_E_ALIGN, "psf_mixer_fwd: X and V0 must be 16-byte aligned");
+  if (!aligned_to(V0, 16)) return fail(PSF_E_ALIGN, "psf_mixer_fwd: V0 must be 16-byte aligned");
   if (B * N > (int64_t)1 << 40) return fail(PSF_E_SHAPE, "psf_mixer_fwd: B*N too large");
   for (int k = 0; k <= M; ++k)
     if (!A[k] || !a[k] || !Bw[k] || !b[k]) return fail(PSF_E_NULL, "psf_mixer_fwd: NULL layer pointer (MLP %d)", k);
@@ -869,17 +900,13 @@ int psf_mixer_fwd_f32(const float* X, int64_t B, int64_t N, int32_t E, int32_t M
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Tuning tn = snapshot();
 
-  // (1) all M + 1 weight sets -> unit images (one launch); (2) V0 = g(X) from the first of them
+  // (1) all M + 1 weight sets -> unit images (one launch)
   int32_t O[32], first_unit[33];
   O[0] = (int32_t)C;
   for (int k = 1; k <= M; ++k) O[k] = L;
   hipError_t e = psf_x3_pack_launch(E, M + 1, A, a, Bw, b, h, O, workspace, first_unit, s);
   if (e != hipSuccess) return fail_hip(e, "psf_mixer_fwd: pack");
-  float* y0[1] = {V0};
-  e = psf_x3_mlp_fwd_launch(X, B * N, E, 1, A, a, Bw, b, h, O, y0, workspace, s, /*packed=*/true);
-  if (e != hipSuccess) return fail_hip(e, "psf_mixer_fwd: g");
-
-  // (3) the M steps
+  // the tile geometry of every launch below
   Offsets offs;
   make_offsets(N, L, nullptr, &offs);
   WinPick pk;
@@ -888,9 +915,25 @@ int psf_mixer_fwd_f32(const float* X, int64_t B, int64_t N, int32_t E, int32_t M
   pk.ragged = (N % mp.TR) != 0;
   const int TG = 1 << mp.tgs;
   pk.all_edge = ((C / 4) % TG) != 0 || !tn.fwd_split || ragged_in_one_launch(tn, pk.ragged, B, N, E, C);  // (E: this step moves the data row, not the W row)
-  for (int m = 0; m < M; ++m) {
+  {  // (2) V0 = g(data): the matrix phase alone, on the same tiles
     FwdMlpArgs fa;
-    fa.X = X;
+    fa.in = mi;
+    fa.V = fa.res = nullptr;
+    fa.out = V0;
+    fa.images = reinterpret_cast<const unsigned char*>(workspace);
+    fa.nu = first_unit[1] - first_unit[0];
+    fa.E = E;
+    fa.offs = offs;
+    fa.wg_per_cu = fa.ablate = 0;
+    fa.stream = s;
+    const bool edge_all = pk.ragged && pk.all_edge;  // the g kernel needs its predicate only for rows >= N
+    const int rc = window_launches(tn, pk, edge_all, B, N, L, C, N * C, false, &fa.gm, &fa.edge,
+                                   [&] { return launch_g(mp.tgs, fa); }, "chord_mixer_g launch");
+    if (rc) return rc;
+  }
+  for (int m = 0; m < M; ++m) {  // (3) the M steps
+    FwdMlpArgs fa;
+    fa.in = mi;
     fa.V = m == 0 ? V0 : out_steps[m - 1];
     fa.res = use_residual ? V0 : nullptr;
     fa.out = out_steps[m];
@@ -907,6 +950,15 @@ int psf_mixer_fwd_f32(const float* X, int64_t B, int64_t N, int32_t E, int32_t M
     if (rc) return rc;
   }
   return PSF_OK;
+}
+
+int psf_mixer_fwd_f32(const float* X, int64_t B, int64_t N, int32_t E, int32_t M, const float* const* A,
+                      const float* const* a, const float* const* Bw, const float* const* b, const int32_t* h, int64_t C,
+                      int32_t L, int32_t use_residual, float* V0, float* const* out_steps, void* workspace,
+                      int64_t workspace_bytes, void* stream) {
+  psf_mixer_input in;
+  in.kind = PSF_MIXER_IN_DATA, in.K = 0, in.src = X, in.weight = in.bias = in.pos = nullptr;
+  return psf_mixer_fwd_in_f32(&in, B, N, E, M, A, a, Bw, b, h, C, L, use_residual, V0, out_steps, workspace, workspace_bytes, stream);
 }
 
 int psf_set_tuning(const char* key, int32_t value) {

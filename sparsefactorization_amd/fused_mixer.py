@@ -22,52 +22,111 @@ enabled = True  # module-level switch (tests / A-B timing)
 #: weight image per tile, 14 KB per 32 hidden rows, which short tiles (C = 32: 64 rows) and 128-wide hidden layers do not
 #: amortise); "always": wherever the shape is covered; "never".
 route = "auto"
+#: Evaluate the embedding lookup inside the mixer kernels (Recipe.tokens) instead of materialising ``data`` with
+#: psf_embed_tokens_f32 first. Off: the lookup makes the table and positional loads depend on the token load, which lengthens
+#: every workgroup's load phase — 712 against 609 + 28 us at Temporal Order's shape (N = 16384, B = 40), 1040 against 885 + 42 at
+#: B = 64 (profiles/r04h_mixer_bench.log). The affine recipe (Adding's init_linear, an 80 us library GEMM for a K = 2
+#: product) has no such dependency and is always taken.
+tokens_in_kernel = False
 
 
-def _sizes(x: torch.Tensor, g: nn.Module, fs: Sequence[nn.Module]):
-    """(N, E, M, h table, C, L) when every block is Linear, GELU(erf), Linear on x's width and the link MLPs agree on L."""
-    if x.dim() != 3 or not len(fs):
+class Recipe:
+    """How ``data`` [B, N, E] comes about (include/psf_chord.h: psf_mixer_input): given (``data``), an affine map of a few
+    inputs per position (``affine``: init_linear of the Adding network, psf.py:153-154) or an embedding lookup (``tokens``:
+    psf.py:151-152), each optionally plus a positional row. With the last two, ``data`` is never written to memory."""
+
+    def __init__(self, kind, src, weight=None, bias=None, pos=None, K=0, E=None):
+        self.kind, self.src, self.weight, self.bias, self.pos, self.K = kind, src, weight, bias, pos, K
+        self.E = E if E is not None else (src.shape[-1] if kind == _lib.MIXER_IN_DATA else weight.shape[0 if kind == _lib.MIXER_IN_AFFINE else 1])
+
+    @staticmethod
+    def data(x):
+        return Recipe(_lib.MIXER_IN_DATA, x)
+
+    @staticmethod
+    def affine(inp, linear: nn.Linear, pos=None):
+        return Recipe(_lib.MIXER_IN_AFFINE, inp, linear.weight, linear.bias, pos, K=inp.shape[-1])
+
+    @staticmethod
+    def tokens(idx, table: torch.Tensor, pos=None):
+        return Recipe(_lib.MIXER_IN_TOKENS, idx, table, None, pos, K=table.shape[0])
+
+    @property
+    def B(self):
+        return self.src.shape[0]
+
+    @property
+    def N(self):
+        return self.src.shape[1]
+
+    def tensors(self):
+        return [t for t in (self.src, self.weight, self.bias, self.pos) if t is not None]
+
+    def ok(self):
+        """Shapes and dtypes the library takes; anything else makes the caller materialise ``data`` instead."""
+        s = self.src
+        if not s.is_cuda:
+            return False
+        if self.kind == _lib.MIXER_IN_DATA:
+            return s.dim() == 3 and s.dtype == torch.float32
+        if self.pos is not None and (self.pos.dtype != torch.float32 or tuple(self.pos.shape) != (self.N, self.E)):
+            return False
+        if self.kind == _lib.MIXER_IN_AFFINE:
+            return (s.dim() == 3 and s.dtype == torch.float32 and 1 <= s.shape[-1] <= 3 and self.weight.dtype == torch.float32
+                    and tuple(self.weight.shape) == (self.E, s.shape[-1]))
+        return s.dim() == 2 and s.dtype == torch.int64 and self.weight.dtype == torch.float32 and self.weight.dim() == 2
+
+
+def _block_sizes(E: int, g: nn.Module, fs: Sequence[nn.Module]):
+    """(M, h table, C, L) when every block is Linear, GELU(erf), Linear of input width E and the link MLPs agree on L."""
+    if not len(fs):
         return None
     pairs = [_two_layer(b) for b in [g, *fs]]
     if any(p is None for p in pairs):
         return None
-    E = x.shape[-1]
     if any(l1.in_features != E or l1.weight.dtype != torch.float32 for l1, _ in pairs):
         return None
     L = pairs[1][1].out_features
     if any(l2.out_features != L for _, l2 in pairs[1:]):
         return None
     h = (ctypes.c_int32 * len(pairs))(*[l1.out_features for l1, _ in pairs])
-    return x.shape[1], E, len(fs), h, pairs[0][1].out_features, L
+    return len(fs), h, pairs[0][1].out_features, L
 
 
-def eligible(x: torch.Tensor, g: nn.Module, fs: Sequence[nn.Module]) -> bool:
-    if not enabled or not x.is_cuda or x.dtype != torch.float32 or _needs_grad(x, [g, *fs]):
+def _route_ok(N: int, C: int, h) -> bool:
+    return route == "always" or (route == "auto" and N >= 8192 and C <= 16 and max(h) <= 32)
+
+
+def eligible_recipe(r: Recipe, g: nn.Module, fs: Sequence[nn.Module]) -> bool:
+    """The fused mixer can run from this recipe, nothing needs a gradient, and ``route`` wants it."""
+    if not enabled or not r.ok() or torch.is_grad_enabled() and any(t.requires_grad for t in r.tensors() if t.is_floating_point()):
         return False
-    sz = _sizes(x, g, fs)
+    if r.kind == _lib.MIXER_IN_TOKENS and not tokens_in_kernel:
+        return False
+    if _needs_grad(torch.empty(0), [g, *fs]):
+        return False
+    sz = _block_sizes(r.E, g, fs)
     if sz is None:
         return False
-    N, E, M, h, C, L = sz
-    if route == "never" or (route == "auto" and not (N >= 8192 and C <= 16 and max(h) <= 32)):
-        return False
-    return _lib.load().psf_mixer_fwd_workspace(N, E, M, h, C, L) >= 0
+    M, h, C, L = sz
+    return _route_ok(r.N, C, h) and _lib.load().psf_mixer_fwd_workspace(r.N, r.E, M, h, C, L) >= 0
 
 
-def covered(x: torch.Tensor, g: nn.Module, fs: Sequence[nn.Module]) -> bool:
-    """The shape is inside the fused path's limits (whatever ``route`` says about using it)."""
-    sz = _sizes(x, g, fs)
-    return sz is not None and x.is_cuda and x.dtype == torch.float32 and _lib.load().psf_mixer_fwd_workspace(*sz) >= 0
-
-
-def mixer_forward(x: torch.Tensor, g: nn.Module, fs: Sequence[nn.Module], use_residual: bool) -> torch.Tensor:
-    """V_M [B, N, C] from ``data`` [B, N, E]. Caller checks ``eligible`` first."""
-    N, E, M, h, C, L = _sizes(x, g, fs)
-    B = x.shape[0]
-    dev = x.device
+def mixer_forward_in(r: Recipe, g: nn.Module, fs: Sequence[nn.Module], use_residual: bool) -> torch.Tensor:
+    """V_M [B, N, C] from the recipe of ``data``. Caller checks ``eligible_recipe`` (or ``covered``) first."""
+    M, h, C, L = _block_sizes(r.E, g, fs)
+    B, N, E = r.B, r.N, r.E
+    dev = r.src.device
     lib = _lib.load()
-    x3 = x.detach().contiguous()
-    if x3.data_ptr() % 16:
-        x3 = x3.clone()
+
+    def prep(t, align):
+        if t is None:
+            return None
+        t = t.detach().contiguous()
+        return t if t.data_ptr() % align == 0 else t.clone()
+
+    keep = [prep(r.src, 16 if r.kind == _lib.MIXER_IN_DATA else 8), prep(r.weight, 16), prep(r.bias, 4), prep(r.pos, 16)]
+    spec = _lib.MixerInput(r.kind, int(r.K), *[t.data_ptr() if t is not None else None for t in keep])
     params = [p.detach().contiguous() for p in _params_of([g, *fs])]
     ws_bytes = lib.psf_mixer_fwd_workspace(N, E, M, h, C, L)
     if ws_bytes < 0:
@@ -77,8 +136,31 @@ def mixer_forward(x: torch.Tensor, g: nn.Module, fs: Sequence[nn.Module], use_re
     bufs = [torch.empty_like(V0) for _ in range(min(M, 2))]
     o_tab = (ctypes.c_void_p * M)(*[bufs[m % len(bufs)].data_ptr() for m in range(M)])
     with torch.cuda.device(dev):
-        rc = lib.psf_mixer_fwd_f32(x3.data_ptr(), B, N, E, M, _ptrs(params[0::4]), _ptrs(params[1::4]), _ptrs(params[2::4]),
-                                   _ptrs(params[3::4]), h, C, L, 1 if use_residual else 0, V0.data_ptr(), o_tab, ws.data_ptr(),
-                                   ws_bytes, torch.cuda.current_stream(dev).cuda_stream)
-    _lib.check(rc, "psf_mixer_fwd_f32")
+        rc = lib.psf_mixer_fwd_in_f32(ctypes.byref(spec), B, N, E, M, _ptrs(params[0::4]), _ptrs(params[1::4]), _ptrs(params[2::4]),
+                                      _ptrs(params[3::4]), h, C, L, 1 if use_residual else 0, V0.data_ptr(), o_tab, ws.data_ptr(),
+                                      ws_bytes, torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "psf_mixer_fwd_in_f32")
     return bufs[(M - 1) % len(bufs)]
+
+
+def _sizes(x: torch.Tensor, g: nn.Module, fs: Sequence[nn.Module]):
+    """(N, E, M, h table, C, L) for ``data`` given as a tensor, or None."""
+    if x.dim() != 3:
+        return None
+    sz = _block_sizes(x.shape[-1], g, fs)
+    return None if sz is None else (x.shape[1], x.shape[-1], *sz)
+
+
+def eligible(x: torch.Tensor, g: nn.Module, fs: Sequence[nn.Module]) -> bool:
+    return eligible_recipe(Recipe.data(x), g, fs) and not x.requires_grad
+
+
+def covered(x: torch.Tensor, g: nn.Module, fs: Sequence[nn.Module]) -> bool:
+    """The shape is inside the fused path's limits (whatever ``route`` says about using it)."""
+    sz = _sizes(x, g, fs)
+    return sz is not None and x.is_cuda and x.dtype == torch.float32 and _lib.load().psf_mixer_fwd_workspace(*sz) >= 0
+
+
+def mixer_forward(x: torch.Tensor, g: nn.Module, fs: Sequence[nn.Module], use_residual: bool) -> torch.Tensor:
+    """V_M [B, N, C] from ``data`` [B, N, E]. Caller checks ``eligible`` (or ``covered``) first."""
+    return mixer_forward_in(Recipe.data(x), g, fs, use_residual)

@@ -198,6 +198,13 @@ class _ChordMixer(nn.Module):
             return outs[0], outs[1:]
         return self.g(data), self.link_weights(data)
 
+    def mix_from_recipe(self, recipe, use_residuals: bool):
+        """V_M from the RECIPE of ``data`` (fused_mixer.Recipe: the affine input layer or the embedding lookup that PSFNet
+        applies first, psf.py:151-162): neither ``data`` nor any W_m is written to memory. None when that path does not apply."""
+        if recipe is not None and self.fused_chain and fused_mixer.eligible_recipe(recipe, self.g, list(self.fs)):
+            return fused_mixer.mixer_forward_in(recipe, self.g, list(self.fs), use_residuals)
+        return None
+
     def mix_from_data(self, data: torch.Tensor, use_residuals: bool):
         """V_M straight from ``data`` with every W_m computed inside its chain step and never written (fused_mixer.py,
         csrc/fwd_mlp_step.h) — psf.py:165-188 in M + 2 launches. None when that path does not apply (a gradient is
@@ -250,7 +257,21 @@ class SyntheticPSFNet(_ChordMixer):
             self.init_linear = TokenLinear(2, embedding_size, bias=True)
         self._build_indices(n_vec, self.n_links, use_cuda)
 
+    def _recipe(self, data):
+        """How ``forward`` obtains its ``data`` from the raw batch, when that is one lookup or one affine layer."""
+        pos = self.pos_embedding.weight if self.use_pos_embedding else None
+        if self.problem == 'order':
+            if data.dim() == 3 and data.size(-1) == 1 and not self.add_init_linear_layer and data.dtype == torch.int64:
+                return fused_mixer.Recipe.tokens(data.squeeze(-1), self.embedding.weight, pos)
+            return None
+        if self.add_init_linear_layer and data.dim() == 3 and data.is_floating_point() and data.size(-1) <= 3:
+            return fused_mixer.Recipe.affine(data, self.init_linear, pos)
+        return None
+
     def forward(self, data):
+        V = self.mix_from_recipe(self._recipe(data), self.use_residuals)
+        if V is not None:
+            return _flat_head(self.final, V.reshape(V.size(0), -1))
         pos_done = False
         if self.problem == 'order':
             if data.dim() == 3 and data.size(-1) == 1:
@@ -324,6 +345,13 @@ class _TokenPSFNet(_ChordMixer):
     def features(self, data, links=None):
         """Everything up to and including the chain and dropout3: returns V [B,N,C]. When ``links`` is a
         list it is filled with the W_m that were used."""
+        quiet = not self.training or (self.dropout1.p == 0 and self.dropout2.p == 0)  # dropout1 / 2 sit inside what is fused
+        if links is None and quiet and data.dim() == 2 and data.dtype == torch.int64:
+            V = self.mix_from_recipe(fused_mixer.Recipe.tokens(data, self.embedding.weight,
+                                                               self.pos_embedding.weight if self.use_pos_embedding else None),
+                                     self.use_residuals)
+            if V is not None:
+                return self.dropout3(V)
         data = embed_tokens(data, self.embedding, self.pos_embedding.weight if self.use_pos_embedding else None)
         data = self.dropout1(data)
         if links is None and not (self.training and self.dropout2.p > 0):  # dropout2 sits between g and the loop
@@ -411,6 +439,11 @@ class AttentionBlockPSF(_ChordMixer):
         self.apc_embedding = nn.Embedding(max_seq_len, embedding_size)
 
     def forward(self, data):
+        if (not self.training or (self.dropout1.p == 0 and self.dropout2.p == 0)) and data.dim() == 2 and data.dtype == torch.int64:
+            V = self.mix_from_recipe(fused_mixer.Recipe.tokens(data, self.embedding.weight, self.apc_embedding.weight),
+                                     self.use_residuals)
+            if V is not None:
+                return self.dropout3(V)
         data = embed_tokens(data, self.embedding, self.apc_embedding.weight)
         data = self.dropout1(data)
         V = None if (self.training and self.dropout2.p > 0) else self.mix_from_data(data, self.use_residuals)

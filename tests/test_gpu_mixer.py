@@ -78,6 +78,53 @@ def test_mixer_matches_the_oracle_chain_fed_with_float64_mlp_w(gpu, name, B, N, 
     assert rel_inf(got, want) <= TOL, f"{name}: rel {rel_inf(got, want):.3e}"
 
 
+RECIPE_CASES = [
+    # name, kind, B, N, E, h, C, L, M, residual, with positional rows, K (inputs per position / vocabulary)
+    ("adding_affine", "affine", 3, 16384, 32, 32, 8, 15, 14, True, False, 2),
+    ("order_tokens_pos", "tokens", 3, 16384, 32, 32, 8, 15, 14, True, True, 6),
+    ("pathfinder_tokens_pos", "tokens", 3, 1024, 32, 128, 32, 12, 11, False, True, 225),
+    ("imdb_tokens_ragged", "tokens", 2, 4097, 32, 128, 32, 13, 12, True, True, 95),
+    ("cifar_tokens_e16", "tokens", 3, 1024, 16, 16, 16, 11, 10, False, True, 256),
+    ("affine_k3_pos_e12", "affine", 2, 600, 12, 40, 12, 9, 5, True, True, 3),
+    ("tokens_nopos_c4", "tokens", 2, 1000, 8, 24, 4, 10, 4, False, False, 11),
+]
+
+
+@pytest.mark.parametrize("name,kind,B,N,E,h,C,L,M,residual,with_pos,K", RECIPE_CASES, ids=[c[0] for c in RECIPE_CASES])
+def test_mixer_from_the_recipe_of_data_matches_the_float64_reference(gpu, name, kind, B, N, E, h, C, L, M, residual, with_pos, K):
+    """psf_mixer_fwd_in_f32: `data` is never materialised — the kernels evaluate the rows they need from the affine input
+    layer (init_linear, psf.py:153-154) or the embedding lookup (+ positional rows, psf.py:151-162). Reference: data in
+    float64 from the same raw inputs, the MLPs in float64, the oracle's f32 chain."""
+    from sparsefactorization_amd import fused_mixer
+    g, fs = _blocks(E, h, C, L, M, seed=21)
+    gen = torch.Generator().manual_seed(8)
+    pos = 0.5 * torch.randn(N, E, generator=gen) if with_pos else None
+    if kind == "affine":
+        lin = nn.Linear(K, E)
+        inp = torch.rand(B, N, K, generator=gen) * 2 - 1
+        data64 = torch.nn.functional.linear(inp.double(), lin.weight.double(), lin.bias.double())
+    else:
+        table = torch.randn(K, E, generator=gen)
+        inp = torch.randint(0, K, (B, N), generator=gen)
+        data64 = table.double()[inp]
+    if pos is not None:
+        data64 = data64 + pos.double()
+    want, _ = _reference(data64.float(), g, fs, residual)  # (the reference rounds data to f32 once, as the network does)
+    g.to(gpu)
+    for f in fs:
+        f.to(gpu)
+    posd = pos.to(gpu) if pos is not None else None
+    if kind == "affine":
+        r = fused_mixer.Recipe.affine(inp.to(gpu), lin.to(gpu), posd)
+    else:
+        r = fused_mixer.Recipe.tokens(inp.to(gpu), table.to(gpu), posd)
+    with torch.no_grad():
+        assert r.ok()
+        got = fused_mixer.mixer_forward_in(r, g, fs, residual).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_inf(got, want) <= TOL, f"{name}: rel {rel_inf(got, want):.3e}"
+
+
 def test_mixer_equals_producer_plus_chain_closely(gpu):
     """The same network through the two routes of this package: W_m written by psf_mlp_fwd_f32 and read by the chain, and W_m
     computed inside the step. Same split-bf16 arithmetic for W, same chain order: they agree far below the parity bar."""
@@ -126,14 +173,17 @@ def test_mixer_is_deterministic_and_leaves_v0_intact(gpu):
 
 
 def test_nets_take_the_fused_mixer_in_inference_and_agree_with_the_unfused_route(gpu):
-    """SyntheticPSFNet (Adding, N = 2048) and the LRA network (Pathfinder widths) under no_grad: with fused_mixer on, no
-    W_m is produced (the chain entry point is never called); logits agree with the unfused route to 1e-5."""
+    """SyntheticPSFNet (Adding and Temporal Order, N = 8192) and the LRA network (Pathfinder widths) under no_grad: with the
+    fused mixer on ("always": the token recipe too), neither `data` nor any W_m is produced (the chain entry point is never
+    called); logits agree with the unfused route to 1e-5."""
     from sparsefactorization_amd import chord, fused_mixer
     from sparsefactorization_amd.psfnet import LRAPSFNet, SyntheticPSFNet
     torch.manual_seed(0)
     nets = [
         (SyntheticPSFNet(1, True, 32, 8192, 13, [32, 'GELU'], [32, 'GELU'], 8, 1, 'FLATTEN', ['linear'], True, True, False,
                          'adding'), torch.rand(4, 8192, 2, device=gpu)),
+        (SyntheticPSFNet(6, False, 32, 8192, 13, [32, 'GELU'], [32, 'GELU'], 8, 4, 'FLATTEN', ['linear'], True, True, True,
+                         'order'), torch.randint(0, 6, (4, 8192, 1), device=gpu)),
         (LRAPSFNet(225, 32, 1024, 11, [128, 'GELU'], [128, 'GELU'], 32, 2, 'FLATTEN', ['linear'], True, False, 0.1, 0.1, 0.1,
                    False, True, 'pathfinder'), torch.randint(0, 225, (4, 1024), device=gpu)),
     ]
@@ -152,11 +202,13 @@ def test_nets_take_the_fused_mixer_in_inference_and_agree_with_the_unfused_route
             import sparsefactorization_amd.psfnet as pn
             pn.chord_chain = spy
             fused_mixer.route = "always"  # (the automatic rule keeps the Pathfinder widths on the W-through-memory route)
+            fused_mixer.tokens_in_kernel = True
             try:
                 got = net(x)
             finally:
                 pn.chord_chain = orig
                 fused_mixer.route = "auto"
+                fused_mixer.tokens_in_kernel = False
         assert not calls, "the fused mixer path must not run the W-from-memory chain"
         assert rel_inf(got.cpu().numpy(), want.cpu().numpy()) <= 1e-5
         net.train()  # dropout active / gradients wanted: the fused inference path must step aside
