@@ -51,7 +51,9 @@ struct X3Args {
 // elements per instruction — the kernel is VALU-issue-bound, rocprofv3: ~70 % VALU-busy, 22 % matrix-pipe-busy).
 // Phi by Abramowitz & Stegun 26.2.17 (the normal-CDF form of 7.1.26, |error| <= 7.5e-8):
 //   t = 1 / (1 + 0.2316419 |x|),  q = exp(-x^2/2)/sqrt(2 pi) * (b1 t + ... + b5 t^5),  Phi = x >= 0 ? 1 - q : q
-// with 1/sqrt(2 pi) folded into the b's and exp as exp2(x^2 * -0.5 log2 e): 19 instructions per pair.
+// with 1/sqrt(2 pi) folded into the b's and exp as exp2(x^2 * -0.5 log2 e): 19 instructions per pair. (The same arithmetic on
+// scalar f32 instructions with -fno-slp-vectorize, in the step kernel of fwd_mlp_step.h: 821.7 against 809.6 us per mixer
+// forward at cfg2, one process, seven rounds — packed stays.)
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
   f32x2 t;
