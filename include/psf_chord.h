@@ -287,6 +287,10 @@ int psf_mlp_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
  *   the result is out_steps[M-1]. Chord offsets only.
  *   Limits: E a multiple of 4, 4 <= E <= 32; 1 <= h[k] <= 128; C a multiple of 4, 4 <= C <= 32; 4 <= L <= 20; 1 <= M <= 31;
  *   N at least two tiles (tile = 256, 256, 128, 64 rows for C <= 4, 8, 16, 32); X, V0 and out_steps 16-byte aligned.
+ *   Short sequences (N a multiple of 32, N * C / 4 <= 1024, C = 4 or 8 — BASELINE configs[0], Adding N = 128, among them) run
+ *   as ONE launch in which V also stays on chip: a workgroup owns a sequence, keeps its data rows in registers and its V in
+ *   LDS through all M steps (csrc/mixer_lds.h; knob "mixer_lds"); a step buffer that a later step overwrites is then not
+ *   stored at all, as in psf_chord_chain_fwd_f32.
  *   psf_mixer_fwd_workspace returns the bytes of 16-byte-aligned device scratch needed (packed weight images), or -1 when
  *   the fused path does not cover the shape — the caller then uses psf_mlp_fwd_f32 + psf_chord_chain_fwd_f32.
  */
@@ -432,6 +436,7 @@ int psf_stream_mix_f32(const float* w, const float* v, const float* r, float* ou
  *                      stores — three workgroups per CU —, round 2's length rule otherwise), 1, 2 = forced (equal bits)
  *   key "wide_fuse"  : psf_mlp_wide_fwd_f32: 1 = the second layers of the MLPs with <= 32 outputs run inside the first
  *                      layers' GEMM epilogue when every MLP has 97..128 hidden rows (default), 0 = always the separate kernel
+ *   key "mixer_lds"  : psf_mixer_fwd_*: 1 = short sequences take the single-launch LDS-resident mixer (default), 0 = per-step kernels
  *   key "mixer_wg_limit": psf_mixer_fwd_f32's step kernel, workgroups per CU: 0 = as many as fit (default: three), n = at most n
  *   key "mixer_ablate": TIMING EXPERIMENTS ONLY (non-zero gives wrong results): bit 0 no MLP arithmetic, bit 1 no multiply-add
  *                      chain, bit 2 no far rows, bit 3 no data rows in psf_mixer_fwd_f32's step kernel (profiles/mixer_bench.py)

@@ -22,6 +22,9 @@ SHAPES = [
     ("imdb_B32", 32, 4097, 32, 128, 32, 13, 12, True),
     ("cifar10_B32", 32, 1024, 16, 16, 16, 11, 10, False),
     ("adding_n2048_B64", 64, 2048, 32, 32, 8, 12, 11, True),
+    ("cfg1_n128_B40", 40, 128, 32, 32, 8, 8, 7, True),       # BASELINE configs[0]: the single-launch LDS-resident mixer
+    ("adding_n512_B64", 64, 512, 32, 32, 8, 10, 9, True),
+    ("adding_n512_B512", 512, 512, 32, 32, 8, 10, 9, True),
 ]
 
 

@@ -397,15 +397,30 @@ chord_mixer_g_k(const MixerIn in, float* __restrict__ out, const unsigned char* 
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(images + 16 * (size_t)v),
                                        (__attribute__((address_space(3))) void*)(sImg + 16 * (v0 + wave64)), 16, 0, 0);
   }
-  stage_affine(in, sAff, E, tid);
-  __syncthreads();
-  for (int t = wv; t < TT; t += NW) {  // wave-uniform
-    const int row = p0 + 32 * t + c;
-    const int rowc = (EDGE && row >= N) ? N - 1 : row;
-    float xv[2][8];
+  if constexpr (KIND == 1) {
+    stage_affine(in, sAff, E, tid);
+    __syncthreads();
+  }
+  // the wave's token tiles (t = wv, wv + 4, ...): every tile's data rows are requested before the first barrier, so that their
+  // memory latency passes beside the image DMA instead of once per tile (the first form loaded inside the loop: 57 us for a
+  // launch that moves 42 MB)
+  constexpr int TPWG = (TT + NW - 1) / NW;
+  float xv[TPWG][2][8];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) data_row8<KIND>(in, sAff, b, rowc, N, E, 16 * s + 8 * half, false, xv[s]);
-    const f32x16 y = mlp_tile(sImg, 0, nu, true, xv, c, half);
+  for (int i = 0; i < TPWG; ++i) {
+    const int t = wv + i * NW;
+    const int row = p0 + 32 * (t < TT ? t : 0) + c;
+    const int rowc = (EDGE && row >= N) ? N - 1 : row;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) data_row8<KIND>(in, sAff, b, rowc, N, E, 16 * s + 8 * half, false, xv[i][s]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TPWG; ++i) {
+    const int t = wv + i * NW;
+    if (t >= TT) break;  // wave-uniform
+    const int row = p0 + 32 * t + c;
+    const f32x16 y = mlp_tile(sImg, 0, nu, true, xv[i], c, half);
     if (!EDGE || row < N) {
       float* __restrict__ orow = out + ((int64_t)b * N + row) * C;
 #pragma unroll

@@ -15,6 +15,7 @@
 #include "fwd_kernels.h"
 #include "fwd_mlp_step_launch.h"
 #include "fwd_window_launch.h"
+#include "mixer_lds_launch.h"
 #include "mlp_fwd_x3.h"
 
 using namespace psf;
@@ -66,6 +67,7 @@ std::atomic<int> g_bwd_fused_wg_limit{0};  // fused backward step: 0 = whatever 
 // Per-step launches of a chain: 1 = alternate the direction in which each XCD walks its tile range
 std::atomic<int> g_chain_zigzag{1};
 std::atomic<int> g_mixer_ablate{0};    // timing experiments on that kernel: bit 0 no MLP arithmetic, 1 no multiply-add chain, 2 no far rows, 3 no data rows
+std::atomic<int> g_mixer_lds{1};       // psf_mixer_fwd_*: 1 = short sequences take the single-launch LDS-resident mixer (mixer_lds.h)
 std::atomic<int> g_mixer_wg_limit{0};  // step kernel that computes its own W (fwd_mlp_step.h): 0 = whatever fits, n = at most n per CU
 
 }  // namespace
@@ -98,6 +100,7 @@ Knob g_knobs[] = {
     {"fwd_wg_limit", &g_fwd_wg_limit, 0, 4},
     {"chain_zigzag", &g_chain_zigzag, 0, 1},
     {"mixer_wg_limit", &g_mixer_wg_limit, 0, 4},
+    {"mixer_lds", &g_mixer_lds, 0, 1},
     {"mixer_ablate", &g_mixer_ablate, 0, 15},
     {"chain_fused", &g_chain_fused, 0, 2},
     {"chain_cc", &g_chain_cc, 0, 1},
@@ -113,7 +116,7 @@ Knob g_knobs[] = {
 // odd steps) travels in it too instead of in thread-local state.
 struct Tuning {
   int fwd_variant, bwd_variant, xcd_remap, fwd_rows, fwd_split, bwd_rows, dv_threads, bwd_fused_nt, bwd_fused, dw_variant,
-      dw_tgs, chain_fused, chain_cc, fwd_wide, fwd_wg_limit, bwd_fused_wg_limit, chain_zigzag, mixer_wg_limit, mixer_ablate;
+      dw_tgs, chain_fused, chain_cc, fwd_wide, fwd_wg_limit, bwd_fused_wg_limit, chain_zigzag, mixer_wg_limit, mixer_ablate, mixer_lds;
   bool walk_backwards;
 };
 
@@ -125,7 +128,7 @@ Tuning snapshot() {
   t.dw_variant = g_dw_variant.load(), t.dw_tgs = g_dw_tgs.load(), t.chain_fused = g_chain_fused.load();
   t.chain_cc = g_chain_cc.load(), t.fwd_wide = g_fwd_wide.load(), t.fwd_wg_limit = g_fwd_wg_limit.load();
   t.bwd_fused_wg_limit = g_bwd_fused_wg_limit.load(), t.chain_zigzag = g_chain_zigzag.load();
-  t.mixer_wg_limit = g_mixer_wg_limit.load(), t.mixer_ablate = g_mixer_ablate.load();
+  t.mixer_wg_limit = g_mixer_wg_limit.load(), t.mixer_ablate = g_mixer_ablate.load(), t.mixer_lds = g_mixer_lds.load();
   t.walk_backwards = false;
   return t;
 }
@@ -678,33 +681,43 @@ int chain_impl(Tuning tn, const T* const* W_steps, const T* V0, T* const* out_st
 // the mixer with W computed inside the step (fwd_mlp_step.h)
 // ------------------------------------------------------------------------------------------------------
 struct MixerPlan {
+  bool step_ok;            // the per-step kernels (fwd_mlp_step.h) cover the shape
+  bool lds_ok;             // the single-launch LDS-resident kernel (mixer_lds.h) covers it
   int tgs, TR, KN, units;  // units = packed images over all M + 1 MLPs
+  MixerLdsPlan lds;
 };
 
-// Whether the fused-step path covers the shape; fills *mp. Mirrors the limits stated in include/psf_chord.h.
+// Whether the fused paths cover the shape; fills *mp. Mirrors the limits stated in include/psf_chord.h.
 bool plan_mixer(int64_t N, int32_t E, int32_t M, const int32_t* h, int64_t C, int32_t L, MixerPlan* mp) {
   if (!h || M < 1 || M > 31 || E < 4 || E > 32 || (E & 3) || C < 4 || C > 32 || (C & 3) || L < kMlpStepLmin || L > kMlpStepLmax ||
       N < 1 || N > (int64_t)1 << 30)
     return false;
-  const int tgs = ceil_log2(C / 4);
-  if (tgs > kMlpStepTgsMax) return false;
-  const int TR = mlp_step_tile_rows(tgs);
-  if (N < 2 * (int64_t)TR) return false;  // the window may wrap at most once
-  int KN = 2;
-  for (int t = TR; t > 1; t >>= 1) ++KN;
-  if (KN > L) KN = L;
-  Offsets offs;
-  make_offsets(N, L, nullptr, &offs);
-  for (int k = 0; k < KN; ++k)
-    if (offs.v[k] != chord_off(k)) return false;  // near offsets are compile-time constants in the window kernels
-  int units = 0;
+  int units = 0, nu_max = 0;
   for (int k = 0; k <= M; ++k) {
     if (h[k] < 1 || h[k] > 128) return false;
-    units += (h[k] + 31) / 32;
+    const int nu = (h[k] + 31) / 32;
+    units += nu;
+    nu_max = nu > nu_max ? nu : nu_max;
   }
   if (units > 128) return false;
-  mp->tgs = tgs, mp->TR = TR, mp->KN = KN, mp->units = units;
-  return true;
+  mp->units = units;
+  mp->lds_ok = plan_mixer_lds(N, C, L, M, nu_max, &mp->lds);
+  mp->step_ok = false;
+  const int tgs = ceil_log2(C / 4);
+  if (tgs <= kMlpStepTgsMax) {
+    const int TR = mlp_step_tile_rows(tgs);
+    if (N >= 2 * (int64_t)TR) {  // the window may wrap at most once
+      int KN = 2;
+      for (int t = TR; t > 1; t >>= 1) ++KN;
+      if (KN > L) KN = L;
+      Offsets offs;
+      make_offsets(N, L, nullptr, &offs);
+      bool chord = true;
+      for (int k = 0; k < KN; ++k) chord = chord && offs.v[k] == chord_off(k);  // near offsets are compile-time constants there
+      if (chord) mp->step_ok = true, mp->tgs = tgs, mp->TR = TR, mp->KN = KN;
+    }
+  }
+  return mp->step_ok || mp->lds_ok;
 }
 
 hipError_t launch_g(int tgs, const FwdMlpArgs& a) {
@@ -906,9 +919,30 @@ int psf_mixer_fwd_in_f32(const psf_mixer_input* in, int64_t B, int64_t N, int32_
   for (int k = 1; k <= M; ++k) O[k] = L;
   hipError_t e = psf_x3_pack_launch(E, M + 1, A, a, Bw, b, h, O, workspace, first_unit, s);
   if (e != hipSuccess) return fail_hip(e, "psf_mixer_fwd: pack");
-  // the tile geometry of every launch below
   Offsets offs;
   make_offsets(N, L, nullptr, &offs);
+  if (mp.lds_ok && tn.mixer_lds && B <= 0x7fffffff) {  // short sequences: the whole mixer in ONE launch, V resident in LDS
+    MixerLdsArgs la;
+    la.in = mi;
+    la.images = reinterpret_cast<const unsigned char*>(workspace);
+    for (int k = 0; k <= M + 1; ++k) la.first_unit[k] = first_unit[k];
+    la.V0 = V0;
+    la.store_mask = 0;
+    for (int m = 0; m < kMixerLdsMaxSteps; ++m) la.out[m] = m < M ? out_steps[m] : nullptr;
+    for (int m = 0; m < M; ++m) {  // a buffer that a later step overwrites (two-buffer inference) is not stored at all
+      bool later = false;
+      for (int q = m + 1; q < M; ++q) later = later || out_steps[q] == out_steps[m];
+      if (!later) la.store_mask |= 1u << m;
+    }
+    la.M = M, la.N = (int32_t)N, la.C = (int32_t)C, la.E = E, la.L = L, la.CG = (int32_t)(C / 4), la.WS = mp.lds.WS;
+    la.TT = (int32_t)(N / 32), la.nu_max = mp.lds.nu_max;
+    e = launch_mixer_lds(mp.lds, use_residual != 0, la, offs, (int)B, s);
+    if (e != hipSuccess) return fail_hip(e, "chord_mixer_lds launch");
+    return PSF_OK;
+  }
+  if (!mp.step_ok)
+    return fail(PSF_E_TUNING, "psf_mixer_fwd: mixer_lds=0 but only the LDS-resident kernel covers N=%lld C=%lld", (long long)N, (long long)C);
+  // the tile geometry of every launch below
   WinPick pk;
   pk.tgs = mp.tgs, pk.rows = mlp_step_rows(mp.tgs), pk.nt = 256, pk.TR = mp.TR, pk.KN = mp.KN;
   pk.tiles_full = (int)(N / mp.TR);

@@ -142,7 +142,10 @@ def test_mixer_entry_point_states_its_limits_without_touching_the_gpu(lib):
     h = (i32 * 3)(32, 32, 32)
     assert lib.psf_mixer_fwd_workspace(16384, 32, 2, h, 8, 15) == 3 * 14080
     assert lib.psf_mixer_fwd_workspace(1024, 32, 2, (i32 * 3)(128, 128, 128), 32, 12) == 12 * 14080
-    assert lib.psf_mixer_fwd_workspace(128, 32, 2, h, 8, 8) == -1      # N < two tiles of 256 rows
+    assert lib.psf_mixer_fwd_workspace(128, 32, 2, h, 8, 8) == 3 * 14080   # BASELINE configs[0]: the single-launch LDS kernel
+    assert lib.psf_mixer_fwd_workspace(100, 32, 2, h, 8, 8) == -1      # neither: N < two tiles of 256 rows, not a multiple of 32
+    assert lib.psf_mixer_fwd_workspace(256, 32, 2, h, 16, 8) == 3 * 14080  # C = 16: two 128-row tiles, per-step kernels
+    assert lib.psf_mixer_fwd_workspace(128, 32, 2, h, 16, 8) == -1     # C = 16 and N < two tiles
     assert lib.psf_mixer_fwd_workspace(512, 32, 2, h, 8, 10) > 0       # exactly two tiles
     assert lib.psf_mixer_fwd_workspace(16384, 48, 2, h, 8, 15) == -1   # E > 32
     assert lib.psf_mixer_fwd_workspace(16384, 30, 2, h, 8, 15) == -1   # E not a multiple of 4
@@ -156,7 +159,7 @@ def test_mixer_entry_point_states_its_limits_without_touching_the_gpu(lib):
     f = lib.psf_mixer_fwd_f32
     ws = 3 * 14080
     assert f(None, 1, 16384, 32, 2, tab, tab, tab, tab, h, 8, 15, 1, one, outs, three, ws, None) == -1
-    assert f(one, 1, 128, 32, 2, tab, tab, tab, tab, h, 8, 8, 1, two, outs, three, ws, None) == -2 and b"fused path" in lib.psf_last_error()
+    assert f(one, 1, 100, 32, 2, tab, tab, tab, tab, h, 8, 8, 1, two, outs, three, ws, None) == -2 and b"fused path" in lib.psf_last_error()
     assert f(one, 1, 16384, 32, 2, tab, tab, tab, tab, h, 8, 15, 1, two, outs, three, ws - 16, None) == -2  # workspace too small
     assert f(vp(20), 1, 16384, 32, 2, tab, tab, tab, tab, h, 8, 15, 1, two, outs, three, ws, None) == -4    # X misaligned
     assert f(one, 1, 16384, 32, 2, tab, tab, tab, tab, h, 8, 15, 1, two, (vp * 2)(32, 32), three, ws, None) == -3  # out aliases V0

@@ -58,6 +58,12 @@ CASES = [
     ("c4", 2, 1000, 8, 24, 4, 10, 4, False),
     ("two_tiles", 2, 512, 32, 32, 8, 10, 9, True),
     ("h96", 2, 2048, 32, 96, 32, 12, 3, True),
+    # the single-launch LDS-resident mixer (csrc/mixer_lds.h): BASELINE configs[0] and the other shapes of its plan
+    ("cfg1", 40, 128, 32, 32, 8, 8, 7, True),
+    ("lds_n512", 3, 512, 32, 32, 8, 10, 9, True),
+    ("lds_n256_nores", 5, 256, 32, 32, 8, 9, 8, False),
+    ("lds_c4_h128", 3, 256, 16, 128, 4, 9, 8, True),
+    ("lds_n64", 7, 64, 32, 32, 8, 7, 6, True),
 ]
 
 
@@ -78,6 +84,26 @@ def test_mixer_matches_the_oracle_chain_fed_with_float64_mlp_w(gpu, name, B, N, 
     assert rel_inf(got, want) <= TOL, f"{name}: rel {rel_inf(got, want):.3e}"
 
 
+def test_short_sequences_run_as_one_launch_and_agree_with_the_per_step_kernels(gpu):
+    """N = 512, C = 8 is covered by both forms of the fused mixer: the LDS-resident single launch (default) and the per-step
+    kernels (knob mixer_lds = 0) compute the same W and accumulate in the same order: equal bits."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import fused_mixer
+    g, fs = _blocks(32, 32, 8, 10, 9, seed=2)
+    g.to(gpu)
+    for f in fs:
+        f.to(gpu)
+    x = torch.randn(6, 512, 32, device=gpu)
+    with torch.no_grad():
+        one = fused_mixer.mixer_forward(x, g, fs, True).clone()
+        sfa.set_tuning("mixer_lds", 0)
+        try:
+            steps = fused_mixer.mixer_forward(x, g, fs, True).clone()
+        finally:
+            sfa.set_tuning("mixer_lds", 1)
+    assert torch.equal(one, steps)
+
+
 RECIPE_CASES = [
     # name, kind, B, N, E, h, C, L, M, residual, with positional rows, K (inputs per position / vocabulary)
     ("adding_affine", "affine", 3, 16384, 32, 32, 8, 15, 14, True, False, 2),
@@ -87,6 +113,8 @@ RECIPE_CASES = [
     ("cifar_tokens_e16", "tokens", 3, 1024, 16, 16, 16, 11, 10, False, True, 256),
     ("affine_k3_pos_e12", "affine", 2, 600, 12, 40, 12, 9, 5, True, True, 3),
     ("tokens_nopos_c4", "tokens", 2, 1000, 8, 24, 4, 10, 4, False, False, 11),
+    ("cfg1_adding_affine_lds", "affine", 40, 128, 32, 32, 8, 8, 7, True, False, 2),
+    ("cfg1_order_tokens_lds", "tokens", 40, 128, 32, 32, 8, 8, 7, True, True, 6),
 ]
 
 
