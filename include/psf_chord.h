@@ -295,6 +295,8 @@ int psf_mlp_fwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
  *   the fused path does not cover the shape — the caller then uses psf_mlp_fwd_f32 + psf_chord_chain_fwd_f32.
  */
 int64_t psf_mixer_fwd_workspace(int64_t N, int32_t E, int32_t M, const int32_t* h, int64_t C, int32_t L);
+/* Which form a call with this shape takes: 0 = none (outside the limits), 1 = M + 1 step launches, 2 = the single LDS-resident launch. */
+int32_t psf_mixer_fwd_plan(int64_t N, int32_t E, int32_t M, const int32_t* h, int64_t C, int32_t L);
 int psf_mixer_fwd_f32(const float* X, int64_t B, int64_t N, int32_t E, int32_t M, const float* const* A,
                       const float* const* a, const float* const* Bw, const float* const* b, const int32_t* h, int64_t C,
                       int32_t L, int32_t use_residual, float* V0, float* const* out_steps, void* workspace,

@@ -56,6 +56,7 @@ SIGNATURES = {
                          ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_vp), c_vp,
                          c_i64, c_vp], ctypes.c_int),
     "psf_mixer_fwd_workspace": ([c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), c_i64, c_i32], c_i64),
+    "psf_mixer_fwd_plan": ([c_i64, c_i32, c_i32, ctypes.POINTER(c_i32), c_i64, c_i32], c_i32),
     "psf_mixer_fwd_f32": ([c_vp, c_i64, c_i64, c_i32, c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                            ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), c_i64, c_i32, c_i32, c_vp, ctypes.POINTER(c_vp), c_vp,
                            c_i64, c_vp], ctypes.c_int),

@@ -866,6 +866,12 @@ int64_t psf_mixer_fwd_workspace(int64_t N, int32_t E, int32_t M, const int32_t* 
   return (int64_t)mp.units * kX3ImageBytes;
 }
 
+int32_t psf_mixer_fwd_plan(int64_t N, int32_t E, int32_t M, const int32_t* h, int64_t C, int32_t L) {
+  MixerPlan mp;
+  if (!plan_mixer(N, E, M, h, C, L, &mp)) return 0;
+  return (mp.lds_ok && g_mixer_lds.load()) ? 2 : (mp.step_ok ? 1 : 0);
+}
+
 int psf_mixer_fwd_in_f32(const psf_mixer_input* in, int64_t B, int64_t N, int32_t E, int32_t M, const float* const* A,
                          const float* const* a, const float* const* Bw, const float* const* b, const int32_t* h, int64_t C,
                          int32_t L, int32_t use_residual, float* V0, float* const* out_steps, void* workspace,

@@ -18,9 +18,9 @@ from .fused_mlp import _needs_grad, _params_of, _ptrs, _two_layer
 
 enabled = True  # module-level switch (tests / A-B timing)
 #: "auto": take the fused path where it is measured faster than psf_mlp_fwd_f32 + psf_chord_chain_fwd_f32 end to end
-#: (profiles/r04c_mixer_ablate.log: long sequences of narrow rows with one hidden unit — the step kernel stages its MLP's
+#: (profiles/r04l_mixer_bench.log: long sequences of narrow rows with one hidden unit — the step kernel stages its MLP's
 #: weight image per tile, 14 KB per 32 hidden rows, which short tiles (C = 32: 64 rows) and 128-wide hidden layers do not
-#: amortise); "always": wherever the shape is covered; "never".
+#: amortise — and the short sequences that run as one LDS-resident launch); "always": wherever the shape is covered; "never".
 route = "auto"
 #: Evaluate the embedding lookup inside the mixer kernels (Recipe.tokens) instead of materialising ``data`` with
 #: psf_embed_tokens_f32 first. Off: the lookup makes the table and positional loads depend on the token load, which lengthens
@@ -93,8 +93,14 @@ def _block_sizes(E: int, g: nn.Module, fs: Sequence[nn.Module]):
     return len(fs), h, pairs[0][1].out_features, L
 
 
-def _route_ok(N: int, C: int, h) -> bool:
-    return route == "always" or (route == "auto" and N >= 8192 and C <= 16 and max(h) <= 32)
+def _route_ok(N: int, E: int, M: int, C: int, L: int, h) -> bool:
+    if route != "auto":
+        return route == "always"
+    if N >= 8192 and C <= 16 and max(h) <= 32:
+        return True
+    # short sequences: ONE launch with V resident in LDS (csrc/mixer_lds.h) against producer + chain
+    # (profiles/r04n_mixer_bench_short.log: cfg1 115 -> 89 us per forward, N = 512: 134 -> 106)
+    return _lib.load().psf_mixer_fwd_plan(N, E, M, h, C, L) == 2
 
 
 def eligible_recipe(r: Recipe, g: nn.Module, fs: Sequence[nn.Module]) -> bool:
@@ -109,7 +115,7 @@ def eligible_recipe(r: Recipe, g: nn.Module, fs: Sequence[nn.Module]) -> bool:
     if sz is None:
         return False
     M, h, C, L = sz
-    return _route_ok(r.N, C, h) and _lib.load().psf_mixer_fwd_workspace(r.N, r.E, M, h, C, L) >= 0
+    return _route_ok(r.N, r.E, M, C, L, h) and _lib.load().psf_mixer_fwd_workspace(r.N, r.E, M, h, C, L) >= 0
 
 
 def mixer_forward_in(r: Recipe, g: nn.Module, fs: Sequence[nn.Module], use_residual: bool) -> torch.Tensor:
