@@ -385,6 +385,13 @@ int psf_mlp_wide_bwd_f32(const void* saved, int64_t saved_bytes, int64_t T, int3
  *   w [2 n_vec4] float4, v / r / out [n_vec4] float4, all 16-byte aligned; bytes moved = 80 n_vec4.
  */
 int psf_stream_mix_f32(const float* w, const float* v, const float* r, float* out, int64_t n_vec4, void* stream);
+/*
+ * The same for the BACKWARD step's byte mix: per index i it reads w[2i], w[2i+1], v[i], z[i] and writes dw[2i], dw[2i+1],
+ * dv[i] — W : V : dZ read, dW : dV written = 2 : 1 : 1, 2 : 1 (the fused backward step at L = 15, C = 8 moves 15 : 8 : 8,
+ * 15 : 8). Bytes moved = 112 n_vec4.
+ */
+int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float* dw, float* dv, int64_t n_vec4,
+                           void* stream);
 
 /*
  * Process-wide tuning knobs (benchmark / test use; defaults are the shipped configuration).
@@ -442,6 +449,8 @@ int psf_stream_mix_f32(const float* w, const float* v, const float* r, float* ou
  *   key "mixer_wg_limit": psf_mixer_fwd_f32's step kernel, workgroups per CU: 0 = as many as fit (default: three), n = at most n
  *   key "mixer_ablate": TIMING EXPERIMENTS ONLY (non-zero gives wrong results): bit 0 no MLP arithmetic, bit 1 no multiply-add
  *                      chain, bit 2 no far rows, bit 3 no data rows in psf_mixer_fwd_f32's step kernel (profiles/mixer_bench.py)
+ *   key "bwd_ablate" : TIMING EXPERIMENTS ONLY, and only in a library built with -DPSF_BWD_ABLATE_LAB (ignored otherwise): parts
+ *                      of the fused backward step left out (csrc/bwd_fused.h, ABL; profiles/bwd_ablate_bench.py)
  *   key "xcd_remap"  : 1 = keep a batch element's tiles on one XCD group (default), 0 = linear
  * psf_get_tuning returns the value (>= 0) or PSF_E_TUNING.
  */

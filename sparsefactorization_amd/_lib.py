@@ -77,6 +77,7 @@ SIGNATURES = {
                               ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(c_vp),
                               ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp, c_i64, c_vp], ctypes.c_int),
     "psf_stream_mix_f32": ([c_vp, c_vp, c_vp, c_vp, c_i64, c_vp], ctypes.c_int),
+    "psf_stream_mix_bwd_f32": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp], ctypes.c_int),
     "psf_set_tuning": ([ctypes.c_char_p, c_i32], ctypes.c_int),
     "psf_get_tuning": ([ctypes.c_char_p], ctypes.c_int),
     "psf_describe_fwd": ([c_i64, c_i64, c_i32, c_i64, c_i32, ctypes.c_char_p, c_i32], ctypes.c_int),

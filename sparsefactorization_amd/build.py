@@ -61,7 +61,10 @@ def _units():
     """(object path, source, extra flags) for every translation unit."""
     units = [(os.path.join(OBJ_DIR, "psf_chord.o"), os.path.join(CSRC, "psf_chord.hip"), [f'-DPSF_CSRC_HASH="{csrc_hash()}"']),
              (os.path.join(OBJ_DIR, "linear_wgrad.o"), os.path.join(CSRC, "linear_wgrad.hip"), []),
-             (os.path.join(OBJ_DIR, "fwd_chain_lds.o"), os.path.join(CSRC, "fwd_chain_lds_inst.hip"), []),
+             # -fno-slp-vectorize: the LDS-resident chain's multiply-add loop is faster on scalar f32 instructions than on the
+             # v_pk_* pairs hipcc builds from it (Pathfinder chain 41.4 -> 33.9 us, profiles/r04p_lib_ab_noslp.log; the
+             # per-step window kernels are the other way round: 367 -> 386 us at cfg2)
+             (os.path.join(OBJ_DIR, "fwd_chain_lds.o"), os.path.join(CSRC, "fwd_chain_lds_inst.hip"), ["-fno-slp-vectorize"]),
              (os.path.join(OBJ_DIR, "embed.o"), os.path.join(CSRC, "embed.hip"), []),
              (os.path.join(OBJ_DIR, "flat_head.o"), os.path.join(CSRC, "flat_head.hip"), []),
              (os.path.join(OBJ_DIR, "sum_tensors.o"), os.path.join(CSRC, "sum_tensors.hip"), []),

@@ -125,10 +125,24 @@ template hipError_t launch_dv_win<PSF_TGS, PSF_NT>(int rows, int L, const BwdWin
 
 #if PSF_NT == 512
 namespace {
-template <int L, int TGS, int NT>
+template <int L, int TGS, int NT, int ABL = 0>
 hipError_t launch_fused(const BwdWinArgs& a) {
   using Cfg = BwdFusedCfg<L, TGS, NT>;
-  auto kern = chord_bwd_fused_k<L, TGS, NT>;
+#ifdef PSF_BWD_ABLATE_LAB  // diagnostic builds: the cfg2 instance with parts left out (bwd_fused.h, ABL)
+  if constexpr (ABL == 0 && L == 15 && TGS == 1 && NT == 256) {
+    switch (a.ablate) {
+#define PSF_ABL(X) \
+  case X:          \
+    return launch_fused<L, TGS, NT, X>(a);
+      PSF_ABL(1) PSF_ABL(2) PSF_ABL(3) PSF_ABL(4) PSF_ABL(8) PSF_ABL(12) PSF_ABL(15) PSF_ABL(16) PSF_ABL(32) PSF_ABL(48)
+      PSF_ABL(63) PSF_ABL(64) PSF_ABL(79) PSF_ABL(112) PSF_ABL(115) PSF_ABL(124) PSF_ABL(128) PSF_ABL(512) PSF_ABL(640)
+#undef PSF_ABL
+      default:
+        break;
+    }
+  }
+#endif
+  auto kern = chord_bwd_fused_k<L, TGS, NT, ABL>;
   int lds = Cfg::lds_bytes;
   if (a.wg_per_cu > 0) {  // occupancy limiter as in the forward launcher (fwd_window_inst.hip)
     const int floor_bytes = kLdsPerCu / (a.wg_per_cu + 1) + 256;

@@ -21,6 +21,7 @@ struct BwdWinArgs {
   int far_k0 = 0;
   const float* V2 = nullptr;    // fused step (bwd_fused.h): WV = W, V2 = V, out = dV, out2 = dW
   float* out2 = nullptr;
+  int ablate = 0;               // fused step, diagnostic builds only (bwd_fused.h: ABL)
   int wg_per_cu = 0;            // fused step: 0 = whatever fits; n > 0: at most n workgroups per CU (by requesting more LDS)
 };
 

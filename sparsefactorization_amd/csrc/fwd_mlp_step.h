@@ -225,6 +225,21 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
     const int t = G == 1 ? wv * TPW + tp : wv % TT;
     int row = p0 + 32 * t + c;
     if (EDGE && row >= N) row = N - 1;
+    if constexpr (KIND == 0 && !EDGE) {
+      // rows of 32 features in a full tile: one scalar block address per token tile plus one lane offset (the row c, the
+      // lane's 8-feature group), four unconditional 16-byte loads (other widths keep the predicated form below)
+      if (E == 32 && !(ablate & 8)) {
+        const PSF_GLOBAL char* blk = sbase(reinterpret_cast<const char*>(in.src) + ((int64_t)b * N + p0 + 32 * t) * (32 * 4));
+        const uint32_t xo = (uint32_t)c * 128u + (uint32_t)half * 32u;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const Vec<float, 4> lo = ldg<float, 4>(blk + (xo + 64u * s)), hi = ldg<float, 4>(blk + (xo + 64u * s + 16u));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xv[tp][s][i] = lo.e[i], xv[tp][s][4 + i] = hi.e[i];
+        }
+        continue;
+      }
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) data_row8<KIND>(in, sAff, b, row, N, E, 16 * s + 8 * half, (ablate & 8) != 0, xv[tp][s]);
   }
@@ -237,6 +252,32 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(images + 16 * (size_t)v),
                                        (__attribute__((address_space(3))) void*)(sImg + 16 * (v0 + wave64)), 16, 0, 0);
   }
+  V4 far[R][NF > 0 ? NF : 1];
+  V4 rres[R];
+  // Full-tile launches (!EDGE; host-checked: N and every far offset multiples of TR, C = 4 TG, N C 4 < 2^31): every row block
+  // the workgroup touches is TR-aligned and never wraps inside — scalar block addresses plus one lane offset per row slot
+  // (fwd_window.h says what that saves; here the vector unit is the bottleneck, so it counts double).
+  constexpr uint32_t rowB = TG * 16u;
+  uint32_t voff[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) voff[j] = (uint32_t)(j * RS + rs) * rowB + (uint32_t)g * 16u;
+  const char* __restrict__ Vbb = reinterpret_cast<const char*>(Vb);
+  if constexpr (!EDGE) {
+    int p1 = p0 + TR;
+    if (p1 >= N) p1 -= N;
+#pragma unroll
+    for (int n = 0; n < Cfg::win_vecs / NT; ++n)
+      stage16g<0>(sbase(Vbb + (uint32_t)(n / R == 0 ? p0 : p1) * rowB) + voff[n % R], sWin + n * NT + wave64);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      int s0 = p0 + offs.v[KN + f];
+      if (s0 >= N) s0 -= N;
+      if (ablate & 4) s0 = p0;  // timing only: the tile's own rows (L2 / window hits) instead of the far ones
+      const PSF_GLOBAL char* blk = sbase(Vbb + (uint32_t)s0 * rowB);
+#pragma unroll
+      for (int j = 0; j < R; ++j) far[j][f] = ldg<float, 4>(blk + voff[j]);
+    }
+  } else {
 #pragma unroll
   for (int n = 0; n < Cfg::win_vecs / NT; ++n) {
     const int i = n * NT + tid;
@@ -248,8 +289,6 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
   }
 
   // ---- (0c) far rows and residual -> registers ----
-  V4 far[R][NF > 0 ? NF : 1];
-  V4 rres[R];
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int pr = p0 + j * RS + rs;
@@ -261,6 +300,8 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
       if (ablate & 4) src = p;  // timing only: the row itself (an L2 / window hit) instead of the far row
       far[j][f] = ld<float, 4>(Vb + (int64_t)src * C + (int64_t)cgc * 4);
     }
+  }
+
   }
 
   __syncthreads();  // images and window have landed (hipcc drains vmcnt before the barrier)
@@ -322,11 +363,17 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
     }
   }
   if constexpr (RES) {  // the residual rows: requested here, behind the matrix phase (8 registers it does not have to carry)
+    if constexpr (!EDGE) {
+      const PSF_GLOBAL char* rb = sbase(reinterpret_cast<const char*>(res + ((int64_t)b * N + p0) * C));
 #pragma unroll
-    for (int j = 0; j < R; ++j) {
-      const int pr = p0 + j * RS + rs;
-      const int p = EDGE ? imin(pr, N - 1) : pr;
-      rres[j] = ld<float, 4>(res + ((int64_t)b * N + p) * C + (int64_t)cgc * 4);
+      for (int j = 0; j < R; ++j) rres[j] = ldg<float, 4>(rb + voff[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int pr = p0 + j * RS + rs;
+        const int p = imin(pr, N - 1);
+        rres[j] = ld<float, 4>(res + ((int64_t)b * N + p) * C + (int64_t)cgc * 4);
+      }
     }
   }
   __syncthreads();
@@ -366,10 +413,16 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
     }
   }
   __builtin_amdgcn_sched_barrier(0);  // nothing but the stores below this line: no later instruction can reuse their registers
+  if constexpr (!EDGE) {
+    PSF_GLOBAL char* ob = sbase(reinterpret_cast<char*>(out + ((int64_t)b * N + p0) * C));
 #pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const int p = p0 + j * RS + rs;
-    if (!EDGE || (p < N && cg_ok)) st<float, 4>(out + ((int64_t)b * N + p) * C + (int64_t)g * 4, acc[j]);
+    for (int j = 0; j < R; ++j) stg<float, 4>(ob + voff[j], acc[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int p = p0 + j * RS + rs;
+      if (p < N && cg_ok) st<float, 4>(out + ((int64_t)b * N + p) * C + (int64_t)g * 4, acc[j]);
+    }
   }
 }
 

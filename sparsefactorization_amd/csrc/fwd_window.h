@@ -66,7 +66,14 @@ __device__ __forceinline__ void stage16(const T* __restrict__ gsrc, Vec<T, VEC>*
   }
 }
 
-template <typename T, int L, int TGS, int R, int NT, bool DMA, bool RES, bool EDGE>
+// the same from a global-address-space byte pointer (sbase(block) + lane offset, psf_common.h); always LDS-DMA
+template <int AUX = 0>
+__device__ __forceinline__ void stage16g(const PSF_GLOBAL char* gsrc, void* sdst_wave_base) {
+  __builtin_amdgcn_global_load_lds((const PSF_GLOBAL void*)gsrc, (__attribute__((address_space(3))) void*)sdst_wave_base, 16, 0,
+                                   AUX);
+}
+
+template <typename T, int L, int TGS, int R, int NT, bool DMA, bool RES, bool EDGE, bool ALIGNED>
 __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* __restrict__ V,
                                              const T* __restrict__ res, T* __restrict__ out, const Geom& gm,
                                              const Offsets& offs, const int64_t w_total, char* smem, int b, int p0,
@@ -92,8 +99,58 @@ __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* _
 
   const T* __restrict__ Vb = V + (int64_t)b * gm.v_bstride;
 
-  // ---- (1) W tile: the 16-byte chunks covering the tile's elements of the flat W buffer ----
+  V4 far[R][NF > 0 ? NF : 1];
+  V4 rres[R];
   const int rows_here = EDGE ? imin(TR, N - p0) : TR;
+  static_assert(!(EDGE && ALIGNED), "aligned launches have full tiles only");
+  if constexpr (ALIGNED) {
+    // Full tiles of a launch the host found aligned (Geom::aligned: N a multiple of TR, so is every far offset, every channel group
+    // valid, chunk-clean W, N * C * sizeof(T) < 2^31): every row block this workgroup touches is TR-aligned and never wraps
+    // inside, so every address is a wave-uniform base (scalar arithmetic) plus ONE per-lane byte offset — the request phase
+    // costs a handful of vector instructions instead of a 64-bit multiply-add chain per load (r04: 151 -> 46 vector
+    // instructions before the barrier at cfg2).
+    const uint32_t rowB = (uint32_t)C * (uint32_t)sizeof(T);
+    const char* __restrict__ Vbb = reinterpret_cast<const char*>(Vb);
+    uint32_t voff[R];  // lane's row rs + j RS of a TR-aligned block, channel group cg
+#pragma unroll
+    for (int j = 0; j < R; ++j) voff[j] = (uint32_t)(j * RS + rs) * rowB + (uint32_t)cg * 16u;
+
+    // (1) W tile: TR L / VEC flat 16-byte chunks exactly (an aligned launch's tiles start on 16-byte boundaries: TR is a
+    //     multiple of 4 and W is chunk-clean, so mis = 0). No lane predicate anywhere in the request phase — a predicate
+    //     splits the basic block and the loads behind it lose the scalar-base form: the last, partial pass clamps its chunk
+    //     index instead and its surplus lanes re-read the last chunk into the pad behind the image.
+    static_assert(TR % VEC == 0, "tiles start on 16-byte boundaries");
+    const char* __restrict__ Wb16 = reinterpret_cast<const char*>(W + e_al);
+    constexpr int kVecs = TR * L / VEC, kFull = kVecs / NT, kRem = kVecs - kFull * NT;
+#pragma unroll
+    for (int n = 0; n < kFull; ++n)
+      stage16g<PSF_W_DMA_AUX>(sbase(Wb16 + (size_t)n * NT * 16) + (uint32_t)tid * 16u, sWv + n * NT + wave64);
+    if constexpr (kRem > 0)
+      stage16g<PSF_W_DMA_AUX>(sbase(Wb16 + (size_t)kFull * NT * 16) + (uint32_t)imin_rt(tid, kRem - 1) * 16u,
+                              sWv + kFull * NT + wave64);
+    // (2) V window: pass n holds rows n RS + rs of [p0, p0 + 2 TR) = block n / R (0: the tile, 1: the next one, mod N)
+    int p1 = p0 + TR;
+    if (p1 >= N) p1 -= N;
+#pragma unroll
+    for (int n = 0; n < Cfg::win_vecs / NT; ++n) {
+      stage16g<0>(sbase(Vbb + (uint32_t)(n / R == 0 ? p0 : p1) * rowB) + voff[n % R], sWin + n * NT + wave64);
+    }
+    // (3) far rows and residual -> registers
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      int s0 = p0 + offs.v[KN + f];
+      if (s0 >= N) s0 -= N;
+      const PSF_GLOBAL char* blk = sbase(Vbb + (uint32_t)s0 * rowB);
+#pragma unroll
+      for (int j = 0; j < R; ++j) far[j][f] = ldg<T, VEC>(blk + voff[j]);
+    }
+    if constexpr (RES) {
+      const PSF_GLOBAL char* rb = sbase(reinterpret_cast<const char*>(res + ((int64_t)b * N + p0) * C));
+#pragma unroll
+      for (int j = 0; j < R; ++j) rres[j] = ldg<T, VEC>(rb + voff[j]);
+    }
+  } else {
+  // ---- (1) W tile: the 16-byte chunks covering the tile's elements of the flat W buffer ----
   const int nvec = (mis + rows_here * L + VEC - 1) / VEC;
   const T* __restrict__ Wal = W + e_al;
 #pragma unroll
@@ -128,8 +185,6 @@ __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* _
   }
 
   // ---- (3) far rows and residual -> registers ----
-  V4 far[R][NF > 0 ? NF : 1];
-  V4 rres[R];
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int pr = p0 + j * RS + rs;
@@ -141,6 +196,8 @@ __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* _
       far[j][f] = ld<T, VEC>(Vb + (int64_t)src * C + (int64_t)cgc * VEC);
     }
     if constexpr (RES) rres[j] = ld<T, VEC>(res + ((int64_t)b * N + p) * C + (int64_t)cgc * VEC);
+  }
+
   }
 
   __syncthreads();  // (hipcc drains vmcnt here: the DMA'd tiles and the register loads have all landed)
@@ -163,7 +220,7 @@ __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* _
     V4 acc;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc.e[i] = T(0);
-    const T* __restrict__ wrow = sWf + mis + pl * L;
+    const T* __restrict__ wrow = sWf + (ALIGNED ? 0 : mis) + pl * L;
 #pragma unroll
     for (int k = 0; k < KN; ++k) {
       const V4 x = sWin[((pl + chord_off(k)) << TGS) + g];
@@ -175,16 +232,22 @@ __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* _
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc.e[i] = add_rn(acc.e[i], rres[j].e[i]);
     }
-    if (!EDGE || (p < N && cg_ok)) st<T, VEC>(out + ((int64_t)b * N + p) * C + (int64_t)cg * VEC, acc);
+    if constexpr (ALIGNED) {
+      PSF_GLOBAL char* ob = sbase(reinterpret_cast<char*>(out + ((int64_t)b * N + p0) * C));
+      stg<T, VEC>(ob + ((uint32_t)pl * ((uint32_t)C * (uint32_t)sizeof(T)) + (uint32_t)cg * 16u), acc);
+    } else {
+      if (p < N && cg_ok) st<T, VEC>(out + ((int64_t)b * N + p) * C + (int64_t)cg * VEC, acc);
+    }
   }
 }
 
+// MODE is chosen by the host per launch: 0 = full tiles, 1 = EDGE, 2 = full tiles of an aligned launch (Geom::aligned).
 // EDGE is chosen by the host per launch (one code path per kernel: letting the two bodies share a kernel made
 // hipcc tail-merge them and split the stores). EDGE = false requires of EVERY tile in the launch: all TR rows
 // < N, all TG channel groups < CG, W base 16-byte aligned and B*N*L a multiple of the vector width (no partial
 // 16-byte chunk anywhere). The dispatcher sends the full tiles to that kernel and the ragged last tile of each
 // sequence, if any, to the EDGE = true kernel in a second small launch (gm.tile0 = first tile of the launch).
-template <typename T, int L, int TGS, int R, int NT, bool DMA, bool RES, bool EDGE>
+template <typename T, int L, int TGS, int R, int NT, bool DMA, bool RES, int MODE>
 __global__ void __launch_bounds__(NT)
 chord_fwd_win_k(const T* __restrict__ W, const T* __restrict__ V, const T* __restrict__ res,
                 T* __restrict__ out, const Geom gm, const Offsets offs, const int64_t w_total, T* __restrict__ wfar,
@@ -199,7 +262,7 @@ chord_fwd_win_k(const T* __restrict__ W, const T* __restrict__ V, const T* __res
   const int64_t e_lo = ((int64_t)b * gm.N + p0) * L;  // first W element of the tile in the flat buffer
   const int mis = (int)(((reinterpret_cast<uintptr_t>(W) / sizeof(T)) + (uint64_t)e_lo) & (VEC - 1));
   const int64_t e_al = e_lo - mis;                    // element index of chunk 0 (-mis at the buffer start)
-  fwd_win_body<T, L, TGS, R, NT, DMA, RES, EDGE>(W, V, res, out, gm, offs, w_total, smem, b, p0, chunk, mis, e_al, wfar,
+  fwd_win_body<T, L, TGS, R, NT, DMA, RES, MODE == 1, MODE == 2>(W, V, res, out, gm, offs, w_total, smem, b, p0, chunk, mis, e_al, wfar,
                                                  far_k0);
 }
 

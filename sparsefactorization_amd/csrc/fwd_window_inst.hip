@@ -16,10 +16,10 @@
 namespace psf {
 namespace {
 
-template <int L, int TGS, int R, int NT, bool RES, bool EDGE>
+template <int L, int TGS, int R, int NT, bool RES, int MODE>
 hipError_t launch_one(const FwdWinArgs& a) {
   using Cfg = FwdWinCfg<float, L, TGS, R, NT>;
-  auto kern = chord_fwd_win_k<float, L, TGS, R, NT, /*DMA=*/true, RES, EDGE>;
+  auto kern = chord_fwd_win_k<float, L, TGS, R, NT, /*DMA=*/true, RES, MODE>;
   // Occupancy limiter: a CU takes floor(160 KB / LDS per workgroup) workgroups, so asking for just over
   // 160 KB / (n + 1) caps it at n. (cfg2: 3 per CU is 2-3 % faster than the 4 the registers allow — fewer
   // windows competing for the XCD's L2; 2 per CU is 10 % slower. DESIGN.md §4.1.)
@@ -45,8 +45,10 @@ hipError_t launch_one(const FwdWinArgs& a) {
 template <int L, int TGS, int R, int NT>
 hipError_t launch_flags(const FwdWinArgs& a) {
   if (a.res != nullptr)
-    return a.edge ? launch_one<L, TGS, R, NT, true, true>(a) : launch_one<L, TGS, R, NT, true, false>(a);
-  return a.edge ? launch_one<L, TGS, R, NT, false, true>(a) : launch_one<L, TGS, R, NT, false, false>(a);
+    return a.edge ? launch_one<L, TGS, R, NT, true, 1>(a)
+                  : (a.gm.aligned ? launch_one<L, TGS, R, NT, true, 2>(a) : launch_one<L, TGS, R, NT, true, 0>(a));
+  return a.edge ? launch_one<L, TGS, R, NT, false, 1>(a)
+                : (a.gm.aligned ? launch_one<L, TGS, R, NT, false, 2>(a) : launch_one<L, TGS, R, NT, false, 0>(a));
 }
 
 template <int TGS, int R, int NT>

@@ -66,6 +66,7 @@ std::atomic<int> g_fwd_wg_limit{0};
 std::atomic<int> g_bwd_fused_wg_limit{0};  // fused backward step: 0 = whatever fits (five of 256 threads at C = 8), n = at most n
 // Per-step launches of a chain: 1 = alternate the direction in which each XCD walks its tile range
 std::atomic<int> g_chain_zigzag{1};
+std::atomic<int> g_bwd_ablate{0};      // fused backward step, -DPSF_BWD_ABLATE_LAB builds only (bwd_fused.h: ABL); ignored otherwise
 std::atomic<int> g_mixer_ablate{0};    // timing experiments on that kernel: bit 0 no MLP arithmetic, 1 no multiply-add chain, 2 no far rows, 3 no data rows
 std::atomic<int> g_mixer_lds{1};       // psf_mixer_fwd_*: 1 = short sequences take the single-launch LDS-resident mixer (mixer_lds.h)
 std::atomic<int> g_mixer_wg_limit{0};  // step kernel that computes its own W (fwd_mlp_step.h): 0 = whatever fits, n = at most n per CU
@@ -102,6 +103,7 @@ Knob g_knobs[] = {
     {"mixer_wg_limit", &g_mixer_wg_limit, 0, 4},
     {"mixer_lds", &g_mixer_lds, 0, 1},
     {"mixer_ablate", &g_mixer_ablate, 0, 15},
+    {"bwd_ablate", &g_bwd_ablate, 0, 1023},
     {"chain_fused", &g_chain_fused, 0, 2},
     {"chain_cc", &g_chain_cc, 0, 1},
     {"mlp_variant", &psf_g_mlp_variant, 0, 3},
@@ -116,7 +118,7 @@ Knob g_knobs[] = {
 // odd steps) travels in it too instead of in thread-local state.
 struct Tuning {
   int fwd_variant, bwd_variant, xcd_remap, fwd_rows, fwd_split, bwd_rows, dv_threads, bwd_fused_nt, bwd_fused, dw_variant,
-      dw_tgs, chain_fused, chain_cc, fwd_wide, fwd_wg_limit, bwd_fused_wg_limit, chain_zigzag, mixer_wg_limit, mixer_ablate, mixer_lds;
+      dw_tgs, chain_fused, chain_cc, fwd_wide, fwd_wg_limit, bwd_fused_wg_limit, chain_zigzag, mixer_wg_limit, mixer_ablate, mixer_lds, bwd_ablate;
   bool walk_backwards;
 };
 
@@ -129,6 +131,7 @@ Tuning snapshot() {
   t.chain_cc = g_chain_cc.load(), t.fwd_wide = g_fwd_wide.load(), t.fwd_wg_limit = g_fwd_wg_limit.load();
   t.bwd_fused_wg_limit = g_bwd_fused_wg_limit.load(), t.chain_zigzag = g_chain_zigzag.load();
   t.mixer_wg_limit = g_mixer_wg_limit.load(), t.mixer_ablate = g_mixer_ablate.load(), t.mixer_lds = g_mixer_lds.load();
+  t.bwd_ablate = g_bwd_ablate.load();
   t.walk_backwards = false;
   return t;
 }
@@ -193,9 +196,12 @@ int make_geom(const Tuning& tn, int64_t B, int64_t N, int32_t L, int64_t C, int 
   if (nb > (int64_t)0x7fffffff)
     return fail(PSF_E_SHAPE, "launch of %lld workgroups exceeds the grid limit", (long long)nb);
   gm->nblocks = (uint32_t)nb;
+  gm->per_b_inv = udiv_inv_of((uint32_t)gm->per_b);
+  gm->chunks_inv = udiv_inv_of((uint32_t)gm->chunks_c);
   gm->xq = gm->nblocks / kXcds;
   gm->xr = gm->nblocks % kXcds;
   gm->remap = tn.xcd_remap ? (tn.walk_backwards && tn.chain_zigzag ? 2 : 1) : 0;
+  gm->aligned = 0;  // window_launches sets it from the pick
   gm->v_bstride = v_bstride;
   return PSF_OK;
 }
@@ -216,6 +222,7 @@ struct WinPick {
   int tiles_full;  // row tiles per sequence with all TR rows < N
   bool ragged;     // N % TR != 0: one more, partial, tile per sequence
   bool all_edge;   // every tile must take the EDGE kernel (channel groups not a multiple of TG, or W not chunk-clean)
+  bool aligned = false;  // Geom::aligned
 };
 
 #define PSF_TGS_SWITCH(FN, ARGS)                 \
@@ -277,6 +284,9 @@ bool pick_fused_step(const Tuning& tn, const void* dZ, const void* W, const void
   if (KN > L) KN = L;
   for (int k = 0; k < KN; ++k)
     if (offs.v[k] != chord_off(k)) return false;
+  for (int k = KN; k < L; ++k)
+    if (offs.v[k] % TR != 0) return false;  // far row blocks are TR-aligned (scalar block addresses in the kernel)
+  if (N * C * 4 >= ((int64_t)1 << 31)) return false;
   pk->tgs = tgs, pk->rows = 1, pk->nt = nt, pk->TR = TR, pk->KN = KN;
   pk->tiles_full = (int)(N / TR), pk->ragged = false, pk->all_edge = false;
   return true;
@@ -378,6 +388,9 @@ bool pick_window(const Tuning& tn, const void* W, int64_t B, int64_t N, int32_t 
   pick->KN = KN;
   pick->tiles_full = (int)(N / TR);
   pick->ragged = (N % TR) != 0;
+  pick->aligned = (N % TR) == 0 && N * C * 4 < ((int64_t)1 << 31);
+  for (int k = KN; k < L; ++k)
+    if (offs.v[k] % TR != 0) pick->aligned = false;
   const int TG = 1 << tgs;
   pick->all_edge = (CG % TG) != 0 || !aligned_to(W, 16) || ((B * N * (int64_t)L) % 4) != 0 || !tn.fwd_split ||
                    ragged_in_one_launch(tn, pick->ragged, B, N, L, C);
@@ -419,6 +432,7 @@ int window_launches(const Tuning& tn, const WinPick& pk, bool all_edge, int64_t 
   for (int i = 0; i < np; ++i) {
     if (int rc = make_geom(tn, B, N, L, C, 4, pk.tgs, pk.TR, split_channels, v_bstride, parts[i].tile0, parts[i].tiles, gm))
       return rc;
+    gm->aligned = pk.aligned && !parts[i].edge;
     *edge = parts[i].edge;
     hipError_t e = launch();
     if (e != hipSuccess) return fail_hip(e, what);
@@ -530,6 +544,7 @@ int bwd_impl(const Tuning& tn, const T* dZ, const T* W, const T* V, T* dW, T* dV
         a.V2 = V;
         a.out2 = dW;
         a.wg_per_cu = tn.bwd_fused_wg_limit;
+        a.ablate = tn.bwd_ablate;
         if (wfar != nullptr && far_k0 >= 0 && far_k0 <= pk.KN && pk.KN < L) {
           a.wfar = wfar;
           a.far_k0 = far_k0;
@@ -954,7 +969,12 @@ int psf_mixer_fwd_in_f32(const psf_mixer_input* in, int64_t B, int64_t N, int32_
   pk.tiles_full = (int)(N / mp.TR);
   pk.ragged = (N % mp.TR) != 0;
   const int TG = 1 << mp.tgs;
-  pk.all_edge = ((C / 4) % TG) != 0 || !tn.fwd_split || ragged_in_one_launch(tn, pk.ragged, B, N, E, C);  // (E: this step moves the data row, not the W row)
+  // The step kernel's full-tile instance takes every row block as TR-aligned (scalar block addresses, fwd_mlp_step.h): N and
+  // every far offset multiples of TR, rows of exactly 4 TG channels, a batch element under 2^31 bytes; anything else runs the
+  // predicated instance on every tile. (ragged_in_one_launch's E: this step moves the data row, not the W row.)
+  bool blocks_aligned = (N % mp.TR) == 0 && C == 4 * (int64_t)TG && N * C * 4 < ((int64_t)1 << 31) && N * (int64_t)E * 4 < ((int64_t)1 << 31);
+  for (int k = mp.KN; k < L; ++k) blocks_aligned = blocks_aligned && (offs.v[k] % mp.TR) == 0;
+  pk.all_edge = !blocks_aligned || !tn.fwd_split || ragged_in_one_launch(tn, pk.ragged, B, N, E, C);
   {  // (2) V0 = g(data): the matrix phase alone, on the same tiles
     FwdMlpArgs fa;
     fa.in = mi;

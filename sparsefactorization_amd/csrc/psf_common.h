@@ -31,8 +31,11 @@ struct Geom {
   int32_t chunks_c;  // ceil(CG / TG)
   int32_t per_b;     // tiles_n * chunks_c : workgroups per batch element
   uint32_t nblocks;  // B * per_b
+  uint32_t per_b_inv, chunks_inv;  // floor(2^32 / per_b), floor(2^32 / chunks_c) (2^32 - 1 for a divisor of 1): udiv_inv
   uint32_t xq, xr;   // nblocks / 8, nblocks % 8 for the bijective XCD remap
   int32_t remap;     // 1: logical block order is contiguous per XCD group
+  int32_t aligned;   // 1: N is a multiple of TR, so is every far offset, and a batch element's rows span < 2^31 bytes: every
+                     //    row block a full tile touches is TR-aligned and never wraps inside (scalar block addresses)
   int64_t v_bstride; // elements between batch elements of the gathered operand (0 = broadcast)
 };
 
@@ -52,11 +55,21 @@ __device__ __forceinline__ uint32_t logical_block(const Geom& gm) {
   return base + idx;
 }
 
+// n / d for wave-uniform operands with inv = floor(2^32 / d) from the host (2^32 - 1 when d = 1): the high product is the
+// quotient or one less, one compare fixes it — six scalar instructions where the compiler's division by a run-time value
+// takes ~25 and a round trip through the vector unit.
+__host__ __device__ inline uint32_t udiv_inv_of(uint32_t d) { return d <= 1u ? 0xffffffffu : (uint32_t)(((uint64_t)1 << 32) / d); }
+__device__ __forceinline__ uint32_t udiv_inv(uint32_t n, uint32_t d, uint32_t inv) {
+  uint32_t q = __umulhi(n, inv);
+  if (n - q * d >= d) ++q;
+  return q;
+}
+
 __device__ __forceinline__ void decode_block(const Geom& gm, int& b, int& tile, int& chunk) {
   const uint32_t lb = logical_block(gm);
-  b = (int)(lb / (uint32_t)gm.per_b);
+  b = (int)udiv_inv(lb, (uint32_t)gm.per_b, gm.per_b_inv);
   const uint32_t rem = lb - (uint32_t)b * (uint32_t)gm.per_b;
-  const uint32_t t = rem / (uint32_t)gm.chunks_c;
+  const uint32_t t = udiv_inv(rem, (uint32_t)gm.chunks_c, gm.chunks_inv);
   chunk = (int)(rem - t * (uint32_t)gm.chunks_c);
   tile = (int)t + gm.tile0;
 }
@@ -66,6 +79,20 @@ __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, 
 __device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
 __device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+
+// A wave-uniform global address pinned to scalar registers, opaque to the optimiser. Used as `sbase(block address) + lane
+// byte offset`: the sum then stays "scalar base + 32-bit vector offset" and selects that addressing form of the memory
+// instructions; left visible, the common `base0 + lane offset` of many loads is hoisted into a 64-bit vector address and
+// every load pays a 64-bit vector add for its block offset instead (r04: 180 -> ~60 vector instructions in the request phase
+// of the fused backward step). For a value already in scalar registers the two readfirstlanes are copies. The result is a
+// global-address-space pointer (the integer round trip would otherwise leave a flat one).
+#define PSF_GLOBAL __attribute__((address_space(1)))
+template <typename P>
+__device__ __forceinline__ PSF_GLOBAL P* sbase(P* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<PSF_GLOBAL P*>(((uint64_t)hi << 32) | lo);
+}
 
 // ---- VEC-wide register vectors ----
 template <typename T, int VEC>
@@ -90,6 +117,26 @@ __device__ __forceinline__ void st(T* p, const Vec<T, VEC>& v) {
   *reinterpret_cast<Vec<T, VEC>*>(p) = v;
 }
 
+// the same through a global-address-space byte pointer (sbase(...) + lane offset); the access itself is made on a built-in
+// vector type (a class type cannot be copied out of an address-space-qualified lvalue)
+template <typename T, int VEC>
+__device__ __forceinline__ Vec<T, VEC> ldg(const PSF_GLOBAL char* p) {
+  using Raw = T __attribute__((ext_vector_type(VEC)));
+  const Raw r = *reinterpret_cast<const PSF_GLOBAL Raw*>(p);
+  Vec<T, VEC> v;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) v.e[i] = r[i];
+  return v;
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void stg(PSF_GLOBAL char* p, const Vec<T, VEC>& v) {
+  using Raw = T __attribute__((ext_vector_type(VEC)));
+  Raw r;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) r[i] = v.e[i];
+  *reinterpret_cast<PSF_GLOBAL Raw*>(p) = r;
+}
+
 template <typename T, int VEC>
 __device__ __forceinline__ void axpy_rn(Vec<T, VEC>& acc, T w, const Vec<T, VEC>& x) {
 #pragma unroll
@@ -104,6 +151,7 @@ constexpr int chord_off(int k) { return k == 0 ? 0 : 1 << (k - 1); }
 
 constexpr int ilog2_floor(int x) { return x <= 1 ? 0 : 1 + ilog2_floor(x >> 1); }
 constexpr int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imin_rt(int a, int b) { return a < b ? a : b; }
 constexpr int imax(int a, int b) { return a > b ? a : b; }
 
 }  // namespace psf

@@ -29,7 +29,43 @@ __global__ void __launch_bounds__(256) stream_mix_k(const float4* __restrict__ w
   }
 }
 
+// the backward step's mix: reads W (2), V, dZ; writes dW (2), dV
+__global__ void __launch_bounds__(256) stream_mix_bwd_k(const float4* __restrict__ w, const float4* __restrict__ v,
+                                                        const float4* __restrict__ z, float4* __restrict__ dw,
+                                                        float4* __restrict__ dv, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i < n; i += stride) {
+    const float4 w0 = w[2 * i], w1 = w[2 * i + 1], vv = v[i], zz = z[i];
+    float4 a, b, c;
+    a.x = zz.x * vv.x, a.y = zz.y * vv.y, a.z = zz.z * vv.z, a.w = zz.w * vv.w;
+    b.x = zz.x + vv.x, b.y = zz.y + vv.y, b.z = zz.z + vv.z, b.w = zz.w + vv.w;
+    c.x = w0.x * zz.x + w1.x, c.y = w0.y * zz.y + w1.y, c.z = w0.z * zz.z + w1.z, c.w = w0.w * zz.w + w1.w;
+    dw[2 * i] = a;
+    dw[2 * i + 1] = b;
+    dv[i] = c;
+  }
+}
+
 }  // namespace
+
+extern "C" int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float* dw, float* dv, int64_t n_vec4,
+                                      void* stream) {
+  if (!w || !v || !z || !dw || !dv) return psf_internal_fail(PSF_E_NULL, "psf_stream_mix_bwd: NULL argument");
+  if (n_vec4 < 0) return psf_internal_fail(PSF_E_SHAPE, "psf_stream_mix_bwd: n_vec4 < 0");
+  if (((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(z) |
+        reinterpret_cast<uintptr_t>(dw) | reinterpret_cast<uintptr_t>(dv)) & 15) != 0)
+    return psf_internal_fail(PSF_E_ALIGN, "psf_stream_mix_bwd: pointers must be 16-byte aligned");
+  if (n_vec4 == 0) return PSF_OK;
+  const int64_t blocks_needed = (n_vec4 + 255) / 256;
+  const int grid = (int)(blocks_needed < 8192 ? blocks_needed : 8192);
+  hipLaunchKernelGGL(stream_mix_bwd_k, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(w), reinterpret_cast<const float4*>(v),
+                     reinterpret_cast<const float4*>(z), reinterpret_cast<float4*>(dw), reinterpret_cast<float4*>(dv),
+                     (size_t)n_vec4);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PSF_OK : psf_internal_fail((int)e, hipGetErrorString(e));
+}
 
 extern "C" int psf_stream_mix_f32(const float* w, const float* v, const float* r, float* out, int64_t n_vec4, void* stream) {
   if (!w || !v || !r || !out) return psf_internal_fail(PSF_E_NULL, "psf_stream_mix: NULL argument");
