@@ -58,6 +58,19 @@ def ab(name, fn, n, check=None):
     print(f"{name:44s} old {o:8.2f} us   new {w:8.2f} us   ({(o / w - 1) * 100:+5.1f} %){extra}", flush=True)
 
 
+from sparsefactorization_amd import fused_mlp  # noqa: E402
+from sparsefactorization_amd.psfnet import MLPBlock  # noqa: E402
+
+torch.manual_seed(0)
+for tag, T, O in (("cfg2: 15 MLPs, 1 M tokens", 64 * 16384, 15), ("Order B=40", 40 * 16384, 15), ("L=12 links", 64 * 2048, 12)):
+    blocks = [MLPBlock([32, 'GELU'], 32, 8).to(dev)] + [MLPBlock([32, 'GELU'], 32, O).to(dev) for _ in range(O - 1)]
+    x = torch.randn(T, 32, device=dev)
+    with torch.no_grad():
+        ab(f"producer MLPs forward, {tag}", lambda i: fused_mlp.fused_mlp_forward(x, blocks), 10,
+           check=lambda: list(fused_mlp.fused_mlp_forward(x, blocks)))
+    del x, blocks
+    torch.cuda.empty_cache()
+
 g = torch.Generator(device=dev).manual_seed(0)
 for tag, B, N, L, C in (("cfg2 B=64", 64, 16384, 15, 8), ("Order B=40", 40, 16384, 15, 8), ("genome B=16 C=32", 16, 16384, 15, 32),
                         ("pathfinder B=64 C=32", 64, 1024, 11, 32), ("C=16 N=4096 B=64", 64, 4096, 13, 16)):

@@ -173,7 +173,7 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
 #pragma unroll
     for (int f = 0; f < NF; ++f) axpy_rn<T, VEC>(acc, farW[f], farZ[f]);
     if (!(ABL & 64) || acc.e[0] == T(12345.678))
-      stg<T, VEC>(sbase(reinterpret_cast<char*>(dV + ((int64_t)b * N + q0) * C)) + voff, acc);
+      stg<T, VEC>(sbase(reinterpret_cast<char*>(dV + ((int64_t)b * N + q0) * C)) + lane_off(voff), acc);
   }
   // (5) dW row dots (the tile's dZ rows are the upper half of the dZ window)
   T dots[L];
@@ -206,6 +206,7 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
   __syncthreads();
   // (6) flat store of the dW tile: TR L / 4 whole chunks (full tiles of chunk-clean buffers: host-checked)
   PSF_GLOBAL char* ob = sbase(reinterpret_cast<char*>(dW + ((int64_t)b * N + q0) * L));
+  const uint32_t vo = lane_off(voff);
   const V4* __restrict__ sOutV = reinterpret_cast<const V4*>(sOutF);
 #pragma unroll
   for (int n = 0; n < FC::passes; ++n) {
@@ -213,9 +214,9 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
     if (n < FC::full || i < FC::tile_vecs) {
       if constexpr ((ABL & 128) != 0) {
         using F4 = float __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store(*reinterpret_cast<const F4*>(&sOutV[i]), reinterpret_cast<PSF_GLOBAL F4*>(ob + (uint32_t)i * 16u));
+        __builtin_nontemporal_store(*reinterpret_cast<const F4*>(&sOutV[i]), reinterpret_cast<PSF_GLOBAL F4*>(ob + ((uint32_t)(n * NT) * 16u + vo)));
       } else {
-        stg<T, VEC>(ob + (uint32_t)i * 16u, sOutV[i]);
+        stg<T, VEC>(ob + ((uint32_t)(n * NT) * 16u + vo), sOutV[i]);
       }
     }
   }

@@ -260,7 +260,7 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
   constexpr uint32_t rowB = TG * 16u;
   uint32_t voff[R];
 #pragma unroll
-  for (int j = 0; j < R; ++j) voff[j] = (uint32_t)(j * RS + rs) * rowB + (uint32_t)g * 16u;
+  for (int j = 0; j < R; ++j) voff[j] = lane_off((uint32_t)(j * RS + rs) * rowB + (uint32_t)g * 16u);  // (not the image loop's tid * 16)
   const char* __restrict__ Vbb = reinterpret_cast<const char*>(Vb);
   if constexpr (!EDGE) {
     int p1 = p0 + TR;
@@ -268,6 +268,8 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
 #pragma unroll
     for (int n = 0; n < Cfg::win_vecs / NT; ++n)
       stage16g<0>(sbase(Vbb + (uint32_t)(n / R == 0 ? p0 : p1) * rowB) + voff[n % R], sWin + n * NT + wave64);
+    // (requesting the far rows behind the barrier instead — nothing reads them before the matrix phase is over — measured
+    // no gain: 752 vs 747 us per mixer forward at cfg2, 516 vs 499 in the Order shape, one process, five rounds)
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       int s0 = p0 + offs.v[KN + f];
@@ -366,7 +368,7 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
     if constexpr (!EDGE) {
       const PSF_GLOBAL char* rb = sbase(reinterpret_cast<const char*>(res + ((int64_t)b * N + p0) * C));
 #pragma unroll
-      for (int j = 0; j < R; ++j) rres[j] = ldg<float, 4>(rb + voff[j]);
+      for (int j = 0; j < R; ++j) rres[j] = ldg<float, 4>(rb + lane_off(voff[j]));
     } else {
 #pragma unroll
       for (int j = 0; j < R; ++j) {
@@ -416,7 +418,7 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
   if constexpr (!EDGE) {
     PSF_GLOBAL char* ob = sbase(reinterpret_cast<char*>(out + ((int64_t)b * N + p0) * C));
 #pragma unroll
-    for (int j = 0; j < R; ++j) stg<float, 4>(ob + voff[j], acc[j]);
+    for (int j = 0; j < R; ++j) stg<float, 4>(ob + lane_off(voff[j]), acc[j]);
   } else {
 #pragma unroll
     for (int j = 0; j < R; ++j) {

@@ -135,7 +135,8 @@ __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* _
     for (int n = 0; n < Cfg::win_vecs / NT; ++n) {
       stage16g<0>(sbase(Vbb + (uint32_t)(n / R == 0 ? p0 : p1) * rowB) + voff[n % R], sWin + n * NT + wave64);
     }
-    // (3) far rows and residual -> registers
+    // (3) far rows and residual -> registers, issued AFTER every DMA request (the barrier below waits for the DMAs only)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       int s0 = p0 + offs.v[KN + f];
@@ -200,7 +201,18 @@ __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* _
 
   }
 
-  __syncthreads();  // (hipcc drains vmcnt here: the DMA'd tiles and the register loads have all landed)
+  if constexpr (ALIGNED) {
+    // The tile and the window have to be in LDS before anyone reads them; the far rows and the residual only before their
+    // own first use, which comes after the near links' arithmetic. Vector-memory operations retire in issue order, so
+    // "at most the register loads still outstanding" means every DMA has landed; the compiler's own counted waits cover the
+    // registers where they are read. (__syncthreads() would put a full vmcnt(0) here.)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NF * R + (RES ? R : 0)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
+    __syncthreads();  // (hipcc drains vmcnt here: the DMA'd tiles and the register loads have all landed)
+  }
 
   // ---- (3b) training: link-major side copy of W's far columns for the dV kernel (include/psf_chord.h) ----
   //      w_far[b][k - k0][p] = W[b][p][k]: the tile is in LDS, a column is TR consecutive floats of the copy
@@ -234,7 +246,7 @@ __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* _
     }
     if constexpr (ALIGNED) {
       PSF_GLOBAL char* ob = sbase(reinterpret_cast<char*>(out + ((int64_t)b * N + p0) * C));
-      stg<T, VEC>(ob + ((uint32_t)pl * ((uint32_t)C * (uint32_t)sizeof(T)) + (uint32_t)cg * 16u), acc);
+      stg<T, VEC>(ob + lane_off((uint32_t)pl * ((uint32_t)C * (uint32_t)sizeof(T)) + (uint32_t)cg * 16u), acc);
     } else {
       if (p < N && cg_ok) st<T, VEC>(out + ((int64_t)b * N + p) * C + (int64_t)cg * VEC, acc);
     }

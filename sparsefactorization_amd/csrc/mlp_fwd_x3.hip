@@ -30,6 +30,7 @@
 #include "mlp_fwd_x3.h"
 #include "mlp_x3_common.h"
 #include "mlp_x3_image.h"
+#include "psf_common.h"
 
 #include <atomic>
 extern std::atomic<int> psf_g_mlp_fwd_store;  // psf_chord.hip: tuning knob "mlp_fwd_store"
@@ -43,6 +44,13 @@ constexpr int kScr = 32 * 36;              // per-wave scratch floats: X staging
 
 // 4-byte-aligned vectors: hipcc emits global_store_dwordx4 / x3 / x2 for them (rows of O floats are 16-byte aligned only
 // when O is a multiple of 4; gfx950 stores unaligned vectors)
+// 4-byte-aligned vectors of 4, 3, 2 floats (built-in vector types: they can be stored through an address-space pointer)
+typedef float V4a __attribute__((ext_vector_type(4)));
+typedef float V3a __attribute__((ext_vector_type(3)));
+typedef float V2a __attribute__((ext_vector_type(2)));
+typedef V4a V4u __attribute__((aligned(4)));
+typedef V3a V3u __attribute__((aligned(4)));
+typedef V2a V2u __attribute__((aligned(4)));
 struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
 struct __attribute__((packed, aligned(4))) F3u { float x, y, z; };
 struct __attribute__((packed, aligned(4))) F2u { float x, y; };
@@ -59,6 +67,38 @@ __device__ unsigned long long psf_x3f_trace[4][16];
 #else
 #define PSF_FTRACE(slot) do { } while (0)
 #endif
+
+// One token's Y row from the lane's registers (store_direct in x3_fwd_k): group q holds outputs 8 q + 4 half + (0..3) at
+// yb + 32 q. OO > 0: the row length is a compile-time constant, so a group's width differs between lanes by `half` only;
+// OO = 0: any length, decided per lane.
+template <int OO>
+__device__ __forceinline__ void store_row_groups(PSF_GLOBAL char* yb, const f32x16& y, int half, int O_rt = 0) {
+  auto put = [&](int q, int n) {
+    if (n >= 4) *reinterpret_cast<PSF_GLOBAL V4u*>(yb + 32 * q) = V4u{y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]};
+    else if (n == 3) *reinterpret_cast<PSF_GLOBAL V3u*>(yb + 32 * q) = V3u{y[4 * q], y[4 * q + 1], y[4 * q + 2]};
+    else if (n == 2) *reinterpret_cast<PSF_GLOBAL V2u*>(yb + 32 * q) = V2u{y[4 * q], y[4 * q + 1]};
+    else if (n == 1) *reinterpret_cast<PSF_GLOBAL float*>(yb + 32 * q) = y[4 * q];
+  };
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if constexpr (OO > 0) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int n0 = OO - 8 * q, n1 = OO - 8 * q - 4;  // floats of the group that exist for half 0 / half 1
+      const int w0 = n0 >= 4 ? 4 : (n0 > 0 ? n0 : 0), w1 = n1 >= 4 ? 4 : (n1 > 0 ? n1 : 0);
+      if (w0 == w1) {
+        put(q, w0);
+      } else if (half == 0) {
+        put(q, w0);
+      } else {
+        put(q, w1);
+      }
+    } else {
+      put(q, O_rt - (8 * q + 4 * half));
+    }
+  }
+}
+
 
 // DIRECT: finished Y^T tiles leave straight from the accumulator registers (knob "mlp_fwd_store" = 1, the default) instead of
 // through the LDS transposition + contiguous bursts of the first form (0): equal bits, 1-10 % less time
@@ -183,22 +223,30 @@ x3_fwd_k(const X3Args a) {
     };
 
     // The lane holds Y^T[o = 8 q + 4 half + (0..3)][tok = c] in registers 4 q .. 4 q + 3: up to four consecutive floats of its
-    // token's row go out as one (unaligned) vector store per q — no LDS transposition, no parked tile, no flush.
+    // token's row go out as one (unaligned) vector store per q — no LDS transposition, no parked tile, no flush. Addresses: the
+    // tile's first row as a scalar base, the lane's token and half as one 32-bit offset, the q groups as immediates
+    // (psf_common.h: sbase). How many of a group's four floats exist depends on O and on the lane's half only; O is
+    // wave-uniform, so the widths PSFNet uses (C = 4, 8, 16, 32 for g; L = 4..20 for the link MLPs) are compiled in —
+    // one scalar branch on O, then per group either one store for every lane or one per half — and only other widths take
+    // the form that decides per lane and per group among four store widths (28 lane-masked blocks per unit).
     auto store_direct = [&](int k, const f32x16 (&y)[TPW]) {
       const X3Mlp& dp = a.m[k];
       const int O = dp.O;
+      const uint32_t lo = (uint32_t)c * (uint32_t)(O * 4) + (uint32_t)half * 16u;
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp) {
-        const int64_t tok = t0[tp] + c;
-        if (tok < a.T) {
-          float* yrow = dp.Y + tok * O;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int o0 = 8 * q + 4 * half, n = O - o0;
-            if (n >= 4) *reinterpret_cast<F4u*>(yrow + o0) = F4u{y[tp][4 * q], y[tp][4 * q + 1], y[tp][4 * q + 2], y[tp][4 * q + 3]};
-            else if (n == 3) *reinterpret_cast<F3u*>(yrow + o0) = F3u{y[tp][4 * q], y[tp][4 * q + 1], y[tp][4 * q + 2]};
-            else if (n == 2) *reinterpret_cast<F2u*>(yrow + o0) = F2u{y[tp][4 * q], y[tp][4 * q + 1]};
-            else if (n == 1) yrow[o0] = y[tp][4 * q];
+        if (t0[tp] + c < a.T) {
+          PSF_GLOBAL char* yb = psf::sbase(reinterpret_cast<char*>(dp.Y + t0[tp] * O)) + lo;
+          switch (O) {
+#define PSF_O(OO) \
+  case OO:        \
+    store_row_groups<OO>(yb, y[tp], half); \
+    break;
+            PSF_O(4) PSF_O(5) PSF_O(6) PSF_O(7) PSF_O(8) PSF_O(9) PSF_O(10) PSF_O(11) PSF_O(12) PSF_O(13) PSF_O(14) PSF_O(15)
+            PSF_O(16) PSF_O(17) PSF_O(18) PSF_O(19) PSF_O(20) PSF_O(32)
+#undef PSF_O
+            default:
+              store_row_groups<0>(yb, y[tp], half, O);
           }
         }
       }

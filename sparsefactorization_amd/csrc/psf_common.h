@@ -117,6 +117,15 @@ __device__ __forceinline__ void st(T* p, const Vec<T, VEC>& v) {
   *reinterpret_cast<Vec<T, VEC>*>(p) = v;
 }
 
+// A copy of a per-lane byte offset that the optimiser treats as a new value (one v_mov at most). The scalar-base form needs
+// to SEE a 32-bit offset being widened in the block of the memory instruction; the widening of a value used in several blocks
+// is done once, in the first, and the later blocks get a 64-bit register they can only add to the base with a 64-bit vector
+// add. So: one laundered copy per later block that uses the offset.
+__device__ __forceinline__ uint32_t lane_off(uint32_t v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 // the same through a global-address-space byte pointer (sbase(...) + lane offset); the access itself is made on a built-in
 // vector type (a class type cannot be copied out of an address-space-qualified lvalue)
 template <typename T, int VEC>
