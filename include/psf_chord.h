@@ -222,6 +222,16 @@ int psf_adam_step_f32(float* const* params, const float* const* grads, float* co
 int psf_embed_tokens_f32(const int64_t* idx, const float* table, const float* pos, float* out, int64_t T, int64_t N,
                          int32_t V, int32_t E, void* stream);
 /*
+ * Rows of a narrow affine input layer — `init_linear` of the synthetic PSFNet (SyntheticExperiments/psf.py:153-154:
+ * Linear(2, embedding_size) on [value, marker]):
+ *     out[t,:] = x[t,0..K) W^T + bias          t < T
+ *   x [T,K] with 1 <= K <= 3, W [E,K], bias [E] or NULL, out [T,E] 16-byte aligned, E a multiple of 4, at most 1024. One pass over the
+ *   output (the K = 2 product is a 134 MB write at 1 M positions, not a GEMM). Arithmetic: x_0 w_e0, fused adds of x_1 w_e1
+ *   and x_2 w_e2, one rounded add of the bias — the same as the mixer entry's PSF_MIXER_IN_AFFINE recipe, bit for bit.
+ */
+int psf_affine_rows_f32(const float* x, const float* W, const float* bias, float* out, int64_t T, int32_t K, int32_t E,
+                        void* stream);
+/*
  * Its gradient with respect to the table:  dTable[v,:] = sum over {t : idx[t] == v} of dOut[t,:]   (fully written;
  * the caller zeroes a padding row). No sort, no atomics, no host read-back: deterministic (a fixed order of
  * additions) and capturable in a HIP graph, unlike the sort-and-partition backward of nn.Embedding.

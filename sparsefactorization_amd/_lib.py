@@ -46,6 +46,7 @@ SIGNATURES = {
                            ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_vp, c_vp], ctypes.c_int),
     "psf_sum_tensors_f32": ([ctypes.POINTER(c_vp), c_i32, c_i64, c_vp, c_vp], ctypes.c_int),
     "psf_embed_tokens_f32": ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp], ctypes.c_int),
+    "psf_affine_rows_f32": ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp], ctypes.c_int),
     "psf_embed_tokens_bwd_workspace": ([c_i64, c_i32, c_i32], c_i64),
     "psf_embed_tokens_bwd_f32": ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp], ctypes.c_int),
     "psf_flat_head_workspace": ([c_i32, c_i64, c_i32], c_i64),

@@ -58,6 +58,55 @@ extern "C" int psf_embed_tokens_f32(const int64_t* idx, const float* table, cons
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Rows of a narrow affine input layer: out[t, :] = x[t, 0..K) W^T + b, K <= 3 inputs per position
+// (init_linear of the synthetic PSFNet, SyntheticExperiments/psf.py:153-154: Linear(2, 32) on [value, marker]).
+// ------------------------------------------------------------------------------------------------------
+// As a library GEMM the K = 2 product takes 80 us for 1 M positions; it is a 134 MB write. A thread computes four features of
+// one position: x_0 w_e0, then fused adds of x_1 w_e1 and x_2 w_e2, then one rounded add of the bias — the arithmetic of the
+// mixer kernels' AFFINE recipe (csrc/fwd_mlp_step.h: data_row8), so the two agree bit for bit.
+namespace {
+
+__global__ void __launch_bounds__(256)
+affine_rows_k(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ out,
+              int64_t T, int32_t K, int32_t E4) {
+  // a thread keeps ONE group of four features (its weights and biases in registers) and walks the positions
+  const int per = 256 / E4;  // positions per workgroup per pass (E4 <= 256: host-checked)
+  const int tid = threadIdx.x, e4 = tid % E4, tl = tid / E4;
+  if (tl >= per) return;
+  float w0[4], w1[4], w2[4], bb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float* w = W + (int64_t)(4 * e4 + j) * K;
+    w0[j] = w[0], w1[j] = K > 1 ? w[1] : 0.f, w2[j] = K > 2 ? w[2] : 0.f;
+    bb[j] = bias ? bias[4 * e4 + j] : 0.f;
+  }
+  for (int64_t t = (int64_t)blockIdx.x * per + tl; t < T; t += (int64_t)gridDim.x * per) {
+    const float x0 = x[t * K], x1 = K > 1 ? x[t * K + 1] : 0.f, x2 = K > 2 ? x[t * K + 2] : 0.f;
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = __fadd_rn(fmaf(x2, w2[j], fmaf(x1, w1[j], __fmul_rn(x0, w0[j]))), bb[j]);
+    reinterpret_cast<float4*>(out)[t * E4 + e4] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+}  // namespace
+
+extern "C" int psf_affine_rows_f32(const float* x, const float* W, const float* bias, float* out, int64_t T, int32_t K, int32_t E,
+                                   void* stream) {
+  if (!x || !W || !out) return psf_internal_fail(PSF_E_NULL, "psf_affine_rows: x, W and out must be non-NULL");
+  if (T < 0 || K < 1 || K > 3 || E < 4 || (E & 3) || E > 1024)
+    return psf_internal_fail(PSF_E_SHAPE, "psf_affine_rows: need T >= 0, 1 <= K <= 3, E a multiple of 4 in 4..1024");
+  if (reinterpret_cast<uintptr_t>(out) & 15) return psf_internal_fail(PSF_E_ALIGN, "psf_affine_rows: out must be 16-byte aligned");
+  if (T == 0) return PSF_OK;
+  const int per = 256 / (E / 4);
+  const int64_t blocks = (T + per - 1) / per;
+  const int grid = (int)(blocks < 8192 ? blocks : 8192);
+  hipLaunchKernelGGL(affine_rows_k, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, W, bias, out, T, K, E / 4);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PSF_OK : psf_internal_fail((int)e, hipGetErrorString(e));
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Gradient of the table:  dTable[v, :] = sum over the tokens t with idx[t] == v of dOut[t, :]
 // ------------------------------------------------------------------------------------------------------
 // PyTorch's embedding_dense_backward sorts the indices and partitions them (rocprim) with sizes read back to the

@@ -25,9 +25,15 @@ route = "auto"
 #: Evaluate the embedding lookup inside the mixer kernels (Recipe.tokens) instead of materialising ``data`` with
 #: psf_embed_tokens_f32 first. Off: the lookup makes the table and positional loads depend on the token load, which lengthens
 #: every workgroup's load phase — 712 against 609 + 28 us at Temporal Order's shape (N = 16384, B = 40), 1040 against 885 + 42 at
-#: B = 64 (profiles/r04h_mixer_bench.log). The affine recipe (Adding's init_linear, an 80 us library GEMM for a K = 2
-#: product) has no such dependency and is always taken.
+#: B = 64 (profiles/r04h_mixer_bench.log).
 tokens_in_kernel = False
+#: Evaluate the affine input layer (Recipe.affine: Adding's init_linear) inside the mixer kernels instead of writing ``data``
+#: with psf_affine_rows_f32 (one 25 us pass) first. Off since the step kernel's request phase went on its instruction diet
+#: (round 4): reading the 128-byte data row costs it ~150 vector instructions per wave, evaluating 32 features from two inputs
+#: ~375, and the vector unit is what bounds that kernel — PSFNet forward at N = 16384, B = 64: 0.97 ms with the recipe in the
+#: kernels, 0.82 with the rows written once (bench.py e2e_forward; the Order network, whose rows come from
+#: psf_embed_tokens_f32, is the same kernel sequence).
+affine_in_kernel = False
 
 
 class Recipe:
@@ -108,6 +114,8 @@ def eligible_recipe(r: Recipe, g: nn.Module, fs: Sequence[nn.Module]) -> bool:
     if not enabled or not r.ok() or torch.is_grad_enabled() and any(t.requires_grad for t in r.tensors() if t.is_floating_point()):
         return False
     if r.kind == _lib.MIXER_IN_TOKENS and not tokens_in_kernel:
+        return False
+    if r.kind == _lib.MIXER_IN_AFFINE and not affine_in_kernel:
         return False
     if _needs_grad(torch.empty(0), [g, *fs]):
         return False

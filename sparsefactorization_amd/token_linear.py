@@ -48,11 +48,37 @@ def linear_wgrad(x2d: torch.Tensor, dy2d: torch.Tensor, need_bias: bool = True):
     return dW, db
 
 
+def affine_rows_supported(x: torch.Tensor, weight: torch.Tensor, bias) -> bool:
+    """``x @ weight.T + bias`` with at most three inputs per position on the GPU in fp32: psf_affine_rows_f32 (csrc/embed.hip)
+    writes the rows in one pass (init_linear of the synthetic PSFNet, SyntheticExperiments/psf.py:153-154: a library GEMM
+    takes 80 us for that K = 2 product at 1 M positions, the pass 25)."""
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() >= 2 and 1 <= x.shape[-1] <= 3
+            and weight.dim() == 2 and weight.shape[1] == x.shape[-1] and weight.shape[0] % 4 == 0 and 4 <= weight.shape[0] <= 1024
+            and (bias is None or bias.dtype == torch.float32))
+
+
+def affine_rows(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
+    """The rows themselves (no autograd). Products summed in input order with fused adds, then one rounded add of the bias —
+    the arithmetic of the mixer kernels' affine recipe, bit for bit."""
+    K, E = x.shape[-1], weight.shape[0]
+    x2 = x.detach().reshape(-1, K).contiguous()
+    w = weight.detach().contiguous()
+    b = bias.detach().contiguous() if bias is not None else None
+    out = torch.empty((x2.shape[0], E), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().psf_affine_rows_f32(x2.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None, out.data_ptr(),
+                                             x2.shape[0], K, E, torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "psf_affine_rows_f32")
+    return out.reshape(*x.shape[:-1], E)
+
+
 class _TokenLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if affine_rows_supported(x, weight, bias):
+            return affine_rows(x, weight, bias)
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -185,4 +211,6 @@ class TokenLinear(nn.Linear):
         if torch.is_grad_enabled() and (self.weight.requires_grad or (self.bias is not None and self.bias.requires_grad)) \
                 and x.dim() >= 2 and wgrad_supported(x.reshape(-1, x.shape[-1]), self.out_features):
             return _TokenLinearFn.apply(x, self.weight, self.bias)
+        if not torch.is_grad_enabled() and affine_rows_supported(x, self.weight, self.bias):
+            return affine_rows(x, self.weight, self.bias)
         return super().forward(x)

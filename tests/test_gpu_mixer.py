@@ -153,6 +153,28 @@ def test_mixer_from_the_recipe_of_data_matches_the_float64_reference(gpu, name, 
     assert rel_inf(got, want) <= TOL, f"{name}: rel {rel_inf(got, want):.3e}"
 
 
+@pytest.mark.parametrize("K,E,bias", [(2, 32, True), (1, 8, True), (3, 12, False)])
+def test_affine_rows_kernel_matches_float64_and_the_linear_module(gpu, K, E, bias):
+    """psf_affine_rows_f32 (init_linear of the synthetic PSFNet as one pass over its output, psf.py:153-154) against the same
+    layer in float64, through TokenLinear's no-grad path; under autograd the module's forward gives the same bits."""
+    from sparsefactorization_amd.token_linear import TokenLinear
+    torch.manual_seed(5)
+    lin = TokenLinear(K, E, bias=bias)
+    x = torch.rand(3, 1000, K) * 4 - 2
+    with torch.no_grad():
+        want = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double() if bias else None).numpy()
+    lin.to(gpu)
+    xg = x.to(gpu)
+    with torch.no_grad():
+        got = lin(xg)
+    assert got.shape == (3, 1000, E)
+    assert rel_inf(got.cpu().numpy(), want) <= 1e-6
+    again = lin(xg)  # grad enabled: the autograd function's forward
+    assert again.requires_grad and torch.equal(again.detach(), got)
+    again.sum().backward()
+    assert torch.isfinite(lin.weight.grad).all()
+
+
 def test_mixer_equals_producer_plus_chain_closely(gpu):
     """The same network through the two routes of this package: W_m written by psf_mlp_fwd_f32 and read by the chain, and W_m
     computed inside the step. Same split-bf16 arithmetic for W, same chain order: they agree far below the parity bar."""
