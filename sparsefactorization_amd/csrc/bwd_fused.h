@@ -184,13 +184,19 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
       V4 x;
       if (k < KN) x = (ABL & 32) ? dz : sV[((pl + chord_off(k)) << TGS) + g];
       else x = farV[k - KN < NF ? k - KN : 0];
-      T part = T(0);
+      // the lane's four products as two packed multiplies, summed pairwise: (p0 + p2) + (p1 + p3) — four instructions. (Written
+      // as a running sum, hipcc paired the sums of two LINKS into packed adds and paid four register moves per pair: eight
+      // instructions per link. dW is held to 1e-5, not to the oracle's bits: its sum over a row's lanes is a tree already.)
+      using F2 = float __attribute__((ext_vector_type(2)));
+      T part;
       if constexpr ((ABL & 512) != 0) {
+        part = T(0);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) part = __builtin_fmaf(dz.e[i], x.e[i], part);
       } else {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) part = add_rn(part, mul_rn(dz.e[i], x.e[i]));
+        const F2 pa = F2{dz.e[0], dz.e[1]} * F2{x.e[0], x.e[1]}, pb = F2{dz.e[2], dz.e[3]} * F2{x.e[2], x.e[3]};
+        const F2 ps = pa + pb;
+        part = add_rn(ps.x, ps.y);
       }
       dots[k] = row_group_sum<TG>(part);
     }
