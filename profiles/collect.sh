@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 python3 -c "from sparsefactorization_amd.build import csrc_hash; print(csrc_hash())" > "$OUT/csrc_hash.txt"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train --no-extra-legs"
 
 run() {  # name, rocprofv3 args...
   local name=$1; shift

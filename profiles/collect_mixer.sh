@@ -10,7 +10,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_${TAG}_mixer
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for route in never always; do
+for route in never always recipe; do
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$route" -- python3 $ROOT/profiles/mixer_route_run.py $route > "$OUT/stats_$route.log" 2>&1
   echo "stats $route rc=$?"
   timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_$route" -- python3 $ROOT/profiles/mixer_route_run.py $route > "$OUT/fetch_$route.log" 2>&1

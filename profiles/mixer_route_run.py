@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Workload for rocprofv3: 20 no-grad forwards of the Adding PSFNet (seed 42, N = 16384, B = 64) through ONE route of the
-mixer:  python3 profiles/mixer_route_run.py never|always   (never = W through memory, always = W computed inside the step)."""
+mixer:  python3 profiles/mixer_route_run.py never|always|recipe   (never = W through memory, always = W computed inside the
+step, recipe = the same with the affine input layer evaluated inside the kernels too: `data` never written)."""
 import os
 import sys
 
@@ -11,6 +12,8 @@ from sparsefactorization_amd import fused_mixer, psf_training  # noqa: E402
 from sparsefactorization_amd.train import seed_everything  # noqa: E402
 
 fused_mixer.route = sys.argv[1] if len(sys.argv) > 1 else "never"
+if fused_mixer.route == "recipe":
+    fused_mixer.route, fused_mixer.affine_in_kernel = "always", True
 problem = sys.argv[2] if len(sys.argv) > 2 else "adding"
 dev = torch.device("cuda:0")
 seed_everything(42)

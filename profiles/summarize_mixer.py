@@ -33,7 +33,8 @@ print(f"# {tag} — the Adding forward (PSFNet seed 42, N = 16384, B = 64, no_gr
 print("Per forward; memory-side bytes = L2 <-> fabric (Infinity-Cache hits included), FETCH_SIZE doubled per the guide.\n")
 summary = {}
 for route, title in (("never", "W through memory: psf_mlp_fwd_f32 + psf_chord_chain_fwd_f32"),
-                     ("always", "W computed inside the step: psf_mixer_fwd_f32")):
+                     ("always", "W computed inside the step: psf_mixer_fwd_f32 (data rows written once by psf_affine_rows_f32)"),
+                     ("recipe", "W computed inside the step and the affine input layer evaluated in the kernels: psf_mixer_fwd_in_f32, `data` never written")):
     stats = glob.glob(os.path.join(src, f"stats_{route}", "**", "*kernel_stats.csv"), recursive=True)
     fetch = counters(os.path.join(src, f"fetch_{route}"), "FETCH_SIZE")
     write = counters(os.path.join(src, f"write_{route}"), "WRITE_SIZE")
@@ -57,7 +58,10 @@ for route, title in (("never", "W through memory: psf_mlp_fwd_f32 + psf_chord_ch
                 print(f"| `{k[:90]}` | {calls:.2f} | {avg:.1f} | {calls * avg:.1f} | {r:.0f} | {w:.0f} |")
     print(f"| **total** | | | **{tot_us:.0f}** | **{tot_r:.0f}** | **{tot_w:.0f}** |\n")
     summary[route] = (tot_us, tot_r, tot_w)
-if len(summary) == 2:
+if "never" in summary and "always" in summary:
     a, b = summary["never"], summary["always"]
     print(f"Written per forward: {a[2]:.0f} MB -> {b[2]:.0f} MB; read: {a[1]:.0f} MB -> {b[1]:.0f} MB; kernel time {a[0]:.0f} us -> {b[0]:.0f} us. "
           "The 14 W_m of this forward are 14 x 62.9 MB = 881 MB: written once and read once on the first route, absent from the second.")
+if "recipe" in summary:
+    c = summary["recipe"]
+    print(f"\nWith `data` left unwritten as well: written {c[2]:.0f} MB, read {c[1]:.0f} MB, kernel time {c[0]:.0f} us per forward.")

@@ -185,6 +185,26 @@ def test_forward_explicit_offsets(gpu):
     assert np.array_equal(got, oc.spmul_fwd(W, V, off))
 
 
+@pytest.mark.parametrize("B,N,L,C,far", [(2, 4096, 12, 8, [777, 3001]), (2, 2048, 11, 32, [200, 1000, 1500]),
+                                           (3, 16384, 15, 8, [512, 1024, 2048, 4096, 8192])])
+def test_window_kernels_with_chord_near_links_and_any_far_offsets(gpu, B, N, L, C, far):
+    """The window kernels take the near links as the chord pattern's constants and the far ones as run-time values. Far
+    offsets that are multiples of the tile length — every chord offset is — let a launch of full tiles compute its row-block
+    addresses on the scalar unit (Geom::aligned, fwd_window.h / bwd_fused.h); any others keep the per-lane form. Both against
+    the oracle: forward and dV bit for bit, dW to the parity bar."""
+    import sparsefactorization_amd as sfa
+    off = [0] + [1 << k for k in range(L - 1 - len(far))] + list(far)
+    assert len(off) == L
+    W, V, dZ = _mk((B, N, L), 91), _mk((B, N, C), 92), _mk((B, N, C), 93)
+    Wt, Vt = _t(W, gpu).requires_grad_(True), _t(V, gpu).requires_grad_(True)
+    out = sfa.chord_spmm(Wt, Vt, offsets=off)
+    assert np.array_equal(out.detach().cpu().numpy(), oc.spmul_fwd(W, V, off))
+    out.backward(_t(dZ, gpu))
+    dF, dV = oc.spmul_bwd(dZ, W, V, off)
+    assert np.array_equal(Vt.grad.cpu().numpy(), dV)
+    assert rel_inf(Wt.grad.cpu().numpy(), dF) <= TOL
+
+
 def test_forward_f64(gpu):
     import sparsefactorization_amd as sfa
     rng = np.random.default_rng(12)
