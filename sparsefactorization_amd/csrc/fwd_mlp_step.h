@@ -281,29 +281,28 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
     }
   } else {
 #pragma unroll
-  for (int n = 0; n < Cfg::win_vecs / NT; ++n) {
-    const int i = n * NT + tid;
-    const int wr = i >> TGS, gg = i & (TG - 1);
-    int src = p0 + wr;
-    if (src >= N) src -= N;
-    if (!EDGE || gg < gm.CG)
-      stage16<float, 4, true>(Vb + (int64_t)src * C + (int64_t)gg * 4, sWin + n * NT + wave64, lane);
-  }
-
-  // ---- (0c) far rows and residual -> registers ----
-#pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const int pr = p0 + j * RS + rs;
-    const int p = EDGE ? imin(pr, N - 1) : pr;
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      int src = p + offs.v[KN + f];
+    for (int n = 0; n < Cfg::win_vecs / NT; ++n) {
+      const int i = n * NT + tid;
+      const int wr = i >> TGS, gg = i & (TG - 1);
+      int src = p0 + wr;
       if (src >= N) src -= N;
-      if (ablate & 4) src = p;  // timing only: the row itself (an L2 / window hit) instead of the far row
-      far[j][f] = ld<float, 4>(Vb + (int64_t)src * C + (int64_t)cgc * 4);
+      if (!EDGE || gg < gm.CG)
+        stage16<float, 4, true>(Vb + (int64_t)src * C + (int64_t)gg * 4, sWin + n * NT + wave64, lane);
     }
-  }
 
+    // (0c) far rows -> registers
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int pr = p0 + j * RS + rs;
+      const int p = EDGE ? imin(pr, N - 1) : pr;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        int src = p + offs.v[KN + f];
+        if (src >= N) src -= N;
+        if (ablate & 4) src = p;  // timing only: the row itself (an L2 / window hit) instead of the far row
+        far[j][f] = ld<float, 4>(Vb + (int64_t)src * C + (int64_t)cgc * 4);
+      }
+    }
   }
 
   __syncthreads();  // images and window have landed (hipcc drains vmcnt before the barrier)

@@ -151,54 +151,53 @@ __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* _
       for (int j = 0; j < R; ++j) rres[j] = ldg<T, VEC>(rb + voff[j]);
     }
   } else {
-  // ---- (1) W tile: the 16-byte chunks covering the tile's elements of the flat W buffer ----
-  const int nvec = (mis + rows_here * L + VEC - 1) / VEC;
-  const T* __restrict__ Wal = W + e_al;
+    // ---- (1) W tile: the 16-byte chunks covering the tile's elements of the flat W buffer ----
+    const int nvec = (mis + rows_here * L + VEC - 1) / VEC;
+    const T* __restrict__ Wal = W + e_al;
 #pragma unroll
-  for (int n = 0; n < Cfg::w_passes; ++n) {
-    const int i = n * NT + tid;
-    if (i < nvec) {
-      bool whole = true;
-      if constexpr (EDGE) {
-        const int64_t e0 = e_al + (int64_t)i * VEC;
-        whole = e0 >= 0 && e0 + VEC <= w_total;
-        if (!whole) {  // first / last 16 bytes of the whole buffer only
-          T* se = reinterpret_cast<T*>(sWv + i);
+    for (int n = 0; n < Cfg::w_passes; ++n) {
+      const int i = n * NT + tid;
+      if (i < nvec) {
+        bool whole = true;
+        if constexpr (EDGE) {
+          const int64_t e0 = e_al + (int64_t)i * VEC;
+          whole = e0 >= 0 && e0 + VEC <= w_total;
+          if (!whole) {  // first / last 16 bytes of the whole buffer only
+            T* se = reinterpret_cast<T*>(sWv + i);
 #pragma unroll
-          for (int u = 0; u < VEC; ++u)
-            if (e0 + u >= 0 && e0 + u < w_total) se[u] = Wal[(int64_t)i * VEC + u];
+            for (int u = 0; u < VEC; ++u)
+              if (e0 + u >= 0 && e0 + u < w_total) se[u] = Wal[(int64_t)i * VEC + u];
+          }
         }
+        if (whole) stage16<T, VEC, DMA, PSF_W_DMA_AUX>(Wal + (int64_t)i * VEC, sWv + n * NT + wave64, lane);
       }
-      if (whole) stage16<T, VEC, DMA, PSF_W_DMA_AUX>(Wal + (int64_t)i * VEC, sWv + n * NT + wave64, lane);
     }
-  }
 
-  // ---- (2) V window [p0, p0+WR) mod N ----
+    // ---- (2) V window [p0, p0+WR) mod N ----
 #pragma unroll
-  for (int n = 0; n < Cfg::win_vecs / NT; ++n) {
-    const int i = n * NT + tid;
-    const int wr = i >> TGS, gg = i & (TG - 1);
-    int src = p0 + wr;
-    if (src >= N) src -= N;
-    const int cgi = chunk * TG + gg;
-    if (!EDGE || cgi < gm.CG)
-      stage16<T, VEC, DMA>(Vb + (int64_t)src * C + (int64_t)cgi * VEC, sWin + n * NT + wave64, lane);
-  }
-
-  // ---- (3) far rows and residual -> registers ----
-#pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const int pr = p0 + j * RS + rs;
-    const int p = EDGE ? imin(pr, N - 1) : pr;
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      int src = p + offs.v[KN + f];
+    for (int n = 0; n < Cfg::win_vecs / NT; ++n) {
+      const int i = n * NT + tid;
+      const int wr = i >> TGS, gg = i & (TG - 1);
+      int src = p0 + wr;
       if (src >= N) src -= N;
-      far[j][f] = ld<T, VEC>(Vb + (int64_t)src * C + (int64_t)cgc * VEC);
+      const int cgi = chunk * TG + gg;
+      if (!EDGE || cgi < gm.CG)
+        stage16<T, VEC, DMA>(Vb + (int64_t)src * C + (int64_t)cgi * VEC, sWin + n * NT + wave64, lane);
     }
-    if constexpr (RES) rres[j] = ld<T, VEC>(res + ((int64_t)b * N + p) * C + (int64_t)cgc * VEC);
-  }
 
+    // ---- (3) far rows and residual -> registers ----
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int pr = p0 + j * RS + rs;
+      const int p = EDGE ? imin(pr, N - 1) : pr;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        int src = p + offs.v[KN + f];
+        if (src >= N) src -= N;
+        far[j][f] = ld<T, VEC>(Vb + (int64_t)src * C + (int64_t)cgc * VEC);
+      }
+      if constexpr (RES) rres[j] = ld<T, VEC>(res + ((int64_t)b * N + p) * C + (int64_t)cgc * VEC);
+    }
   }
 
   if constexpr (ALIGNED) {
