@@ -465,6 +465,20 @@ chord_mixer_g_k(const MixerIn in, float* __restrict__ out, const unsigned char* 
     const int t = wv + i * NW;
     const int row = p0 + 32 * (t < TT ? t : 0) + c;
     const int rowc = (EDGE && row >= N) ? N - 1 : row;
+    if constexpr (KIND == 0 && !EDGE) {  // rows of 32 features in a full tile: scalar block address + one lane offset (as the step kernel)
+      if (E == 32) {
+        const PSF_GLOBAL char* blk =
+            sbase(reinterpret_cast<const char*>(in.src) + ((int64_t)b * N + p0 + 32 * (t < TT ? t : 0)) * (32 * 4));
+        const uint32_t xo = (uint32_t)c * 128u + (uint32_t)half * 32u;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const Vec<float, 4> lo = ldg<float, 4>(blk + (xo + 64u * s)), hi = ldg<float, 4>(blk + (xo + 64u * s + 16u));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xv[i][s][q] = lo.e[q], xv[i][s][4 + q] = hi.e[q];
+        }
+        continue;
+      }
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) data_row8<KIND>(in, sAff, b, rowc, N, E, 16 * s + 8 * half, false, xv[i][s]);
   }

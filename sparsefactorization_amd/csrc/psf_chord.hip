@@ -776,6 +776,7 @@ const char* psf_build_info(void) {
          " | producers: fused MLP fwd (split-bf16 MFMA at f32 accuracy, f32 MFMA) + fused MLP bwd (split-bf16 MFMA on dual-use LDS planes, f32 MFMA),"
          " tall-skinny weight gradients (f32 MFMA), token embedding + positional add"
          ", wide producer MLPs (E <= 1024: stacked first layers as split-bf16 GEMMs from bf16 term planes, LDS-DMA ring)"
+         " | mixer: W_m computed inside the chain step (per-step kernels; one LDS-resident launch for short sequences)"
          " | arithmetic of the chord path: uncontracted mul+add, links ascending"
 #ifdef PSF_CSRC_HASH
          " | csrc=" PSF_CSRC_HASH  // build.csrc_hash() of the sources this library was built from (_lib.load compares)
@@ -1054,7 +1055,7 @@ int psf_describe_fwd(int64_t B, int64_t N, int32_t L, int64_t C, int32_t elem_by
   if (variant != 1 && elem_bytes == 4 && pick_window(tn, nullptr, B, N, L, C, offs, vec_ok, &pk, tn.fwd_rows, true)) {
     snprintf(buf, cap, "chord_fwd_win_k<f32,L=%d,TG=%d,R=%d,NT=%d> TR=%d near=%d far=%d tiles=%s", (int)L,
              1 << pk.tgs, pk.rows, pk.nt, pk.TR, pk.KN, (int)L - pk.KN,
-             pk.all_edge ? "edge" : (pk.ragged ? "full+ragged" : "full"));
+             pk.all_edge ? "edge" : (pk.ragged ? "full+ragged" : (pk.aligned ? "full, aligned (scalar block addresses)" : "full")));
   } else {
     snprintf(buf, cap, "chord_fwd_generic_k<%s,VEC=%d>", elem_bytes == 4 ? "f32" : "f64", vec_ok ? vecw : 1);
   }
