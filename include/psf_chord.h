@@ -420,9 +420,12 @@ int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float
  *   key "dw_tgs"     : chunk-looping dW, lanes per row chunk: 0 = auto (8; 16 when that spares a ragged tile), 4 = 8, 5 = 16
  *   key "dv_threads" : dV window kernel: 0 = auto (512 threads x 1 row for C <= 8, else 256 threads), 1 = 256 threads
  *                      (rows per thread from "bwd_rows"), 2 = 512 threads x 1 row where compiled (C <= 32)
- *   key "bwd_fused"  : a backward step that wants both dW and dV: 1 or 2 = ONE fused kernel where it applies (default:
- *                      rows of C = 4, 8, 16 or 32 channels, N a multiple of the tile, 16-byte-aligned chunk-clean
- *                      buffers — the dZ window staged once serves both gradients), 0 = always the two kernels
+ *   key "bwd_fused"  : a backward step that wants both dW and dV: 1 (default) = ONE fused kernel for rows of C = 4, 8, 16 or
+ *                      32 channels and sequences of at least two tiles — the dZ window staged once serves both gradients:
+ *                      the aligned instance (N and the far offsets multiples of the tile, 16-byte-aligned chunk-clean
+ *                      buffers: row-block addresses on the scalar unit) or else the general one (any N — N = 2^k + 1 with a
+ *                      CLS token —, any far offsets, W / dW at any alignment); 2 = the aligned instance or the two kernels;
+ *                      0 = always the two kernels
  *   key "bwd_fused_nt": threads of the fused kernel: 1 = 256 (default; tile = 256 / (C / 4) rows), 0 = 512
  *   key "fwd_wide"   : rows of >= 64 channels: 0 = one workgroup spans the whole row (default, fastest measured);
  *                      1 = 32-channel chunks on 1024-thread workgroups (256-row tiles); 2 = 32-channel chunks

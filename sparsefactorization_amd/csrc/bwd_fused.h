@@ -228,4 +228,140 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
   }
 }
 
+// The same step for ANY sequence length of at least two tiles and any far offsets — LRA's CLS-token column makes N = 2^k + 1
+// (LRA/listops_training.py:65-72: IMDb N = 4097), where no row block is tile-aligned: per-lane wrapped addresses, the last
+// tile of a sequence partial (its rows >= N request clamped addresses and store nothing), W tiles and the dW tile at any
+// misalignment (the ends of a dW tile that share a 16-byte chunk with a neighbour's rows go out element by element, chunks
+// sticking out of the buffer are staged element by element). Arithmetic and order as above: dV bit-identical to the oracle.
+// Before it, these shapes took the two-kernel path: 26.1 -> 23.5 us per step at IMDb's shape (N = 4097, C = 32, B = 32; 22.3 at
+// N = 4096), 13.0 -> 10.2 at N = 1025, C = 32, B = 64; no change for 8-channel rows (profiles/r04ae_*, r04af_*).
+template <int L, int TGS, int NT>
+__global__ void __launch_bounds__(NT, (NT == 256 && TGS <= 1) ? 5 : 2)
+chord_bwd_fused_edge_k(const float* __restrict__ dZ, const float* __restrict__ W, const float* __restrict__ V,
+                       float* __restrict__ dW, float* __restrict__ dV, const Geom gm, const Offsets offs, const int64_t w_total) {
+  using T = float;
+  using Cfg = BwdWinCfg<T, L, TGS, 1, NT>;
+  constexpr int VEC = Cfg::VEC, TG = Cfg::TG, TR = Cfg::TR, KN = Cfg::KN, NF = Cfg::NF;
+  using V4 = Vec<T, VEC>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  V4* __restrict__ sZ = reinterpret_cast<V4*>(smem);
+  V4* __restrict__ sV = reinterpret_cast<V4*>(smem + Cfg::win_bytes);
+  V4* __restrict__ sWpV = reinterpret_cast<V4*>(smem + 2 * Cfg::win_bytes);
+  V4* __restrict__ sWcV = reinterpret_cast<V4*>(smem + 2 * Cfg::win_bytes + Cfg::w_tile_bytes);
+  const T* __restrict__ sWpF = reinterpret_cast<const T*>(sWpV);
+  const T* __restrict__ sWcF = reinterpret_cast<const T*>(sWcV);
+  T* __restrict__ sOutF = reinterpret_cast<T*>(sWpV);  // the dW tile image: written after the last read of the W tiles
+
+  int b, tile, chunk;
+  decode_block(gm, b, tile, chunk);  // chunks_c == 1
+  const int tid = threadIdx.x, lane = tid & 63, wave64 = tid & ~63;
+  const int g = tid & (TG - 1), pl = tid >> TGS;  // one row per thread: row slot = local row
+  const int q0 = tile * TR, N = gm.N, C = gm.C, q = q0 + pl;
+  const int rows_here = imin_rt(TR, N - q0);
+  const bool row_ok = pl < rows_here;
+  const int qc = row_ok ? q : N - 1;  // a row that exists, for the requests of the lanes past the end
+  const T* __restrict__ Zb = dZ + (int64_t)b * N * C;
+  const T* __restrict__ Wb = W + (int64_t)b * N * L;
+  const T* __restrict__ Vb = V + (int64_t)b * gm.v_bstride;
+
+  // (1) the two W tiles under the backward window: rows [q0 - TR, q0) mod N (contiguous: N >= 2 TR) and [q0, q0 + rows_here)
+  int prev0 = q0 - TR;
+  if (prev0 < 0) prev0 += N;
+  int misP, misC;
+  stage_flat_tile<T, VEC, NT, Cfg::w_passes, true>(W, w_total, ((int64_t)b * N + prev0) * L, TR * L, sWpV, misP);
+  stage_flat_tile<T, VEC, NT, Cfg::w_passes, true>(W, w_total, ((int64_t)b * N + q0) * L, rows_here * L, sWcV, misC);
+  // (2) dZ window: slot wr <-> row (q0 - TR + wr) mod N;  V window: slot wr <-> row (q0 + wr) mod N
+#pragma unroll
+  for (int n = 0; n < Cfg::win_vecs / NT; ++n) {
+    const int i = n * NT + tid;
+    const int wr = i >> TGS, gg = i & (TG - 1);
+    int sz = q0 - TR + wr;
+    if (sz < 0) sz += N;
+    if (sz >= N) sz -= N;
+    int sv = q0 + wr;
+    if (sv >= N) sv -= N;
+    stage16<T, VEC, true>(Zb + (int64_t)sz * C + (int64_t)gg * VEC, sZ + n * NT + wave64, lane);
+    stage16<T, VEC, true>(Vb + (int64_t)sv * C + (int64_t)gg * VEC, sV + n * NT + wave64, lane);
+  }
+  // (3) far links -> registers
+  V4 farZ[NF > 0 ? NF : 1], farV[NF > 0 ? NF : 1];
+  T farW[NF > 0 ? NF : 1];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    int src = qc - offs.v[KN + f];
+    if (src < 0) src += N;
+    farZ[f] = ld<T, VEC>(Zb + (int64_t)src * C + (int64_t)g * VEC);
+    farW[f] = Wb[(int64_t)src * L + (KN + f)];
+    int dst = qc + offs.v[KN + f];
+    if (dst >= N) dst -= N;
+    farV[f] = ld<T, VEC>(Vb + (int64_t)dst * C + (int64_t)g * VEC);
+  }
+  __syncthreads();
+
+  // (4) dV, links ascending
+  {
+    V4 acc;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc.e[i] = T(0);
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+      const int wr = TR + pl - chord_off(k);  // in [0, 2 TR)
+      const T w = wr < TR ? sWpF[misP + wr * L + k] : sWcF[misC + (wr - TR) * L + k];
+      axpy_rn<T, VEC>(acc, w, sZ[(wr << TGS) + g]);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) axpy_rn<T, VEC>(acc, farW[f], farZ[f]);
+    if (row_ok) st<T, VEC>(dV + ((int64_t)b * N + q) * C + (int64_t)g * VEC, acc);
+  }
+  // (5) dW row dots (the tile's dZ rows are the upper half of the dZ window)
+  T dots[L];
+  {
+    using F2 = float __attribute__((ext_vector_type(2)));
+    const V4 dz = sZ[((TR + pl) << TGS) + g];
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+      V4 x;
+      if (k < KN) x = sV[((pl + chord_off(k)) << TGS) + g];
+      else x = farV[k - KN < NF ? k - KN : 0];
+      const F2 pa = F2{dz.e[0], dz.e[1]} * F2{x.e[0], x.e[1]}, pb = F2{dz.e[2], dz.e[3]} * F2{x.e[2], x.e[3]};
+      const F2 ps = pa + pb;
+      dots[k] = row_group_sum<TG>(add_rn(ps.x, ps.y));
+    }
+  }
+  __syncthreads();  // every thread is done with the W tiles: their first image becomes the dW tile
+  const int64_t e_lo = ((int64_t)b * N + q0) * L;
+  const int misO = (int)(((reinterpret_cast<uintptr_t>(dW) / sizeof(T)) + (uint64_t)e_lo) & (VEC - 1));
+  if (g == 0 && row_ok) {
+#pragma unroll
+    for (int k = 0; k < L; ++k) sOutF[misO + pl * L + k] = dots[k];
+  }
+  __syncthreads();
+  // (6) flat store of the dW tile's rows_here * L elements: whole 16-byte chunks inside, element by element at the two ends
+  const int n_el = rows_here * L;
+  const int nvec = (misO + n_el + VEC - 1) / VEC;
+  T* __restrict__ Oal = dW + (e_lo - misO);
+  const V4* __restrict__ sOutV = reinterpret_cast<const V4*>(sOutF);
+#pragma unroll
+  for (int n = 0; n < Cfg::w_passes; ++n) {
+    const int i = n * NT + tid;
+    if (i < nvec) {
+      const int f0 = i * VEC;
+      if (f0 >= misO && f0 + VEC <= misO + n_el) {
+        st<T, VEC>(Oal + (int64_t)i * VEC, sOutV[i]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < VEC; ++u)
+          if (f0 + u >= misO && f0 + u < misO + n_el) Oal[(int64_t)i * VEC + u] = sOutF[f0 + u];
+      }
+    }
+  }
+}
+
+// LDS of the EDGE instance: two windows and two padded tile images (any misalignment)
+template <int L, int TGS, int NT = kFusedThreads>
+struct BwdFusedEdgeCfg {
+  using B = BwdWinCfg<float, L, TGS, 1, NT>;
+  static constexpr int lds_bytes = 2 * B::win_bytes + 2 * B::w_tile_bytes;
+};
+
 }  // namespace psf

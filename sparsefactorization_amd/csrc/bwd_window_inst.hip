@@ -174,6 +174,34 @@ hipError_t launch_bwd_fused(int L, const BwdWinArgs& a, int nt) {
   }
 }
 template hipError_t launch_bwd_fused<PSF_TGS>(int L, const BwdWinArgs& a, int nt);
+
+namespace {
+template <int L, int TGS, int NT>
+hipError_t launch_fused_edge(const BwdWinArgs& a) {
+  using Cfg = BwdFusedEdgeCfg<L, TGS, NT>;
+  auto kern = chord_bwd_fused_edge_k<L, TGS, NT>;
+  static std::atomic<int> done{0};
+  if (hipError_t e = raise_lds_limit(kern, Cfg::lds_bytes, done); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(NT), Cfg::lds_bytes, a.stream, a.dZ, a.WV, a.V2, a.out2, a.out, a.gm, a.offs,
+                     a.w_total);
+  return hipGetLastError();
+}
+}  // namespace
+template <int TGS>
+hipError_t launch_bwd_fused_edge(int L, const BwdWinArgs& a, int nt) {
+  switch (L) {
+#define PSF_CASE(LL) \
+  case LL:           \
+    return nt == 256 ? launch_fused_edge<LL, TGS, 256>(a) : launch_fused_edge<LL, TGS, kFusedThreads>(a);
+    PSF_CASE(4) PSF_CASE(5) PSF_CASE(6) PSF_CASE(7) PSF_CASE(8) PSF_CASE(9) PSF_CASE(10) PSF_CASE(11)
+    PSF_CASE(12) PSF_CASE(13) PSF_CASE(14) PSF_CASE(15) PSF_CASE(16) PSF_CASE(17) PSF_CASE(18)
+    PSF_CASE(19) PSF_CASE(20)
+#undef PSF_CASE
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+template hipError_t launch_bwd_fused_edge<PSF_TGS>(int L, const BwdWinArgs& a, int nt);
 #endif
 
 }  // namespace psf

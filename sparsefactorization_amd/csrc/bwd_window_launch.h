@@ -47,5 +47,8 @@ hipError_t launch_dv_win(int rows, int L, const BwdWinArgs& a);
 // in the 512-thread units
 template <int TGS>
 hipError_t launch_bwd_fused(int L, const BwdWinArgs& a, int nt);  // nt: 512 (tile = 512 >> TGS rows) or 256
+// the same for any sequence length >= two tiles and any far offsets (per-lane wrap, partial last tile, any W / dW alignment)
+template <int TGS>
+hipError_t launch_bwd_fused_edge(int L, const BwdWinArgs& a, int nt);
 
 }  // namespace psf

@@ -267,6 +267,39 @@ hipError_t launch_fused_step(int tgs, int L, const BwdWinArgs& a, int nt) {
   }
 }
 
+hipError_t launch_fused_edge_step(int tgs, int L, const BwdWinArgs& a, int nt) {
+  switch (tgs) {
+    case 0: return launch_bwd_fused_edge<0>(L, a, nt);
+    case 1: return launch_bwd_fused_edge<1>(L, a, nt);
+    case 2: return launch_bwd_fused_edge<2>(L, a, nt);
+    case 3: return launch_bwd_fused_edge<3>(L, a, nt);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// The EDGE instance of the fused step (bwd_fused.h: chord_bwd_fused_edge_k) takes what pick_fused_step turns away for its
+// geometry: any N >= two tiles (N = 2^k + 1 with a CLS token), any far offsets, W / dW at any alignment. Same rows (C = 4 << tgs,
+// tgs <= 3), chord near offsets, 16-byte aligned row operands. Knob bwd_fused = 2 keeps its meaning (the aligned instance or
+// nothing); 1 (default) lets this one in.
+bool pick_fused_edge_step(const Tuning& tn, const void* dZ, const void* V, const void* dV, int64_t N, int32_t L, int64_t C,
+                          int64_t v_bstride, const Offsets& offs, WinPick* pk) {
+  if (tn.bwd_fused != 1 || L < kWinLmin || L > kWinLmax || (C != 4 && C != 8 && C != 16 && C != 32)) return false;
+  const int tgs = C == 4 ? 0 : C == 8 ? 1 : C == 16 ? 2 : 3;
+  const int nt = tn.bwd_fused_nt ? 256 : kDvMidThreads;
+  const int TR = nt >> tgs;
+  if (N < 2 * (int64_t)TR) return false;
+  if (!aligned_to(dZ, 16) || !aligned_to(V, 16) || !aligned_to(dV, 16)) return false;
+  if (v_bstride != 0 && v_bstride != N * C) return false;
+  int KN = 2;
+  for (int t = TR; t > 1; t >>= 1) ++KN;
+  if (KN > L) KN = L;
+  for (int k = 0; k < KN; ++k)
+    if (offs.v[k] != chord_off(k)) return false;
+  pk->tgs = tgs, pk->rows = 1, pk->nt = nt, pk->TR = TR, pk->KN = KN;
+  pk->tiles_full = (int)(N / TR), pk->ragged = (N % TR) != 0, pk->all_edge = true;
+  return true;
+}
+
 // The fused dV + dW step (bwd_fused.h) applies to full tiles of narrow rows: C = 4 << tgs with tgs <= 3, N a multiple of
 // the tile (512 >> tgs rows) and at least two tiles, chord near offsets, everything 16-byte aligned and chunk-clean.
 bool pick_fused_step(const Tuning& tn, const void* dZ, const void* W, const void* V, const void* dW, const void* dV, int64_t B, int64_t N,
@@ -552,6 +585,17 @@ int bwd_impl(const Tuning& tn, const T* dZ, const T* W, const T* V, T* dW, T* dV
         if (int rc = make_geom(tn, B, N, L, C, 4, pk.tgs, pk.TR, false, v_batch_stride, 0, pk.tiles_full, &a.gm)) return rc;
         hipError_t e = launch_fused_step(pk.tgs, L, a, pk.nt);
         if (e != hipSuccess) return fail_hip(e, "chord_bwd_fused");
+        dW = nullptr;
+        dV = nullptr;
+      }
+      if (dW && dV && wfar == nullptr && pick_fused_edge_step(tn, dZ, V, dV, N, L, C, v_batch_stride, offs, &pk)) {
+        BwdWinArgs a{dZ, W, dV, Geom{}, offs, w_total, true, s};
+        a.V2 = V;
+        a.out2 = dW;
+        if (int rc = make_geom(tn, B, N, L, C, 4, pk.tgs, pk.TR, false, v_batch_stride, 0, pk.tiles_full + (pk.ragged ? 1 : 0), &a.gm))
+          return rc;
+        hipError_t e = launch_fused_edge_step(pk.tgs, L, a, pk.nt);
+        if (e != hipSuccess) return fail_hip(e, "chord_bwd_fused_edge");
         dW = nullptr;
         dV = nullptr;
       }

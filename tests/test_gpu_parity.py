@@ -798,3 +798,49 @@ def test_fused_backward_step_kernel(gpu, B, N, L, C, nt):
     finally:
         sfa.set_tuning("bwd_fused", 1)
         sfa.set_tuning("bwd_fused_nt", 1)
+
+
+FUSED_EDGE_SHAPES = [(2, 4097, 13, 32), (2, 1025, 11, 32), (1, 16385, 15, 8), (3, 777, 9, 16), (2, 643, 10, 4), (2, 1024, 12, 32)]
+
+
+@pytest.mark.parametrize("nt", [0, 1])
+@pytest.mark.parametrize("B,N,L,C", FUSED_EDGE_SHAPES)
+def test_fused_backward_step_general_instance(gpu, B, N, L, C, nt):
+    """chord_bwd_fused_edge_k (csrc/bwd_fused.h): the fused step for any sequence length (LRA's CLS-token column makes
+    N = 2^k + 1, LRA/listops_training.py:65-72), for W / dW buffers that start anywhere (views into larger buffers, one
+    float off a 16-byte boundary) and for far offsets that are no multiples of the tile (last case: aligned N, odd far
+    offsets): dV bit for bit against the oracle, dW to the parity bar, and both equal to the two-kernel path's results."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.chord import _launch_bwd
+    W, V, dZ = _mk((B, N, L), 95), _mk((B, N, C), 96), _mk((B, N, C), 97)
+    off = None
+    if N % 64 == 0:  # aligned length: make the far offsets odd so that only the general instance applies
+        KN = 2
+        t = (256 if nt else 512) >> {4: 0, 8: 1, 16: 2, 32: 3}[C]
+        while t > 1:
+            KN, t = KN + 1, t >> 1
+        KN = min(KN, L)
+        off = [0] + [1 << k for k in range(KN - 1)] + [(1 << k) + 37 for k in range(KN - 1, L - 1)]
+    dF, dV = oc.spmul_bwd(dZ, W, V, off)
+    Wbig = torch.zeros(B * N * L + 1, device=gpu)
+    Wbig[1:] = _t(W, gpu).reshape(-1)
+    Wt = Wbig[1:].view(B, N, L)  # 4 bytes off a 16-byte boundary
+    Vt, dZt = _t(V, gpu), _t(dZ, gpu)
+    sfa.set_tuning("bwd_fused_nt", nt)
+    try:
+        got = {}
+        for fused in (1, 0):
+            sfa.set_tuning("bwd_fused", fused)
+            gWbig = torch.full((B * N * L + 3,), float("nan"), device=gpu)
+            gW = gWbig[3:].view(B, N, L)  # 12 bytes off
+            gV = torch.full_like(Vt, float("nan"))
+            _launch_bwd(dZt, Wt, Vt, gW, gV, B, N, L, C, N * C, off)
+            assert torch.isnan(gWbig[:3]).all(), "wrote in front of the dW buffer"
+            assert np.array_equal(gV.cpu().numpy(), dV), fused
+            assert rel_inf(gW.cpu().numpy(), dF) <= TOL, fused
+            got[fused] = (gW.clone(), gV.clone())
+        assert torch.equal(got[1][1], got[0][1])
+    finally:
+        sfa.set_tuning("bwd_fused", 1)
+        sfa.set_tuning("bwd_fused_nt", 1)
+
