@@ -26,6 +26,7 @@ hipError_t launch_R(const ChainLdsPlan& p, const ChainArgs& a, const Offsets& of
   if (p.rows == 1) return launch_one<L, CC, 1, RES, 512>(a, offs, B, p.threads, p.lds_bytes, s);
   if (p.rows == 2 && p.threads <= 512) return launch_one<L, CC, 2, RES, 512>(a, offs, B, p.threads, p.lds_bytes, s);
   if (p.rows == 2) return launch_one<L, CC, 2, RES, 1024>(a, offs, B, p.threads, p.lds_bytes, s);
+  if (p.rows == 3 && p.threads <= 768) return launch_one<L, CC, 3, RES, 768>(a, offs, B, p.threads, p.lds_bytes, s);
   return hipErrorInvalidValue;
 }
 
@@ -54,7 +55,8 @@ bool plan_chain_lds(int64_t N, int64_t C, int32_t L, int32_t M, ChainLdsPlan* p,
   if (N * cc > kChainLdsMaxSlots) cc = 1;
   if (N * cc > kChainLdsMaxSlots) return false;
   const int64_t slots = N * cc;                 // (row, channel group) pairs a workgroup owns
-  const int R = slots <= 256 ? 1 : 2;           // 2 rows per thread: <= 512 threads up to 1024 slots
+  const int R = slots <= 256 ? 1 : (slots <= kChainLdsSlots2 ? 2 : 3);  // 2 rows per thread: <= 512 threads up to 1024 slots
+  if (R == 3 && L > 14) return false;           // 3 rows x 2 W rows of L floats: beyond L = 14 the 768-thread instance spills
   int64_t threads = (slots + R - 1) / R;
   threads = (threads + 63) / 64 * 64;           // whole waves; threads / cc row slots cover ceil(N / R) rows
   if (threads > 1024) return false;

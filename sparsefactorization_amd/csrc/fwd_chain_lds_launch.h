@@ -6,13 +6,16 @@
 namespace psf {
 
 constexpr int kChainLdsLmin = 2, kChainLdsLmax = 20;  // compiled link counts
-// N * CC: 2 rows per thread x 1024 threads (4 rows per thread would need > 128 VGPRs at 1024 threads and spill)
-constexpr int kChainLdsMaxSlots = 2048;
-constexpr int kChainLdsMaxBytes = 2 * kChainLdsMaxSlots * 16;  // two X buffers: 64 KiB, two workgroups per CU
+// N * CC: 2 rows per thread x 1024 threads (4 rows per thread would need > 128 VGPRs at 1024 threads and spill). A few slots
+// beyond 2048 — N = 1025 with two channel groups, N = 2049 with one: LRA's CLS-token column makes N = 2^k + 1 — run 3 rows per
+// thread on <= 768 threads (170 VGPRs) instead of falling to four more workgroups per sequence or to the per-step kernels.
+constexpr int kChainLdsSlots2 = 2048;  // up to here 1 or 2 rows per thread
+constexpr int kChainLdsMaxSlots = 2112;
+constexpr int kChainLdsMaxBytes = 2 * kChainLdsMaxSlots * 16;  // two X buffers: 66 KiB, two workgroups per CU
 
 struct ChainLdsPlan {
   int cc;       // channel groups (of 4 channels) per workgroup: 1 or 2
-  int rows;     // rows per thread: 1 or 2
+  int rows;     // rows per thread: 1, 2 or 3
   int threads;  // workgroup size (multiple of 64, <= 1024)
   int chunks;   // workgroups per sequence
   int lds_bytes;

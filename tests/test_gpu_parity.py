@@ -471,6 +471,7 @@ CHAIN_SHAPES = [  # (B, N, M, L, C, residual)
     (40, 128, 7, 8, 8, True), (3, 2000, 11, 12, 16, False), (2, 1024, 11, 12, 32, True), (2, 2048, 5, 12, 8, True),
     (5, 777, 4, 9, 12, True), (1, 64, 3, 7, 4, False), (2, 1500, 6, 20, 8, True), (2, 300, 9, 3, 24, False),
     (3, 1025, 2, 11, 8, True), (2, 2049, 3, 12, 8, True), (1, 100, 12, 9, 260, True),
+    (2, 1025, 11, 12, 32, False), (2, 2049, 4, 13, 64, True), (2, 1056, 3, 12, 16, True),  # three rows per thread (CLS-token lengths)
 ]
 
 
