@@ -18,8 +18,12 @@ constexpr int kWinTgsMax = 6;               // TG = 1 << TGS <= 64 lanes share a
 // (32 channels = one 128-byte line per row chunk; wider rows are split into channel chunks) at 1024 threads,
 // i.e. 256-row tiles. For C >= 64 that turns all but L-10 links into near links (see fwd_window.h).
 constexpr int kWideTgs = 3, kWideThreads = 1024;
+// ... and 512 threads for rows of exactly 32 channels (8 lanes per row): 128-row tiles with 2 rows per thread, one far link
+// fewer than the 64-row tiles of 256 threads (knob "fwd_wide" = 3; measured in profiles/r04ai_*).
+constexpr int kFwdMidTgs = 3, kFwdMidThreads = 512;
 constexpr bool win_pair_compiled(int tgs, int nt) {
-  return (nt == 256 && tgs >= 0 && tgs <= kWinTgsMax) || (nt == kWideThreads && tgs == kWideTgs);
+  return (nt == 256 && tgs >= 0 && tgs <= kWinTgsMax) || (nt == kWideThreads && tgs == kWideTgs) ||
+         (nt == kFwdMidThreads && tgs == kFwdMidTgs);
 }
 
 // Rows per thread R that are compiled, and the default.

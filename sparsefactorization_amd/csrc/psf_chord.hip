@@ -91,7 +91,7 @@ struct Knob {
 Knob g_knobs[] = {
     {"fwd_variant", &g_fwd_variant, 0, 2}, {"bwd_variant", &g_bwd_variant, 0, 1}, {"xcd_remap", &g_xcd_remap, 0, 1},
     {"fwd_rows", &g_fwd_rows, 0, 8},       {"fwd_split", &g_fwd_split, 0, 2},     {"bwd_rows", &g_bwd_rows, 0, 8},
-    {"fwd_wide", &g_fwd_wide, 0, 2},
+    {"fwd_wide", &g_fwd_wide, 0, 3},
     {"dw_variant", &g_dw_variant, 0, 2},
     {"dv_threads", &g_dv_threads, 0, 2},
     {"bwd_fused", &g_bwd_fused, 0, 2},
@@ -239,6 +239,7 @@ struct WinPick {
 
 hipError_t launch_win(const WinPick& pk, int L, const FwdWinArgs& a) {
   if (pk.nt == kWideThreads) return pk.tgs == kWideTgs ? launch_fwd_win<kWideTgs, kWideThreads>(pk.rows, L, a) : hipErrorInvalidValue;
+  if (pk.nt == kFwdMidThreads) return pk.tgs == kFwdMidTgs ? launch_fwd_win<kFwdMidTgs, kFwdMidThreads>(pk.rows, L, a) : hipErrorInvalidValue;
   PSF_TGS_SWITCH(launch_fwd_win, (pk.rows, L, a))
 }
 
@@ -390,7 +391,7 @@ hipError_t launch_dw(const WinPick& pk, int L, const BwdWinArgs& a) {
 // `chunk_channels`: the kernel may split a row's channels over several workgroups (forward, dV) — then wide rows
 // (C >= 64) use the wide-row configuration: 32-channel chunks, 1024 threads, 256-row tiles.
 bool pick_window(const Tuning& tn, const void* W, int64_t B, int64_t N, int32_t L, int64_t C, const Offsets& offs, bool vec_ok,
-                 WinPick* pick, int rows_pref, bool chunk_channels, int nt_pref = 0) {
+                 WinPick* pick, int rows_pref, bool chunk_channels, int nt_pref = 0, bool forward = false) {
   if (!vec_ok || L < kWinLmin || L > kWinLmax) return false;
   const int64_t CG = C / 4;
   int tgs = ceil_log2(CG) > kWinTgsMax ? kWinTgsMax : ceil_log2(CG);
@@ -401,6 +402,9 @@ bool pick_window(const Tuning& tn, const void* W, int64_t B, int64_t N, int32_t 
   if (chunk_channels && wide == 1 && CG >= 16 && N >= 2 * (int64_t)win_tile_rows(kWideTgs, rows, kWideThreads)) {
     tgs = kWideTgs;  // 32-channel chunks on 1024-thread workgroups
     nt = kWideThreads;
+  } else if (forward && wide == 3 && CG == 8 && N >= 2 * (int64_t)win_tile_rows(kFwdMidTgs, rows, kFwdMidThreads)) {
+    tgs = kFwdMidTgs;  // rows of exactly 32 channels on 512-thread workgroups (forward only)
+    nt = kFwdMidThreads;
   } else if (chunk_channels && wide == 2 && CG >= 16) {
     tgs = kWideTgs;  // 32-channel chunks on 256-thread workgroups
   } else if (nt_pref == kDvMidThreads && tgs <= kDvMidTgsMax && N >= 2 * (int64_t)win_tile_rows(tgs, 1, kDvMidThreads)) {
@@ -493,7 +497,10 @@ int fwd_window_f32(const Tuning& tn, const WinPick& pk, const float* W, const fl
   // 16.1; B = 40 19.9 / 19.0; B = 48 22.8 / 21.8. So: three for narrow rows on launches of >= 1536 tiles, no limit otherwise.
   const int knob = tn.fwd_wg_limit;
   const int64_t tiles_total = B * (int64_t)(pk.tiles_full + (pk.ragged ? 1 : 0));
-  a.wg_per_cu = knob == 0 ? ((pk.tgs <= 1 && pk.nt == 256 && tiles_total >= 1536) ? 3 : 0) : (knob == 1 ? 0 : knob);
+  // Rows of 32 channels on launches of >= 8192 tiles (round 4, profiles/r04ai_fwd_mid_sweep.log, N = 16384, B = 64): 102.9 / 97.4;
+  // at B = 16 (4096 tiles) 22.6 / 22.7, N = 4096, B = 32: 11.2 / 11.6 — so three there too, from 8192 tiles on.
+  const bool three = pk.nt == 256 && ((pk.tgs <= 1 && tiles_total >= 1536) || (pk.tgs == 3 && tiles_total >= 8192));
+  a.wg_per_cu = knob == 0 ? (three ? 3 : 0) : (knob == 1 ? 0 : knob);
   return window_launches(tn, pk, pk.all_edge, B, N, L, C, v_batch_stride, true, &a.gm, &a.edge,
                          [&] { return launch_win(pk, L, a); }, "chord_fwd_win launch");
 }
@@ -523,7 +530,7 @@ int fwd_impl(const Tuning& tn, const T* W, const T* V, const T* res, T* out, int
   const int variant = tn.fwd_variant;
   if constexpr (sizeof(T) == 4) {  // the window kernels are compiled for f32 only (f64 exists for gradcheck)
     WinPick pk;
-    if (variant != 1 && pick_window(tn, W, B, N, L, C, offs, vec_ok, &pk, tn.fwd_rows, true)) {
+    if (variant != 1 && pick_window(tn, W, B, N, L, C, offs, vec_ok, &pk, tn.fwd_rows, true, 0, true)) {
       const bool emit = wfar != nullptr && far_k0 >= 0 && far_k0 < L;
       if (copied) *copied = emit;
       return fwd_window_f32(tn, pk, W, V, res, out, B, N, L, C, v_batch_stride, offs, s, emit ? wfar : nullptr, far_k0);
@@ -1096,7 +1103,7 @@ int psf_describe_fwd(int64_t B, int64_t N, int32_t L, int64_t C, int32_t elem_by
   WinPick pk;
   const Tuning tn = snapshot();
   const int variant = tn.fwd_variant;
-  if (variant != 1 && elem_bytes == 4 && pick_window(tn, nullptr, B, N, L, C, offs, vec_ok, &pk, tn.fwd_rows, true)) {
+  if (variant != 1 && elem_bytes == 4 && pick_window(tn, nullptr, B, N, L, C, offs, vec_ok, &pk, tn.fwd_rows, true, 0, true)) {
     snprintf(buf, cap, "chord_fwd_win_k<f32,L=%d,TG=%d,R=%d,NT=%d> TR=%d near=%d far=%d tiles=%s", (int)L,
              1 << pk.tgs, pk.rows, pk.nt, pk.TR, pk.KN, (int)L - pk.KN,
              pk.all_edge ? "edge" : (pk.ragged ? "full+ragged" : (pk.aligned ? "full, aligned (scalar block addresses)" : "full")));

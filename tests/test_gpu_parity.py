@@ -347,6 +347,29 @@ def test_backward_dw_chunk_kernel_is_the_default_for_wide_rows(gpu):
         sfa.set_tuning("dw_variant", 0)
 
 
+@pytest.mark.parametrize("B,N,L,C", [(2, 16384, 15, 32), (2, 4097, 13, 32), (3, 1024, 11, 32), (2, 300, 9, 32)])
+def test_rows_of_32_channels_on_512_thread_tiles(gpu, B, N, L, C):
+    """fwd_wide = 3: the forward step (with and without residual) on 512-thread workgroups, 128-row tiles, bit for bit; the
+    backward is not affected by the knob."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.chord import _launch_bwd
+    W, V, R, dZ = _mk((B, N, L), 71), _mk((B, N, C), 72), _mk((B, N, C), 73), _mk((B, N, C), 74)
+    sfa.set_tuning("fwd_wide", 3)
+    try:
+        desc = sfa.describe_fwd(B, N, L, C)
+        got = sfa.chord_spmm(_t(W, gpu), _t(V, gpu), _t(R, gpu)).cpu().numpy()
+        got_nores = sfa.chord_spmm(_t(W, gpu), _t(V, gpu)).cpu().numpy()
+        gV = torch.full((B, N, C), float("nan"), device=gpu)
+        _launch_bwd(_t(dZ, gpu), _t(W, gpu), _t(V, gpu), None, gV, B, N, L, C, N * C, None)
+    finally:
+        sfa.set_tuning("fwd_wide", 0)
+    if N >= 512:
+        assert "NT=512" in desc, desc
+    assert np.array_equal(got, _oracle_fwd(W, V, R)), desc
+    assert np.array_equal(got_nores, _oracle_fwd(W, V)), desc
+    assert np.array_equal(gV.cpu().numpy(), oc.spmul_bwd(dZ, W, V)[1])
+
+
 @pytest.mark.parametrize("wide", [1, 2])
 @pytest.mark.parametrize("B,N,L,C", [(2, 2000, 12, 128), (2, 640, 10, 260), (2, 2048, 12, 64)])
 def test_backward_dv_wide_row_configs(gpu, B, N, L, C, wide):
