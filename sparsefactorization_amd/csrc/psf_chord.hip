@@ -822,7 +822,7 @@ const char* psf_last_error(void) { return g_err; }
 
 const char* psf_build_info(void) {
   return "libpsf_chord: gfx950 (CDNA4, wave64) | hipcc " __VERSION__
-         " | fwd: generic<f32,f64> + LDS-window<f32, L=4..20, LDS-DMA staging> + LDS-resident chain<f32, N<=2048>"
+         " | fwd: generic<f32,f64> + LDS-window<f32, L=4..20, LDS-DMA staging> + LDS-resident chain<f32, N<=2112>"
          " | bwd: generic dV/dW<f32,f64> + LDS-window dV/dW<f32> + fused dV+dW step<f32, C<=32>"
          " | producers: fused MLP fwd (split-bf16 MFMA at f32 accuracy, f32 MFMA) + fused MLP bwd (split-bf16 MFMA on dual-use LDS planes, f32 MFMA),"
          " tall-skinny weight gradients (f32 MFMA), token embedding + positional add"
