@@ -192,6 +192,33 @@ def test_mixer_equals_producer_plus_chain_closely(gpu):
     assert rel_inf(got.cpu().numpy(), ref.cpu().numpy()) <= 2e-6
 
 
+@pytest.mark.parametrize("N,C,L,M,h", [(16384, 8, 15, 14, 32), (4096, 32, 13, 12, 32), (128, 8, 8, 7, 32)])
+def test_mixer_at_full_size_treats_batch_elements_independently(gpu, N, C, L, M, h):
+    """Size-independent properties at BASELINE.json's full sequence length (configs[1]: N = 16384, M = 14), where the CPU
+    reference takes minutes: (1) the mixer of a batch equals, bit for bit, the mixer of each of its sequences alone — tiles,
+    XCD mapping, zigzag walk and the batch size must not leak into the arithmetic; (2) so does a batch with its sequences
+    permuted; (3) the residual route equals the non-residual route plus nothing when V0's producer is zero (g = 0):
+    then V_M = sum of the chain applied to 0 = 0 without residual, and with it V_M solves V <- W V, V_0 = 0: also 0."""
+    from sparsefactorization_amd import fused_mixer
+    g, fs = _blocks(32, h, C, L, M, seed=31)
+    g.to(gpu)
+    for f in fs:
+        f.to(gpu)
+    x = torch.randn(5, N, 32, device=gpu, generator=torch.Generator(device=gpu).manual_seed(4))
+    with torch.no_grad():
+        whole = fused_mixer.mixer_forward(x, g, fs, True).clone()
+        for i in (0, 3):
+            alone = fused_mixer.mixer_forward(x[i:i + 1].contiguous(), g, fs, True)
+            assert torch.equal(alone[0], whole[i]), f"sequence {i} alone differs from its place in the batch"
+        perm = torch.tensor([3, 0, 4, 2, 1], device=gpu)
+        assert torch.equal(fused_mixer.mixer_forward(x[perm].contiguous(), g, fs, True), whole[perm])
+        for p in g.parameters():
+            p.zero_()
+        for res in (False, True):
+            out = fused_mixer.mixer_forward(x, g, fs, res)
+            assert float(out.abs().max()) == 0.0
+
+
 def test_mixer_step_is_bit_stable_under_repetition(gpu):
     """The first build of the step kernel came out wrong in a few lanes of a few launches in a hundred at these shapes
     (profiles/r04b_mixer_lds_wait.md): 200 launches each must be bit-identical, and equal to the W-through-memory route."""
