@@ -604,10 +604,12 @@ def test_full_size_properties(gpu):
     assert np.array_equal(out[sel].cpu().numpy(), want)
 
 
-def test_full_size_shift_equivariance_and_identity(gpu):
-    """The pattern is circulant: rolling W and V along N rolls the output. W = e_0 (self link only) is identity."""
+@pytest.mark.parametrize("B,N,L,C", [(8, 16384, 15, 8), (4, 16385, 15, 8), (4, 4097, 13, 32), (4, 16384, 15, 32)])
+def test_full_size_shift_equivariance_and_identity(gpu, B, N, L, C):
+    """The pattern is circulant: rolling W and V along N rolls the output. W = e_0 (self link only) is identity. At
+    BASELINE.json's sequence length and at the 2^k + 1 lengths a CLS-token column makes (aligned and general instances of the
+    forward and backward kernels)."""
     import sparsefactorization_amd as sfa
-    B, N, L, C = 8, 16384, 15, 8
     g = torch.Generator(device=gpu).manual_seed(5)
     W = torch.randn(B, N, L, device=gpu, generator=g)
     V = torch.randn(B, N, C, device=gpu, generator=g)
@@ -625,6 +627,15 @@ def test_full_size_shift_equivariance_and_identity(gpu):
     lhs = (dZ.double() * out.double()).sum()
     rhs = (Vr.grad.double() * V.double()).sum()
     assert abs(float(lhs - rhs)) <= 1e-6 * abs(float(lhs))
+    # both gradients of one step (the fused backward kernels): <dW, W> == <dZ, W.V> as well (the step is bilinear), and the
+    # gradients roll with their operands
+    Wr, Vr = W.clone().requires_grad_(True), V.clone().requires_grad_(True)
+    sfa.chord_spmm(Wr, Vr).backward(dZ)
+    assert abs(float((Wr.grad.double() * W.double()).sum() - lhs)) <= 1e-5 * abs(float(lhs))
+    Ws, Vs = torch.roll(W, s, 1).requires_grad_(True), torch.roll(V, s, 1).requires_grad_(True)
+    sfa.chord_spmm(Ws, Vs).backward(torch.roll(dZ, s, 1))
+    assert torch.equal(torch.roll(Vr.grad, s, 1), Vs.grad)
+    assert float((torch.roll(Wr.grad, s, 1) - Ws.grad).abs().max() / Wr.grad.abs().max()) <= TOL
 
 
 def test_errors(gpu):
