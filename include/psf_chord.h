@@ -427,9 +427,11 @@ int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float
  *                      CLS token —, any far offsets, W / dW at any alignment); 2 = the aligned instance or the two kernels;
  *                      0 = always the two kernels
  *   key "bwd_fused_nt": threads of the fused kernel: 1 = 256 (default; tile = 256 / (C / 4) rows), 0 = 512
- *   key "fwd_wide"   : rows of >= 64 channels: 0 = one workgroup spans the whole row (default, fastest measured);
- *                      1 = 32-channel chunks on 1024-thread workgroups (256-row tiles); 2 = 32-channel chunks
- *                      on 256-thread workgroups; 3 = rows of exactly 32 channels on 512-thread workgroups (128-row
+ *   key "fwd_wide"   : rows of >= 64 channels: 0 = automatic (default): the forward step takes 32-channel chunks on
+ *                      1024-thread workgroups (256-row tiles) for rows of 64..256 channels and N <= 4096, one workgroup per
+ *                      whole row otherwise; the backward kernels one workgroup per whole row; 1 = the 1024-thread chunks
+ *                      wherever they fit (forward and dV); 2 = 32-channel chunks on 256-thread workgroups; 4 = one workgroup
+ *                      per whole row always; 3 = rows of exactly 32 channels on 512-thread workgroups (128-row
  *                      tiles: one far link fewer; equal to the default at N = 16384, B = 16 and N = 4096, B = 32, 3-8 %
  *                      faster at B = 64: profiles/r04ai_fwd_mid_sweep.log)
  *   key "chain_fused": 1 = psf_chord_chain_fwd_f32 runs short sequences (N <= 2112, L <= 20, C % 4 == 0, rows of at most

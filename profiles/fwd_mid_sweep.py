@@ -12,8 +12,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sparsefactorization_amd as sfa  # noqa: E402
 
 dev = torch.device("cuda:0")
-for tag, B, N, M, C, res in (("genome-like", 16, 16384, 14, 32, 0), ("IMDb-like", 32, 4096, 12, 32, 0), ("IMDb N=4097", 32, 4097, 12, 32, 0),
-                             ("genome B=64", 64, 16384, 14, 32, 1)):
+SHAPES = (("genome-like", 16, 16384, 14, 32, 0), ("IMDb-like", 32, 4096, 12, 32, 0), ("IMDb N=4097", 32, 4097, 12, 32, 0),
+          ("genome B=64", 64, 16384, 14, 32, 1))
+WIDES = (0, 3)
+if len(sys.argv) > 1 and sys.argv[1] == "wide-rows":  # rows of >= 64 channels: whole row per workgroup against 32-channel chunks
+    SHAPES = (("ListOps ref", 32, 2000, 11, 128, 0), ("ListOps 2048x64", 32, 2048, 11, 64, 0), ("attention map", 8, 1024, 11, 1024, 0))
+    WIDES = (0, 1, 2)
+for tag, B, N, M, C, res in SHAPES:
     g = torch.Generator(device=dev).manual_seed(0)
     Ws = [0.1 * torch.randn(B, N, M + 1, device=dev, generator=g) for _ in range(M)]
     V0 = torch.randn(B, N, C, device=dev, generator=g)
@@ -30,7 +35,7 @@ for tag, B, N, M, C, res in (("genome-like", 16, 16384, 14, 32, 0), ("IMDb-like"
         return e0.elapsed_time(e1) / chains / M * 1e3, out
 
     reading(30)
-    settings = list(itertools.product((0, 3), (1, 2), (0, 2, 3)))
+    settings = list(itertools.product(WIDES, (1, 2), (0, 3)))
     times, desc, ref = {s: [] for s in settings}, {}, None
     for rnd in range(7):
         for s in (settings if rnd % 2 == 0 else settings[::-1]):

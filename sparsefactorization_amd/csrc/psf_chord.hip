@@ -91,7 +91,7 @@ struct Knob {
 Knob g_knobs[] = {
     {"fwd_variant", &g_fwd_variant, 0, 2}, {"bwd_variant", &g_bwd_variant, 0, 1}, {"xcd_remap", &g_xcd_remap, 0, 1},
     {"fwd_rows", &g_fwd_rows, 0, 8},       {"fwd_split", &g_fwd_split, 0, 2},     {"bwd_rows", &g_bwd_rows, 0, 8},
-    {"fwd_wide", &g_fwd_wide, 0, 3},
+    {"fwd_wide", &g_fwd_wide, 0, 4},
     {"dw_variant", &g_dw_variant, 0, 2},
     {"dv_threads", &g_dv_threads, 0, 2},
     {"bwd_fused", &g_bwd_fused, 0, 2},
@@ -399,7 +399,13 @@ bool pick_window(const Tuning& tn, const void* W, int64_t B, int64_t N, int32_t 
   int rows = rows_pref;
   if (rows <= 0 || !win_rows_compiled(rows)) rows = win_default_rows(tgs);
   const int wide = tn.fwd_wide;
-  if (chunk_channels && wide == 1 && CG >= 16 && N >= 2 * (int64_t)win_tile_rows(kWideTgs, rows, kWideThreads)) {
+  // Forward, rows of 64..256 channels, sequences up to 4096: 32-channel chunks on 1024-thread workgroups (256-row tiles: two
+  // far links at L = 12 instead of five to seven). With the scalar block addresses of round 4 they beat the whole-row tiles that
+  // rounds 1-3 measured faster: N = 2048, B = 32: C = 64 10.7 -> 9.0 us per step, C = 96 16.7 -> 14.3, C = 128 19.5 -> 18.3,
+  // C = 192 29.9 -> 25.7, C = 256 36.1 -> 33.9; N = 4096: +2..5 %; C = 512: equal; N = 16384, C = 64, B = 8: 23.7 -> 25.7 (slower)
+  // (profiles/r04ak_fwd_wide_rule_sweep.log). The backward kernels keep their configuration.
+  const bool auto_wide = forward && wide == 0 && CG >= 16 && CG <= 64 && N <= 4096;
+  if (chunk_channels && (wide == 1 || auto_wide) && CG >= 16 && N >= 2 * (int64_t)win_tile_rows(kWideTgs, rows, kWideThreads)) {
     tgs = kWideTgs;  // 32-channel chunks on 1024-thread workgroups
     nt = kWideThreads;
   } else if (forward && wide == 3 && CG == 8 && N >= 2 * (int64_t)win_tile_rows(kFwdMidTgs, rows, kFwdMidThreads)) {

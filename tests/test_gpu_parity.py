@@ -102,11 +102,12 @@ def test_forward_split_and_edge_kernels_agree_on_all_shapes(gpu, split):
         sfa.set_tuning("fwd_split", 1)
 
 
-@pytest.mark.parametrize("wide", [0, 1, 2])
+@pytest.mark.parametrize("wide", [0, 1, 2, 4])
 @pytest.mark.parametrize("B,N,L,C", [(2, 2000, 12, 128), (1, 1024, 12, 1024), (3, 600, 10, 64), (2, 4097, 13, 260),
                                      (2, 512, 9, 64), (2, 511, 9, 64), (1, 1536, 20, 96)])
 def test_forward_wide_rows(gpu, B, N, L, C, wide):
-    """Rows of >= 64 channels: channel-chunked 1024-thread tiles (fwd_wide=1) vs one workgroup per whole row."""
+    """Rows of >= 64 channels: channel-chunked 1024-thread tiles (fwd_wide = 1; the automatic choice, 0, for 64..256 channels
+    and N <= 4096), chunks on 256 threads (2), one workgroup per whole row (4)."""
     import sparsefactorization_amd as sfa
     W, V, R = _mk((B, N, L), 51), _mk((B, N, C), 52), _mk((B, N, C), 53)
     sfa.set_tuning("fwd_wide", wide)
@@ -118,6 +119,8 @@ def test_forward_wide_rows(gpu, B, N, L, C, wide):
         sfa.set_tuning("fwd_wide", 0)
     if wide == 1 and N >= 512:
         assert "NT=1024" in desc, desc
+    if wide == 4:
+        assert "NT=256" in desc and "TG=8," not in desc, desc
     assert np.array_equal(got, _oracle_fwd(W, V, R)), desc
     assert np.array_equal(got_nores, _oracle_fwd(W, V)), desc
 
