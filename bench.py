@@ -488,13 +488,17 @@ def run_rank(args) -> int:
         if shapes is not None:
             line["shapes"] = shapes
         if world == 1 and not args.no_cpu_baseline:
+            # the GPU side of cfg1 first: its 200 chains are launch-bound, and the CPU legs leave up to 256 OpenMP threads
+            # spinning beside the launching thread (one run read 18.7 M tokens/s behind them where it reads 220-250 M alone)
+            try:
+                gpu1, gpu1_err = gpu_cfg1(device), None
+            except Exception as exc:
+                gpu1, gpu1_err = None, repr(exc)
             line["cpu_baseline"] = cpu_baseline()
             cfg1 = cpu_baseline_cfg1()
-            try:
-                cfg1["gpu_value"] = gpu_cfg1(device)
-            except Exception as exc:
-                cfg1["gpu_value"] = None
-                cfg1["gpu_error"] = repr(exc)
+            cfg1["gpu_value"] = gpu1
+            if gpu1_err is not None:
+                cfg1["gpu_error"] = gpu1_err
             line["cpu_baseline_cfg1"] = cfg1
         print(json.dumps(line), flush=True)
 
