@@ -434,9 +434,11 @@ int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float
  *                      per whole row always; 3 = rows of exactly 32 channels on 512-thread workgroups (128-row
  *                      tiles: one far link fewer; equal to the default at N = 16384, B = 16 and N = 4096, B = 32, 3-8 %
  *                      faster at B = 64: profiles/r04ai_fwd_mid_sweep.log)
- *   key "chain_fused": 1 = psf_chord_chain_fwd_f32 runs short sequences (N <= 2112, L <= 20, C % 4 == 0, rows of at most
- *                      64 channels: at most 8 workgroups share a sequence) as ONE launch with the sequence resident in
- *                      LDS (default); 0 = always M per-step launches; 2 = the single launch wherever it fits
+ *   key "chain_fused": 1 (default) = psf_chord_chain_fwd_f32 runs short sequences (N <= 2112, L <= 20, C % 4 == 0) as ONE
+ *                      launch with the sequence resident in LDS: always when at most two step results are kept (inference
+ *                      with alternating buffers), and when every step is kept (training) for sequences of at most 33792
+ *                      elements shared by at most 8 workgroups; 0 = always M per-step launches; 2 = the single launch
+ *                      wherever it fits
  *   key "fwd_wg_limit": LDS-window forward kernel, workgroups per CU: 0 = auto (3 for rows of <= 8 channels on
  *                      launches of >= 4096 tiles, else unlimited), 1 = unlimited, 2..4 = that many
  *   key "chain_zigzag": per-step launches of psf_chord_chain_fwd_*: 1 = every XCD walks its tile range forwards on

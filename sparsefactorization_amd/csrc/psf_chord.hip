@@ -698,9 +698,21 @@ int chain_impl(Tuning tn, const T* const* W_steps, const T* V0, T* const* out_st
     // L2 -> CU `chunks` times and every output row is stored in `chunks` pieces. Past ~8 the per-step kernels win
     // (profiles/r03n_chain_train_sweep.log, us per chain one launch / per step: ListOps N = 2000, C = 128, 32 chunks:
     // 361 / 223; N = 2048, C = 64, 16 chunks: 184 / 119; Pathfinder C = 32, 4 chunks: 72 / 78). chain_fused = 2 forces it.
+    // Round 4 (the kernel built without SLP packing, profiles/r04al_chain_fused*.log, us per step, per-step / one launch):
+    // when only the last result is kept (inference: two alternating buffers) the one launch wins wherever it fits, wide rows
+    // included — N = 2000, C = 128: 18.6 / 15.1; N = 1024, C = 1024: 20.1 / 10.4; N = 2048, C = 64: 9.0 / 8.4 — and when every
+    // step is kept (training) it loses from 65536 elements per sequence on — N = 2048, C = 32: 6.9 / 10.3; C = 64: 10.2 / 17.2 —
+    // and wins below — N = 1024, C = 32: 7.1 / 5.6; N = 2048, C = 8: 6.9 / 4.3.
     const int cf = tn.chain_fused;
+    int kept = 0;  // step results that reach memory
+    for (int m = 0; m < M; ++m) {
+      bool later = false;
+      for (int q = m + 1; q < M; ++q) later = later || out_steps[q] == out_steps[m];
+      kept += later ? 0 : 1;
+    }
+    const bool few_kept = kept <= 2;
     bool ok = cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, tn.chain_cc) &&
-              (cf == 2 || plan.chunks <= 8) &&
+              (cf == 2 || few_kept || (plan.chunks <= 8 && N * C <= 33792)) &&
               aligned_to(V0, 16) && B * (int64_t)plan.chunks <= 0x7fffffff;
     for (int m = 0; ok && m < M; ++m) ok = aligned_to(W_steps[m], 4) && aligned_to(out_steps[m], 16);
     if (ok) {
@@ -1125,8 +1137,8 @@ int psf_describe_chain_fwd(int64_t B, int64_t N, int32_t L, int64_t C, int32_t M
   ChainLdsPlan plan;
   const Tuning tn = snapshot();
   const int cf = tn.chain_fused;
-  if (cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, tn.chain_cc) &&
-      (cf == 2 || plan.chunks <= 8)) {
+  // (as an inference chain is run: only the last result kept)
+  if (cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, tn.chain_cc)) {
     snprintf(buf, cap, "chord_chain_lds_k<f32,L=%d,CC=%d,R=%d> one launch for all %d steps, %d threads, %d workgroup(s) per sequence",
              (int)L, plan.cc, plan.rows, (int)M, plan.threads, plan.chunks);
     return PSF_OK;
