@@ -589,7 +589,10 @@ int bwd_impl(const Tuning& tn, const T* dZ, const T* W, const T* V, T* dW, T* dV
         BwdWinArgs a{dZ, W, dV, Geom{}, offs, w_total, false, s};
         a.V2 = V;
         a.out2 = dW;
-        a.wg_per_cu = tn.bwd_fused_wg_limit;
+        // Workgroups per CU, re-measured on the round-4 kernel with rotating operands (profiles/r04am_bwd_fused_wg_sweep.log, us per
+        // step, what fits / three): 5120 tiles (N = 16384, C = 8, B = 40) 42.3 / 40.9; 8192 tiles (C = 32, B = 16) 51.0 / 49.6; 4096
+        // tiles (N = 4096, C = 16, B = 64) 26.6 / 25.4; 2048 tiles 12.6 / 13.5 and 14.7 / 15.0: three from 4096 tiles on.
+        a.wg_per_cu = tn.bwd_fused_wg_limit ? tn.bwd_fused_wg_limit : (B * (int64_t)pk.tiles_full >= 4096 ? 3 : 0);
         a.ablate = tn.bwd_ablate;
         if (wfar != nullptr && far_k0 >= 0 && far_k0 <= pk.KN && pk.KN < L) {
           a.wfar = wfar;

@@ -102,7 +102,7 @@ def _block_sizes(E: int, g: nn.Module, fs: Sequence[nn.Module]):
 def _route_ok(N: int, E: int, M: int, C: int, L: int, h) -> bool:
     if route != "auto":
         return route == "always"
-    if N >= 8192 and C <= 16 and max(h) <= 32:
+    if N >= 8192 and C <= 32 and max(h) <= 32:  # (32-channel rows since the step kernel's diet: genome shape 488 -> 451 us)
         return True
     # short sequences: ONE launch with V resident in LDS (csrc/mixer_lds.h) against producer + chain
     # (profiles/r04n_mixer_bench_short.log: cfg1 115 -> 89 us per forward, N = 512: 134 -> 106)
