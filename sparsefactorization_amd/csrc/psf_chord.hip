@@ -505,7 +505,10 @@ int fwd_window_f32(const Tuning& tn, const WinPick& pk, const float* W, const fl
   const int64_t tiles_total = B * (int64_t)(pk.tiles_full + (pk.ragged ? 1 : 0));
   // Rows of 32 channels on launches of >= 8192 tiles (round 4, profiles/r04ai_fwd_mid_sweep.log, N = 16384, B = 64): 102.9 / 97.4;
   // at B = 16 (4096 tiles) 22.6 / 22.7, N = 4096, B = 32: 11.2 / 11.6 — so three there too, from 8192 tiles on.
-  const bool three = pk.nt == 256 && ((pk.tgs <= 1 && tiles_total >= 1536) || (pk.tgs == 3 && tiles_total >= 8192));
+  // Rows of 16 channels (same sweep script, us per step, what fits / three): 8192 tiles (N = 16384, B = 64) 45.9 / 44.3; 2048
+  // tiles (B = 16) 13.1 / 12.8; 1024 tiles (N = 4096, B = 32) 7.1 / 7.8: three from 2048 tiles on.
+  const bool three = pk.nt == 256 && ((pk.tgs <= 1 && tiles_total >= 1536) || (pk.tgs == 2 && tiles_total >= 2048) ||
+                                      (pk.tgs == 3 && tiles_total >= 8192));
   a.wg_per_cu = knob == 0 ? (three ? 3 : 0) : (knob == 1 ? 0 : knob);
   return window_launches(tn, pk, pk.all_edge, B, N, L, C, v_batch_stride, true, &a.gm, &a.edge,
                          [&] { return launch_win(pk, L, a); }, "chord_fwd_win launch");
