@@ -715,9 +715,52 @@ def shapes_leg(device):
             out[name] = entry
             del Ws, V0
             torch.cuda.empty_cache()
+        out["backward_step_vs_stream"] = backward_vs_stream(device, timed)
     except Exception as exc:
         out["error"] = repr(exc)
     return out
+
+
+def backward_vs_stream(device, timed):
+    """The fused backward step of the Temporal-Order training shape (N = 16384, L = 15, C = 8, B = 40) with its operands rotating
+    through ten sets, as a training step sees them (W_m, V_m and the outputs are new every step; dZ is the previous step's
+    output), beside the library's gather-free streaming kernel with the same byte mix on the same operands
+    (psf_stream_mix_bwd_f32: reads W : V : dZ = 2 : 1 : 1, writes dW : dV = 2 : 1). DESIGN.md 4.3."""
+    import torch
+    from sparsefactorization_amd import _lib
+    from sparsefactorization_amd.chord import _launch_bwd
+    B, N, L, C, sets = 40, 16384, 15, 8, 10
+    g = torch.Generator(device=device).manual_seed(11)
+    Ws = [0.1 * torch.randn(B, N, L, device=device, generator=g) for _ in range(sets)]
+    Vs = [torch.randn(B, N, C, device=device, generator=g) for _ in range(sets)]
+    dZ = torch.randn(B, N, C, device=device, generator=g)
+    dWs = [torch.empty_like(Ws[0]) for _ in range(sets)]
+    dVs = [torch.empty_like(Vs[0]) for _ in range(sets)]
+    nv = B * N * C // 4
+    sW = [torch.empty(8 * nv, device=device).fill_(0.5) for _ in range(sets)]  # the stream kernel's W-like operands: 2 vectors per V vector
+    sdW = [torch.empty(8 * nv, device=device) for _ in range(sets)]
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    it = [0]
+
+    def step():
+        s = it[0] % sets
+        it[0] += 1
+        _launch_bwd(dZ, Ws[s], Vs[s], dWs[s], dVs[s], B, N, L, C, N * C, None)
+
+    def stream_step():
+        s = it[0] % sets
+        it[0] += 1
+        _lib.check(lib.psf_stream_mix_bwd_f32(sW[s].data_ptr(), Vs[s].data_ptr(), dZ.data_ptr(), sdW[s].data_ptr(), dVs[s].data_ptr(),
+                                              nv, stream), "psf_stream_mix_bwd_f32")
+
+    t_step, t_stream = timed(step, 100), timed(stream_step, 100)
+    step_bytes, stream_bytes = 4 * B * N * (2 * L + 3 * C), 112 * nv
+    return {"shape": {"B": B, "N": N, "L": L, "C": C}, "operands": f"rotating through {sets} sets, dZ fixed",
+            "step_us": t_step, "step_bytes": step_bytes, "step_GBps": step_bytes / t_step / 1e3,
+            "step_frac_of_hbm_peak": step_bytes / t_step / 1e3 / HBM_PEAK_GBS,
+            "stream_us": t_stream, "stream_bytes": stream_bytes, "stream_GBps": stream_bytes / t_stream / 1e3,
+            "step_frac_of_stream": (step_bytes / t_step) / (stream_bytes / t_stream)}
 
 
 def main() -> int:
