@@ -467,8 +467,9 @@ int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float
  *                      layers' GEMM epilogue when every MLP has 97..128 hidden rows (default), 0 = always the separate kernel
  *   key "mixer_lds"  : psf_mixer_fwd_*: 1 = short sequences take the single-launch LDS-resident mixer (default), 0 = per-step kernels
  *   key "mixer_wg_limit": psf_mixer_fwd_f32's step kernel, workgroups per CU: 0 = as many as fit (default: three), n = at most n
- *   key "mixer_ablate": TIMING EXPERIMENTS ONLY (non-zero gives wrong results): bit 0 no MLP arithmetic, bit 1 no multiply-add
- *                      chain, bit 2 no far rows, bit 3 no data rows in psf_mixer_fwd_f32's step kernel (profiles/mixer_bench.py)
+ *   key "mixer_ablate": TIMING EXPERIMENTS ONLY, and only in a library built with -DPSF_MIXER_ABLATE_LAB (ignored otherwise):
+ *                      bit 0 no MLP arithmetic, bit 1 no multiply-add chain, bit 2 no far rows, bit 3 no data rows in
+ *                      psf_mixer_fwd_f32's step kernel (profiles/mixer_bench.py)
  *   key "bwd_ablate" : TIMING EXPERIMENTS ONLY, and only in a library built with -DPSF_BWD_ABLATE_LAB (ignored otherwise): parts
  *                      of the fused backward step left out (csrc/bwd_fused.h, ABL; profiles/bwd_ablate_bench.py)
  *   key "xcd_remap"  : 1 = keep a batch element's tiles on one XCD group (default), 0 = linear

@@ -47,6 +47,11 @@ def csrc_hash() -> str:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
+    # the effective flag list of every unit (a diagnostic build with PSF_HIPCC_EXTRA / PSF_MLP_STEP_EXTRA, or one made with
+    # other per-unit flags, must not carry the product hash: _lib.load's staleness check and bench.py's PMC match use it)
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    for obj, _src, extra, _lint in _unit_table():
+        h.update((os.path.basename(obj) + " " + " ".join(extra)).encode())
     return h.hexdigest()
 
 
@@ -58,8 +63,17 @@ def hipcc() -> str:
 
 
 def _units():
-    """(object path, source, extra flags) for every translation unit."""
-    units = [(os.path.join(OBJ_DIR, "psf_chord.o"), os.path.join(CSRC, "psf_chord.hip"), [f'-DPSF_CSRC_HASH="{csrc_hash()}"']),
+    """(object path, source, extra flags, lint) for every translation unit; psf_chord.o carries the source hash."""
+    table = _unit_table()
+    define = f'-DPSF_CSRC_HASH="{csrc_hash()}"'
+    return [(o, s, [*e, define] if os.path.basename(o) == "psf_chord.o" else e, l) for o, s, e, l in table]
+
+
+def _unit_table():
+    """The units without the hash define (csrc_hash() folds their flags in). `lint`: the unit's gfx950 assembly is kept and
+    checked by isa_lint.py — every unit with a hand-placed s_waitcnt, and every one that mixes MFMA phases with LDS-fed
+    packed arithmetic."""
+    units = [(os.path.join(OBJ_DIR, "psf_chord.o"), os.path.join(CSRC, "psf_chord.hip"), []),
              (os.path.join(OBJ_DIR, "linear_wgrad.o"), os.path.join(CSRC, "linear_wgrad.hip"), []),
              # -fno-slp-vectorize: the LDS-resident chain's multiply-add loop is faster on scalar f32 instructions than on the
              # v_pk_* pairs hipcc builds from it (Pathfinder chain 41.4 -> 33.9 us, profiles/r04p_lib_ab_noslp.log; the
@@ -97,7 +111,12 @@ def _units():
     wide = ["-DPSF_TGS=3", "-DPSF_NT=1024"]
     units.append((os.path.join(OBJ_DIR, "fwd_window_wide.o"), os.path.join(CSRC, "fwd_window_inst.hip"), wide))
     units.append((os.path.join(OBJ_DIR, "bwd_window_wide.o"), os.path.join(CSRC, "bwd_window_inst.hip"), wide))
-    return units
+    return [(o, s, e, os.path.basename(o).startswith(LINT_UNITS)) for o, s, e in units]
+
+
+# hand-placed waits: fwd_window.h (counted vmcnt before the barrier), x3_gemm.h in mlp_wide (counted vmcnt per chunk),
+# fwd_mlp_step.h / mixer_lds.h (full LDS wait in front of packed arithmetic beside MFMA phases)
+LINT_UNITS = ("fwd_window", "fwd_mlp_step", "mixer_lds", "mlp_wide", "mlp_fwd", "mlp_bwd")  # (+ the other MFMA units: R0, R2, R3)
 
 
 def built_hash(path: str = LIB_PATH):
@@ -118,13 +137,32 @@ def needs_build() -> bool:
 
 
 def _compile(unit, cc, verbose):
-    obj, src, extra = unit
+    obj, src, extra, lint = unit
+    if lint:  # keep the unit's assembly (in a directory of its own: the temporaries are named after the source file)
+        tmp = obj[:-2] + ".tmp.d"
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        real_obj, obj = obj, os.path.join(tmp, os.path.basename(obj))
+        extra = [*extra, "-save-temps=obj"]
     cmd = [cc, *HIPCC_FLAGS, *extra, "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError(f"hipcc failed on {os.path.basename(src)} {extra} ({proc.returncode}):\n{proc.stderr[-4000:]}")
+    if lint:
+        from . import isa_lint
+        asm = [os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith(f"{ARCH}.s")]
+        if len(asm) != 1:
+            raise RuntimeError(f"isa_lint: expected one {ARCH} assembly file for {os.path.basename(real_obj)}, found {asm}")
+        errs, notes, nfun = isa_lint.lint_file(asm[0])
+        if verbose:
+            print(f"isa_lint {os.path.basename(real_obj)}: {nfun} functions, {len(errs)} errors, {len(notes)} notes", file=sys.stderr)
+        if errs:
+            raise RuntimeError(f"isa_lint rejects {os.path.basename(real_obj)} (kept: {asm[0]}):\n" + "\n".join(errs[:20]))
+        os.replace(obj, real_obj)
+        shutil.rmtree(tmp, ignore_errors=True)
+        obj = real_obj
     return obj
 
 

@@ -87,7 +87,8 @@ __device__ __forceinline__ void data_row8(const MixerIn& in, const float* sAff, 
         v[i] = __fadd_rn(fmaf(x2, w.z, fmaf(x1, w.y, __fmul_rn(x0, w.x))), w.w);  // the products summed, then the bias
       }
   } else {  // table[token]
-    const int64_t tok = reinterpret_cast<const int64_t*>(in.src)[(int64_t)b * N + row];
+    int64_t tok = reinterpret_cast<const int64_t*>(in.src)[(int64_t)b * N + row];
+    tok = tok < 0 ? 0 : (tok >= in.K ? in.K - 1 : tok);  // never read outside the table (as psf_embed_tokens_f32 clamps)
     const float* __restrict__ tr = in.weight + tok * E;
     if (e0 < E) {
       const float4 lo = *reinterpret_cast<const float4*>(tr + e0);
@@ -188,9 +189,15 @@ template <int L, int TGS, bool RES, bool EDGE, int KIND>
 __global__ void __launch_bounds__(256, 3)
 chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __restrict__ res,
                 float* __restrict__ out, const unsigned char* __restrict__ images, const int nu, const int E, const Geom gm,
-                const Offsets offs, const int ablate) {
+                const Offsets offs, const int ablate_arg) {
   using namespace psf_x3;
   using Cfg = MlpStepCfg<L, TGS>;
+#ifdef PSF_MIXER_ABLATE_LAB  // timing experiments (tuning key "mixer_ablate"): compiled out of the product, where the key is ignored
+  const int ablate = ablate_arg;
+#else
+  constexpr int ablate = 0;
+  (void)ablate_arg;
+#endif
   constexpr int NT = Cfg::NT, R = Cfg::R, TG = Cfg::TG, RS = Cfg::RS, TR = Cfg::TR, KN = Cfg::KN, NF = Cfg::NF;
   constexpr int WS = Cfg::WS, TT = Cfg::TT, G = Cfg::G, TPW = Cfg::TPW;
   using V4 = Vec<float, 4>;
@@ -346,12 +353,17 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
       for (int og = 1; og < G; ++og) {
         if (og * per >= nu) break;  // that group had no units (wave-uniform)
         const float* src = sPart + (((og - 1) * TT + wv % TT) * 32 + c) * WS;
+        using F4 = float __attribute__((ext_vector_type(4)));
+        F4 v[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-          if (8 * q + 4 * half < L) {
-            const float4 v = *reinterpret_cast<const float4*>(src + 8 * q + 4 * half);
-            acc2[0][4 * q] += v.x, acc2[0][4 * q + 1] += v.y, acc2[0][4 * q + 2] += v.z, acc2[0][4 * q + 3] += v.w;
-          }
+          v[q] = 8 * q + 4 * half < L ? *reinterpret_cast<const F4*>(src + 8 * q + 4 * half) : F4{0.f, 0.f, 0.f, 0.f};
+        lds_wait_all();  // (the same rule: the partial sums are added behind a full wait)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          behind_wait(v[q]);
+          acc2[0][4 * q] += v[q].x, acc2[0][4 * q + 1] += v[q].y, acc2[0][4 * q + 2] += v[q].z, acc2[0][4 * q + 3] += v[q].w;
+        }
       }
     }
     if (grp == 0) {  // (G > 1 means one token tile per wave)
@@ -398,7 +410,11 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
     for (int k = 0; k < KN; ++k) xs[k] = sWin[((pl + chord_off(k)) << TGS) + g];
 #pragma unroll
     for (int k = 0; k < L; ++k) wk[k] = wrow[k];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds_wait_all();  // psf_common.h, "LDS results in kernels that also issue MFMAs": the consumers below depend on this wait
+#pragma unroll
+    for (int k = 0; k < KN; ++k) behind_wait(xs[k]);
+#pragma unroll
+    for (int k = 0; k < L; ++k) behind_wait(wk[k]);
     __builtin_amdgcn_sched_barrier(0);
     if (ablate & 2) {  // timing only: operands consumed, no multiply-add chain
 #pragma unroll

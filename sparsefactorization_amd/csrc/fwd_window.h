@@ -247,7 +247,7 @@ __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* _
       PSF_GLOBAL char* ob = sbase(reinterpret_cast<char*>(out + ((int64_t)b * N + p0) * C));
       stg<T, VEC>(ob + lane_off((uint32_t)pl * ((uint32_t)C * (uint32_t)sizeof(T)) + (uint32_t)cg * 16u), acc);
     } else {
-      if (p < N && cg_ok) st<T, VEC>(out + ((int64_t)b * N + p) * C + (int64_t)cg * VEC, acc);
+      if (!EDGE || (p < N && cg_ok)) st<T, VEC>(out + ((int64_t)b * N + p) * C + (int64_t)cg * VEC, acc);  // full tiles: no predicate
     }
   }
 }

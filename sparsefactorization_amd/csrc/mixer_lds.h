@@ -129,7 +129,9 @@ chord_mixer_lds_k(const MixerLdsArgs a, const Offsets offs) {
             x[i] = xb[cur + src * CG + g];
             w[i] = wrow[k];
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          lds_wait_all();
+#pragma unroll
+          for (int i = 0; i < 5; ++i) behind_wait(x[i]), behind_wait(w[i]);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int i = 0; i < 5; ++i)

@@ -126,6 +126,25 @@ __device__ __forceinline__ uint32_t lane_off(uint32_t v) {
   return v;
 }
 
+// ---- LDS results in kernels that also issue MFMAs: the rule (profiles/r04b_mixer_lds_wait.md, isa_lint.py R3) ----
+// A packed-f32 instruction (v_pk_*_f32: 64-bit register-pair operands) must not be the first consumer of a ds_read result
+// right behind the counted `s_waitcnt lgkmcnt(n)` that released it. That is the only thing the ISA of the one sporadically
+// wrong build of this library (chord_fwd_mlp_k, round 4) has which its two clean builds have not; the counts themselves were
+// right (in-order LDS returns, no scalar load in flight, no hand-written instruction anywhere near). So the kernels that
+// mix MFMA phases with LDS-fed f32 arithmetic read ALL LDS operands of a row first, wait for lgkmcnt(0), and make every
+// consumer DATA-DEPENDENT on that wait: lds_wait_all() is the wait, behind_wait(r) re-defines r behind it (volatile asm
+// statements keep their order; an empty one costs no instruction). A bare `asm volatile("s_waitcnt ...")` with a memory
+// clobber does not do that: hipcc is free to linearise register-only arithmetic in front of it, and did (the first
+// "fixed" build had its wait behind most of the row's multiplies — r04b, "What the ISA says").
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void behind_wait(float& r) { asm volatile("" : "+v"(r)); }
+__device__ __forceinline__ void behind_wait(float __attribute__((ext_vector_type(4))) & r) { asm volatile("" : "+v"(r)); }
+template <int VEC>
+__device__ __forceinline__ void behind_wait(Vec<float, VEC>& v) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) asm volatile("" : "+v"(v.e[i]));
+}
+
 // the same through a global-address-space byte pointer (sbase(...) + lane offset); the access itself is made on a built-in
 // vector type (a class type cannot be copied out of an address-space-qualified lvalue)
 template <typename T, int VEC>
