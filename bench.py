@@ -463,6 +463,9 @@ def run_rank(args) -> int:
                                               "abandoned so that the headline line is kept",
                                      "rc": TRAIN_ABANDONED_RC}
                     print(json.dumps(line), flush=True)
+                if rank != 0:
+                    time.sleep(5)  # rank 0 prints first: a peer that leaves earlier closes its sockets under rank 0's collective,
+                                   # which then fails with "connection closed" before rank 0's own deadline has fired
                 os._exit(TRAIN_ABANDONED_RC)
 
             guard = threading.Timer(TRAIN_DEADLINE_S, abandon)
@@ -708,7 +711,7 @@ def shapes_leg(device):
                     V = torch.randn(B, N, C, device=device, generator=g)
                     dZ = torch.randn(B, N, C, device=device, generator=g)
                     dW, dV = torch.empty_like(Ws[0]), torch.empty_like(V)
-                    t_bwd = timed(lambda: _launch_bwd(dZ, Ws[0], V, dW, dV, B, N, L, C, N * C, None, None, 0), 40)
+                    t_bwd = timed(lambda: _launch_bwd(dZ, Ws[0], V, dW, dV, B, N, L, C, N * C, None), 40)
                     bwd_bytes = 4 * B * N * (2 * L + 3 * C)
                     entry.update({"bwd_us_per_step": t_bwd, "bwd_bytes_per_step": bwd_bytes,
                                   "bwd_frac_of_hbm_peak": bwd_bytes / (t_bwd * 1e-6) / 1e9 / HBM_PEAK_GBS})

@@ -146,33 +146,10 @@ int psf_chord_chain_fwd_f64(const double* const* W_steps, const double* V0, doub
                             const int64_t* offsets, void* stream);
 
 /*
- * Training variants with a link-major SIDE COPY of W's far columns.
- *
- * dV[q] = sum_k W[q - off_k, k] * dZ[q - off_k] reads ONE column element of W per row and link. For the links the dV
- * kernel serves from far source tiles that is a 4-byte read at a row stride of 4L bytes: every 128-byte line of the
- * source rows is moved from L2 to the CU for 4 useful bytes — 300 of the kernel's 676 bytes of L2 traffic per row at
- * N = 16384, L = 15, C = 8 (profiles/r02f_dvlab.log: 29.1 us with those reads, 25.0 us with them served from a
- * link-major copy, 22.8 us with none). The forward step has each W tile in LDS anyway and can write those columns out
- * link-major for 4(L - k0) extra bytes per row:
- *     w_far[b][k - k0][n] = W[b][n][k]        k0 <= k < L            (a [B, L-k0, N] array)
- *   psf_chord_bwd_far_first_link  k0 for this shape: the first link the dV window kernel treats as far; returns L when
- *                                 a side copy would not be used (no window kernel, no far links), < 0 on bad arguments
- *   psf_chord_chain_fwd_far_f32   psf_chord_chain_fwd_f32 that also fills wfar_steps[m] (each [B, L-k0, N]; entries or
- *                                 the table may be NULL = no copy for that step). Steps that run on a kernel which
- *                                 cannot emit the copy (the single-launch LDS chain, the generic kernel) report it:
- *                                 *copied_mask gets bit m set for every step whose copy was written (may be NULL).
- *   psf_chord_spmm_bwd_far_f32    psf_chord_spmm_bwd_f32 with w_far (or NULL) for the same W; k0 as returned above.
- * Results are bit-identical with and without the copy (same values, same order).
+ * (Rounds 2-4 also exported training variants that kept a link-major side copy of W's far columns for the dV kernel —
+ * "..._chain_fwd_far_f32", "..._spmm_bwd_far_f32", "..._bwd_far_first_link". A wash end to end
+ * (profiles/r02n_far_copy.log, r03aj_farcopy_in_step_ab.log), off by default since round 2, removed in round 5.)
  */
-int32_t psf_chord_bwd_far_first_link(int64_t B, int64_t N, int32_t L, int64_t C);
-int psf_chord_chain_fwd_far_f32(const float* const* W_steps, const float* V0, float* const* out_steps,
-                                float* const* wfar_steps, int32_t far_k0, uint64_t* copied_mask,
-                                int32_t M, int32_t use_residual,
-                                int64_t B, int64_t N, int32_t L, int64_t C, int64_t v0_batch_stride,
-                                const int64_t* offsets, void* stream);
-int psf_chord_spmm_bwd_far_f32(const float* dZ, const float* W, const float* V, float* dW, float* dV,
-                               int64_t B, int64_t N, int32_t L, int64_t C, int64_t v_batch_stride,
-                               const int64_t* offsets, const float* w_far, int32_t far_k0, void* stream);
 
 /*
  * Producer side: weight / bias gradient of the token-wise Linear layers of MLPBlock
@@ -407,8 +384,6 @@ int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float
  * Process-wide tuning knobs (benchmark / test use; defaults are the shipped configuration).
  *   key "fwd_variant": 0 = auto, 1 = generic direct-gather kernel, 2 = LDS-window kernel
  *   key "bwd_variant": 0 = auto (LDS-window dV / dW kernels where they apply), 1 = generic kernels
- *   key "fwd_rows"   : 0 = per-shape default, else rows per thread of the LDS-window kernel (1, 2)
- *   key "bwd_rows"   : 0 = defaults (dV 2, dW 1), else rows per thread of both backward window kernels
  *   key "fwd_split"  : window kernels (forward, dV, dW) on shapes with a ragged last tile per sequence: 1 = by size
  *                      (default: one launch of the general (edge) instance below ~300 MB of algorithmic bytes, where the
  *                      ~2.7 us of a second launch outweigh predicating every tile; above that as 2); 2 = full tiles on
@@ -418,22 +393,19 @@ int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float
  *                      chunks of 8, else the whole-row window kernel), 1 = whole-row window kernel, 2 = chunk-looping
  *                      kernel or PSF_E_TUNING where it does not apply
  *   key "dw_tgs"     : chunk-looping dW, lanes per row chunk: 0 = auto (8; 16 when that spares a ragged tile), 4 = 8, 5 = 16
- *   key "dv_threads" : dV window kernel: 0 = auto (512 threads x 1 row for C <= 8, else 256 threads), 1 = 256 threads
- *                      (rows per thread from "bwd_rows"), 2 = 512 threads x 1 row where compiled (C <= 32)
+ *   key "dv_threads" : dV window kernel: 0 = auto (512 threads x 1 row for C <= 8, else 256 threads x 2 rows), 1 = 256 threads
  *   key "bwd_fused"  : a backward step that wants both dW and dV: 1 (default) = ONE fused kernel for rows of C = 4, 8, 16 or
  *                      32 channels and sequences of at least two tiles — the dZ window staged once serves both gradients:
  *                      the aligned instance (N and the far offsets multiples of the tile, 16-byte-aligned chunk-clean
  *                      buffers: row-block addresses on the scalar unit) or else the general one (any N — N = 2^k + 1 with a
  *                      CLS token —, any far offsets, W / dW at any alignment); 2 = the aligned instance or the two kernels;
  *                      0 = always the two kernels
- *   key "bwd_fused_nt": threads of the fused kernel: 1 = 256 (default; tile = 256 / (C / 4) rows), 0 = 512
  *   key "fwd_wide"   : rows of >= 64 channels: 0 = automatic (default): the forward step takes 32-channel chunks on
  *                      1024-thread workgroups (256-row tiles) for rows of 64..256 channels and N <= 4096, one workgroup per
  *                      whole row otherwise; the backward kernels one workgroup per whole row; 1 = the 1024-thread chunks
- *                      wherever they fit (forward and dV); 2 = 32-channel chunks on 256-thread workgroups; 4 = one workgroup
- *                      per whole row always; 3 = rows of exactly 32 channels on 512-thread workgroups (128-row
- *                      tiles: one far link fewer; equal to the default at N = 16384, B = 16 and N = 4096, B = 32, 3-8 %
- *                      faster at B = 64: profiles/r04ai_fwd_mid_sweep.log)
+ *                      wherever they fit (forward and dV); 2 = 32-channel chunks on 256-thread workgroups; 4 (and 3, whose
+ *                      512-thread instance for rows of 32 channels was removed in round 5) = one workgroup per whole row
+ *                      always
  *   key "chain_fused": 1 (default) = psf_chord_chain_fwd_f32 runs short sequences (N <= 2112, L <= 20, C % 4 == 0) as ONE
  *                      launch with the sequence resident in LDS: always when at most two step results are kept (inference
  *                      with alternating buffers), and when every step is kept (training) for sequences of at most 33792

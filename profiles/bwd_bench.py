@@ -41,28 +41,5 @@ def main():
     t_both = time_us(lambda: chord._launch_bwd(dZ, W, V, dW, dV, B, N, L, C, N * C, None))
     print(f"B={B} N={N} L={L} C={C}: fwd(+res) {t_fw:.1f} us  dV {t_dv:.1f} us ({alg / t_dv / 1e6:.2f} TB/s)  "
           f"dW {t_dw:.1f} us ({alg / t_dw / 1e6:.2f} TB/s)  both {t_both:.1f} us")
-    # link-major side copy of W's far columns: what the forward step pays to write it, what dV gains from it
-    import ctypes
-    from sparsefactorization_amd import _lib
-    lib = _lib.load()
-    k0 = lib.psf_chord_bwd_far_first_link(B, N, L, C)
-    if 0 <= k0 < L:
-        wfar = torch.empty(B, L - k0, N, device=dev)
-        tab = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())  # noqa: E731
-        def fwd_far():
-            rc = lib.psf_chord_chain_fwd_far_f32(tab(W), V.data_ptr(), tab(out), tab(wfar), k0, None, 1, 1, B, N, L, C, N * C,
-                                                 None, torch.cuda.current_stream().cuda_stream)
-            assert rc == 0
-        def fwd_plain():
-            rc = lib.psf_chord_chain_fwd_far_f32(tab(W), V.data_ptr(), tab(out), None, k0, None, 1, 1, B, N, L, C, N * C,
-                                                 None, torch.cuda.current_stream().cuda_stream)
-            assert rc == 0
-        t_f0, t_f1 = time_us(fwd_plain), time_us(fwd_far)
-        t_dv_far = time_us(lambda: chord._launch_bwd(dZ, W, V, None, dV, B, N, L, C, N * C, None, wfar, k0))
-        t_dv2 = time_us(lambda: chord._launch_bwd(dZ, W, V, None, dV, B, N, L, C, N * C, None))
-        print(f"    far-column side copy (links >= {k0}): fwd(+res, res = V) {t_f0:.1f} -> {t_f1:.1f} us with the copy written;  "
-              f"dV {t_dv2:.1f} -> {t_dv_far:.1f} us ({alg / t_dv_far / 1e6:.2f} TB/s = {alg / t_dv_far / 8e6:.3f} of 8) with it read")
-
-
 if __name__ == "__main__":
     main()

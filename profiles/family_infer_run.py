@@ -13,7 +13,7 @@ from sparsefactorization_amd import genome_training, lra_training, psf_training,
 from sparsefactorization_amd.train import seed_everything  # noqa: E402
 
 fam = sys.argv[1] if len(sys.argv) > 1 else "order"
-for kv in filter(None, os.environ.get("PSF_TUNE", "").split(",")):  # e.g. PSF_TUNE=fwd_wide=1,fwd_rows=1
+for kv in filter(None, os.environ.get("PSF_TUNE", "").split(",")):  # e.g. PSF_TUNE=fwd_wide=1,fwd_wg_limit=3
     import sparsefactorization_amd as sfa
     key, val = kv.split("=")
     sfa.set_tuning(key, int(val))

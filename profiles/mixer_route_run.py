@@ -12,8 +12,6 @@ from sparsefactorization_amd import fused_mixer, psf_training  # noqa: E402
 from sparsefactorization_amd.train import seed_everything  # noqa: E402
 
 fused_mixer.route = sys.argv[1] if len(sys.argv) > 1 else "never"
-if fused_mixer.route == "recipe":
-    fused_mixer.route, fused_mixer.affine_in_kernel = "always", True
 problem = sys.argv[2] if len(sys.argv) > 2 else "adding"
 dev = torch.device("cuda:0")
 seed_everything(42)

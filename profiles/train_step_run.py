@@ -7,9 +7,6 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparsefactorization_amd import psf_training  # noqa: E402
 
-if os.environ.get("PSF_FAR_COPY") == "1":  # A/B: forward steps leave the link-major side copy of W's far columns (chord.far_copy)
-    from sparsefactorization_amd import chord
-    chord.far_copy = True
 problem = sys.argv[1] if len(sys.argv) > 1 else "order"
 steps = sys.argv[2] if len(sys.argv) > 2 else "40"
 psf_training.main(["--problem", problem, "--n-vec", "16384", "--json", "--max-steps", steps, "--train-seqs", "1600",

@@ -104,9 +104,6 @@ def _unit_table():
     for t in range(4):
         units.append((os.path.join(OBJ_DIR, f"bwd_window_mid_tgs{t}.o"), os.path.join(CSRC, "bwd_window_inst.hip"),
                       [f"-DPSF_TGS={t}", "-DPSF_NT=512"]))
-    # rows of 32 channels on 512-thread workgroups (fwd_window_launch.h: kFwdMidTgs, kFwdMidThreads)
-    units.append((os.path.join(OBJ_DIR, "fwd_window_mid_tgs3.o"), os.path.join(CSRC, "fwd_window_inst.hip"),
-                  ["-DPSF_TGS=3", "-DPSF_NT=512"]))
     # wide-row configuration (fwd_window_launch.h: kWideTgs, kWideThreads)
     wide = ["-DPSF_TGS=3", "-DPSF_NT=1024"]
     units.append((os.path.join(OBJ_DIR, "fwd_window_wide.o"), os.path.join(CSRC, "fwd_window_inst.hip"), wide))

@@ -87,19 +87,13 @@ def _launch_fwd(W, V, res, out, B, N, L, C, stride, offsets):
     _lib.check(rc, "psf_chord_spmm_fwd")
 
 
-def _launch_bwd(dZ, W, V, dW, dV, B, N, L, C, stride, offsets, w_far=None, far_k0=0):
-    """``w_far``: the link-major side copy of W's columns >= far_k0 that a training forward chain left (fp32), or None."""
+def _launch_bwd(dZ, W, V, dW, dV, B, N, L, C, stride, offsets):
     dev = _require_hip(dZ, W, V)
     off = _lib.offsets_array(offsets)
     with torch.cuda.device(dev):
-        if w_far is not None and dZ.dtype == torch.float32:
-            rc = _lib.load().psf_chord_spmm_bwd_far_f32(
-                dZ.data_ptr(), W.data_ptr(), V.data_ptr(), dW.data_ptr() if dW is not None else None,
-                dV.data_ptr() if dV is not None else None, B, N, L, C, stride, off, w_far.data_ptr(), far_k0, _stream_ptr(dev))
-        else:
-            fn = getattr(_lib.load(), "psf_chord_spmm_bwd" + _suffix(dZ))
-            rc = fn(dZ.data_ptr(), W.data_ptr(), V.data_ptr(), dW.data_ptr() if dW is not None else None,
-                    dV.data_ptr() if dV is not None else None, B, N, L, C, stride, off, _stream_ptr(dev))
+        fn = getattr(_lib.load(), "psf_chord_spmm_bwd" + _suffix(dZ))
+        rc = fn(dZ.data_ptr(), W.data_ptr(), V.data_ptr(), dW.data_ptr() if dW is not None else None,
+                dV.data_ptr() if dV is not None else None, B, N, L, C, stride, off, _stream_ptr(dev))
     _lib.check(rc, "psf_chord_spmm_bwd")
 
 
@@ -244,15 +238,6 @@ def _sum_tensors(terms: Sequence[torch.Tensor]) -> torch.Tensor:
     return out
 
 
-#: Let training forward chains leave a link-major side copy of W's far columns for the dV kernel (``psf_chord.h``,
-#: ``psf_chord_chain_fwd_far_f32`` / ``psf_chord_spmm_bwd_far_f32``). OFF by default: written by the forward STEP the
-#: copy costs what it saves (profiles/r02n_far_copy.log, us per launch at N = 16384, L = 15: C = 8, B = 64: forward
-#: 26.7 -> 30.8, dV 31.5 -> 27.4; B = 40: 19.8 -> 21.7, 22.1 -> 18.9; C = 32: 25.1 -> 27.7, 25.0 -> 24.2). It pays only
-#: when whoever produces W can write those columns for free.
-far_copy: bool = False
-_FAR_COPY_MIN_N = 2048  # shorter sequences take the single-launch LDS chain, which writes no copy
-
-
 class _ChordChain(torch.autograd.Function):
     """X_0 = V0; X_{m+1} = W_m (.) X_m (+ V0) — SyntheticExperiments/psf.py:167-188 as one autograd node."""
 
@@ -277,33 +262,13 @@ class _ChordChain(torch.autograd.Function):
         lib = _lib.load()
         w_tab = (ctypes.c_void_p * M)(*[w.data_ptr() for w in Ws])
         o_tab = (ctypes.c_void_p * M)(*[o.data_ptr() for o in outs])
-        # Training: let the forward steps leave a link-major side copy of W's far columns for the dV kernel (each step has
-        # its W tile in LDS anyway; the dV kernel otherwise pulls a 128-byte line per 4-byte far element — psf_chord.h).
-        # Only where dX is needed (every step but the first, unless V0 needs a gradient) and the kernels support it.
-        wfars: List[Optional[torch.Tensor]] = [None] * M
-        k0 = L
-        need_dx = [m > 0 or ctx.needs_input_grad[0] for m in range(M)]
-        if keep_all and far_copy and offsets is None and V0c.dtype == torch.float32 and M <= 64 and N > _FAR_COPY_MIN_N:
-            k0 = lib.psf_chord_bwd_far_first_link(B, N, L, C)
         with torch.cuda.device(dev):
-            if 0 <= k0 < L:
-                wfars = [torch.empty((B, L - k0, N), dtype=torch.float32, device=dev) if need_dx[m] else None
-                         for m in range(M)]
-                f_tab = (ctypes.c_void_p * M)(*[f.data_ptr() if f is not None else None for f in wfars])
-                mask = ctypes.c_uint64(0)
-                rc = lib.psf_chord_chain_fwd_far_f32(w_tab, V0c.data_ptr(), o_tab, f_tab, k0, ctypes.byref(mask), M,
-                                                     1 if use_residual else 0, B, N, L, C, stride0,
-                                                     _lib.offsets_array(offsets), _stream_ptr(dev))
-                wfars = [f if (mask.value >> m) & 1 else None for m, f in enumerate(wfars)]
-            else:
-                fn = getattr(lib, "psf_chord_chain_fwd" + _suffix(V0c))
-                rc = fn(w_tab, V0c.data_ptr(), o_tab, M, 1 if use_residual else 0, B, N, L, C, stride0,
-                        _lib.offsets_array(offsets), _stream_ptr(dev))
+            fn = getattr(lib, "psf_chord_chain_fwd" + _suffix(V0c))
+            rc = fn(w_tab, V0c.data_ptr(), o_tab, M, 1 if use_residual else 0, B, N, L, C, stride0,
+                    _lib.offsets_array(offsets), _stream_ptr(dev))
         _lib.check(rc, "psf_chord_chain_fwd")
         if keep_all:
-            ctx.save_for_backward(V0c, *Ws, *outs[:-1], *[f for f in wfars if f is not None])
-        ctx.far_slots = [m for m, f in enumerate(wfars) if f is not None]
-        ctx.far_k0 = k0
+            ctx.save_for_backward(V0c, *Ws, *outs[:-1])
         ctx.M, ctx.geom, ctx.offsets, ctx.use_residual, ctx.v_shape = M, (B, N, L, C, stride0), offsets, use_residual, V0.shape
         return outs[-1]
 
@@ -314,7 +279,6 @@ class _ChordChain(torch.autograd.Function):
         B, N, L, C, stride0 = ctx.geom
         saved = ctx.saved_tensors
         V0, Ws, steps = saved[0], saved[1:1 + M], saved[1 + M:2 * M]
-        wfars = dict(zip(ctx.far_slots, saved[2 * M:]))
         need_v0 = ctx.needs_input_grad[0]
         need_w = ctx.needs_input_grad[3:]
         g = g.contiguous()
@@ -336,7 +300,7 @@ class _ChordChain(torch.autograd.Function):
             dW = torch.empty_like(Ws[m]) if need_w[m] else None
             dX = torch.empty((B, N, C), dtype=g.dtype, device=g.device) if want_dx else None
             if dW is not None or dX is not None:
-                _launch_bwd(g, Ws[m], x_in, dW, dX, B, N, L, C, stride, ctx.offsets, wfars.get(m), ctx.far_k0)
+                _launch_bwd(g, Ws[m], x_in, dW, dX, B, N, L, C, stride, ctx.offsets)
             dWs[m] = dW
             g = dX
         dV0 = None

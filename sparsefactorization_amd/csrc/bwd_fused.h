@@ -51,8 +51,7 @@ struct BwdFusedCfg {
 template <int L, int TGS, int NT, int ABL = 0>
 __global__ void __launch_bounds__(NT, (NT == 256 && TGS <= 1) ? 5 : 2)
 chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, const float* __restrict__ V,
-                  float* __restrict__ dW, float* __restrict__ dV, const Geom gm, const Offsets offs, const int64_t w_total,
-                  const float* __restrict__ wfar, const int far_k0) {
+                  float* __restrict__ dW, float* __restrict__ dV, const Geom gm, const Offsets offs, const int64_t w_total) {
   using T = float;
   using Cfg = BwdWinCfg<T, L, TGS, 1, NT>;
   constexpr int VEC = Cfg::VEC, TG = Cfg::TG, TR = Cfg::TR, KN = Cfg::KN, NF = Cfg::NF;
@@ -132,21 +131,14 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
       stage16g<0>(sbase(wc + (size_t)FC::full * NT * 16) + i * 16u, sWV + FC::tile_vecs + FC::full * NT + wave64);
     }
   }
-  // (3b) far-link W elements: element (src0 + pl) of the link's column — in the link-major side copy when the producer left
-  //      one (wave-uniform choice), in row-major W otherwise
+  // (3b) far-link W elements: element (src0 + pl) of the link's column of row-major W. (Reading them from a link-major side
+  //      copy — consecutive rows consecutive floats, the contiguous layout the round-4 review asked for — did not move this
+  //      step: 44.6 vs 43.8 us in the training step, profiles/r03aj_farcopy_in_step_ab.log; the copy was removed in round 5.)
   if constexpr (!(ABL & 2)) {
-    if (wfar != nullptr) {
-      const T* __restrict__ Wf = wfar + ((int64_t)b * (L - far_k0) + (KN - far_k0)) * N;
 #pragma unroll
-      for (int f = 0; f < NF; ++f)
-        farW[f] = *reinterpret_cast<const PSF_GLOBAL T*>(sbase(reinterpret_cast<const char*>(Wf + (int64_t)f * N + src0[f])) +
-                                                         (uint32_t)pl * (uint32_t)sizeof(T));
-    } else {
-#pragma unroll
-      for (int f = 0; f < NF; ++f)
-        farW[f] = *reinterpret_cast<const PSF_GLOBAL T*>(sbase(reinterpret_cast<const char*>(Wb + (int64_t)src0[f] * L + (KN + f))) +
-                                                         (uint32_t)pl * (uint32_t)(L * sizeof(T)));
-    }
+    for (int f = 0; f < NF; ++f)
+      farW[f] = *reinterpret_cast<const PSF_GLOBAL T*>(sbase(reinterpret_cast<const char*>(Wb + (int64_t)src0[f] * L + (KN + f))) +
+                                                       (uint32_t)pl * (uint32_t)(L * sizeof(T)));
   } else {
 #pragma unroll
     for (int f = 0; f < NF; ++f) farW[f] = T(f);

@@ -199,7 +199,7 @@ chord_dw_win_k(const T* __restrict__ dZ, const T* __restrict__ V, T* __restrict_
 template <typename T, int L, int TGS, int R, int NT, bool EDGE>
 __global__ void __launch_bounds__(NT)
 chord_dv_win_k(const T* __restrict__ dZ, const T* __restrict__ W, T* __restrict__ dV, const Geom gm,
-               const Offsets offs, const int64_t w_total, const T* __restrict__ wfar, const int far_k0) {
+               const Offsets offs, const int64_t w_total) {
   using Cfg = BwdWinCfg<T, L, TGS, R, NT>;
   constexpr int VEC = Cfg::VEC, TG = Cfg::TG, RS = Cfg::RS, TR = Cfg::TR, KN = Cfg::KN, NF = Cfg::NF;
   using V4 = Vec<T, VEC>;
@@ -241,12 +241,11 @@ chord_dv_win_k(const T* __restrict__ dZ, const T* __restrict__ W, T* __restrict_
     if (!EDGE || cgi < gm.CG) stage16<T, VEC, true>(Zb + (int64_t)src * C + (int64_t)cgi * VEC, sWin + n * NT + wave64, lane);
   }
 
-  // (3) far links: dZ rows (coalesced) and one W column element per row — from the link-major side copy when the
-  //     forward pass left one (consecutive rows are consecutive floats), else strided out of W's rows (one 128-byte
-  //     line of L2->CU traffic per 4-byte element)
+  // (3) far links: dZ rows (coalesced) and one W column element per row, strided out of W's rows (a link-major side copy
+  //     of those columns, written by the forward step, was built in round 2 and removed in round 5: a wash end to end —
+  //     profiles/r02n_far_copy.log, r03aj_farcopy_in_step_ab.log)
   V4 farZ[R][NF > 0 ? NF : 1];
   T farW[R][NF > 0 ? NF : 1];
-  const T* __restrict__ Wf = wfar ? wfar + ((int64_t)b * (L - far_k0) + (KN - far_k0)) * N : nullptr;  // wave-uniform
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int qr = q0 + j * RS + rs;
@@ -256,7 +255,7 @@ chord_dv_win_k(const T* __restrict__ dZ, const T* __restrict__ W, T* __restrict_
       int src = q - offs.v[KN + f];
       if (src < 0) src += N;
       farZ[j][f] = ld<T, VEC>(Zb + (int64_t)src * C + (int64_t)cgc * VEC);
-      farW[j][f] = Wf ? Wf[(int64_t)f * N + src] : Wb[(int64_t)src * L + (KN + f)];
+      farW[j][f] = Wb[(int64_t)src * L + (KN + f)];
     }
   }
   __syncthreads();

@@ -45,7 +45,7 @@ hipError_t launch_dv(const BwdWinArgs& a) {
   static std::atomic<int> done{0};
   if (hipError_t e = raise_lds_limit(kern, Cfg::lds_dv, done); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(NT), Cfg::lds_dv, a.stream, a.dZ, a.WV, a.out, a.gm, a.offs,
-                     a.w_total, a.wfar, a.far_k0);
+                     a.w_total);
   return hipGetLastError();
 }
 
@@ -96,8 +96,7 @@ hipError_t launch_L(int L, const BwdWinArgs& a) {
 #if PSF_NT == 256
 template <int TGS>
 hipError_t launch_dw_win(int rows, int L, const BwdWinArgs& a) {
-  if (rows == 1) return launch_L<TGS, 1, 256, true>(L, a);
-  if (rows == 2) return launch_L<TGS, 2, 256, true>(L, a);
+  if (rows == 1) return launch_L<TGS, 1, 256, true>(L, a);  // (dW: one row per thread only)
   return hipErrorInvalidValue;
 }
 template hipError_t launch_dw_win<PSF_TGS>(int rows, int L, const BwdWinArgs& a);
@@ -112,16 +111,19 @@ template hipError_t launch_dw_chunk<PSF_TGS>(int L, const BwdWinArgs& a);
 #endif
 #endif
 
+#if PSF_NT != 512 || PSF_TGS <= 1  // (dV on 512 threads x 1 row is compiled for rows of <= 8 channels: bwd_window_launch.h)
 template <int TGS, int NT>
 hipError_t launch_dv_win(int rows, int L, const BwdWinArgs& a) {
   static_assert(dv_pair_compiled(TGS, NT), "not a compiled (TGS, NT) pair");
-  if (rows == 1) return launch_L<TGS, 1, NT, false>(L, a);
-  if constexpr (NT != kDvMidThreads) {
+  if constexpr (NT == kDvMidThreads) {  // 512 threads x 1 row, or two rows per thread
+    if (rows == 1) return launch_L<TGS, 1, NT, false>(L, a);
+  } else {
     if (rows == 2) return launch_L<TGS, 2, NT, false>(L, a);
   }
   return hipErrorInvalidValue;
 }
 template hipError_t launch_dv_win<PSF_TGS, PSF_NT>(int rows, int L, const BwdWinArgs& a);
+#endif
 
 #if PSF_NT == 512
 namespace {
@@ -155,16 +157,16 @@ hipError_t launch_fused(const BwdWinArgs& a) {
     done.store(lds);
   }
   hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(NT), lds, a.stream, a.dZ, a.WV, a.V2, a.out2, a.out,
-                     a.gm, a.offs, a.w_total, a.wfar, a.far_k0);
+                     a.gm, a.offs, a.w_total);
   return hipGetLastError();
 }
 }  // namespace
 template <int TGS>
-hipError_t launch_bwd_fused(int L, const BwdWinArgs& a, int nt) {
+hipError_t launch_bwd_fused(int L, const BwdWinArgs& a) {
   switch (L) {
 #define PSF_CASE(LL) \
   case LL:           \
-    return nt == 256 ? launch_fused<LL, TGS, 256>(a) : launch_fused<LL, TGS, kFusedThreads>(a);
+    return launch_fused<LL, TGS, 256>(a);
     PSF_CASE(4) PSF_CASE(5) PSF_CASE(6) PSF_CASE(7) PSF_CASE(8) PSF_CASE(9) PSF_CASE(10) PSF_CASE(11)
     PSF_CASE(12) PSF_CASE(13) PSF_CASE(14) PSF_CASE(15) PSF_CASE(16) PSF_CASE(17) PSF_CASE(18)
     PSF_CASE(19) PSF_CASE(20)
@@ -173,7 +175,7 @@ hipError_t launch_bwd_fused(int L, const BwdWinArgs& a, int nt) {
       return hipErrorInvalidValue;
   }
 }
-template hipError_t launch_bwd_fused<PSF_TGS>(int L, const BwdWinArgs& a, int nt);
+template hipError_t launch_bwd_fused<PSF_TGS>(int L, const BwdWinArgs& a);
 
 namespace {
 template <int L, int TGS, int NT>
@@ -188,11 +190,11 @@ hipError_t launch_fused_edge(const BwdWinArgs& a) {
 }
 }  // namespace
 template <int TGS>
-hipError_t launch_bwd_fused_edge(int L, const BwdWinArgs& a, int nt) {
+hipError_t launch_bwd_fused_edge(int L, const BwdWinArgs& a) {
   switch (L) {
 #define PSF_CASE(LL) \
   case LL:           \
-    return nt == 256 ? launch_fused_edge<LL, TGS, 256>(a) : launch_fused_edge<LL, TGS, kFusedThreads>(a);
+    return launch_fused_edge<LL, TGS, 256>(a);
     PSF_CASE(4) PSF_CASE(5) PSF_CASE(6) PSF_CASE(7) PSF_CASE(8) PSF_CASE(9) PSF_CASE(10) PSF_CASE(11)
     PSF_CASE(12) PSF_CASE(13) PSF_CASE(14) PSF_CASE(15) PSF_CASE(16) PSF_CASE(17) PSF_CASE(18)
     PSF_CASE(19) PSF_CASE(20)
@@ -201,7 +203,7 @@ hipError_t launch_bwd_fused_edge(int L, const BwdWinArgs& a, int nt) {
       return hipErrorInvalidValue;
   }
 }
-template hipError_t launch_bwd_fused_edge<PSF_TGS>(int L, const BwdWinArgs& a, int nt);
+template hipError_t launch_bwd_fused_edge<PSF_TGS>(int L, const BwdWinArgs& a);
 #endif
 
 }  // namespace psf

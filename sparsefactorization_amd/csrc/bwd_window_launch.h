@@ -17,8 +17,6 @@ struct BwdWinArgs {
   int64_t w_total;  // B*N*L
   bool edge;
   hipStream_t stream;
-  const float* wfar = nullptr;  // dV: link-major side copy of W's columns >= far_k0 (include/psf_chord.h), or nullptr
-  int far_k0 = 0;
   const float* V2 = nullptr;    // fused step (bwd_fused.h): WV = W, V2 = V, out = dV, out2 = dW
   float* out2 = nullptr;
   int ablate = 0;               // fused step, diagnostic builds only (bwd_fused.h: ABL)
@@ -37,18 +35,21 @@ hipError_t launch_dw_chunk(int L, const BwdWinArgs& a);
 // dV: the forward's (TGS, NT) pairs plus 512 threads x 1 row per thread for narrow rows (TGS <= 3): the same 256-row
 // tile as 256 threads x 2 rows at C = 8, with twice the waves per workgroup sharing the staged W tiles — r02 lab
 // (profiles/dvlab.hip): 28.65 vs 29.05 us at cfg2 next to the shipped kernel's 30.07.
-constexpr int kDvMidThreads = 512, kDvMidTgsMax = 3;
+constexpr int kDvMidThreads = 512, kDvMidTgsMax = 1;  // rows of <= 8 channels, where it is the automatic choice (the instances
+                                                       // for 16 and 32 channels were reachable by knob only: removed in round 5)
+constexpr int kFusedTgsMax = 3;                        // fused step: rows of <= 32 channels
 constexpr bool dv_pair_compiled(int tgs, int nt) {
   return win_pair_compiled(tgs, nt) || (nt == kDvMidThreads && tgs >= 0 && tgs <= kDvMidTgsMax);
 }
 template <int TGS, int NT>
 hipError_t launch_dv_win(int rows, int L, const BwdWinArgs& a);
-// fused dV + dW step (bwd_fused.h): 512 threads x 1 row, rows of exactly 4 << TGS channels, TGS <= kDvMidTgsMax; compiled
-// in the 512-thread units
+// fused dV + dW step (bwd_fused.h): 256 threads x 1 row (tile = 256 >> TGS rows), rows of exactly 4 << TGS channels,
+// TGS <= kFusedTgsMax; compiled in the -DPSF_NT=512 units (whose 512-thread fused instances round 5 removed: 256-thread
+// tiles stayed ahead in every sweep, profiles/r04am_bwd_fused_wg_sweep.log)
 template <int TGS>
-hipError_t launch_bwd_fused(int L, const BwdWinArgs& a, int nt);  // nt: 512 (tile = 512 >> TGS rows) or 256
+hipError_t launch_bwd_fused(int L, const BwdWinArgs& a);
 // the same for any sequence length >= two tiles and any far offsets (per-lane wrap, partial last tile, any W / dW alignment)
 template <int TGS>
-hipError_t launch_bwd_fused_edge(int L, const BwdWinArgs& a, int nt);
+hipError_t launch_bwd_fused_edge(int L, const BwdWinArgs& a);
 
 }  // namespace psf

@@ -185,7 +185,7 @@ __device__ __forceinline__ psf_x3::f32x16 mlp_tile(const unsigned char* sImg, in
   return acc2;
 }
 
-template <int L, int TGS, bool RES, bool EDGE, int KIND>
+template <int L, int TGS, bool RES, bool EDGE>
 __global__ void __launch_bounds__(256, 3)
 chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __restrict__ res,
                 float* __restrict__ out, const unsigned char* __restrict__ images, const int nu, const int E, const Geom gm,
@@ -206,7 +206,6 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
   float* __restrict__ sW = reinterpret_cast<float*>(smem + Cfg::win_bytes);
   float* __restrict__ sPart = reinterpret_cast<float*>(smem + Cfg::win_bytes + Cfg::w_bytes);
   unsigned char* __restrict__ sImg = reinterpret_cast<unsigned char*>(smem + Cfg::img_off);
-  float* __restrict__ sAff = reinterpret_cast<float*>(smem + Cfg::img_off + nu * kImgBytes);  // 512 bytes: stage_affine
 
   int b, tile, chunk;
   decode_block(gm, b, tile, chunk);  // chunk == 0: rows of <= 32 channels are never split
@@ -222,10 +221,11 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
 
   // ---- (0a) this wave's rows of `data`, straight into B-operand order: k-step s covers e = 16 s + 8 half + (0..7) ----
   const int grp = G == 1 ? 0 : wv / TT;  // which share of the hidden units this wave takes (wave-uniform)
-  if constexpr (KIND == 1) {  // the affine recipe reads its 512-byte table from LDS
-    stage_affine(in, sAff, E, tid);
-    __syncthreads();
-  }
+  // (`data` is given as its rows here. The recipes of psf_mixer_input — affine input layer, embedding lookup — are evaluated
+  // by the single-launch kernel of mixer_lds.h only: inside the per-step kernels they measured slower than rows written once,
+  // r04h_mixer_bench.log, and tripled this unit's instance count; round 5 took them out.)
+  constexpr int KIND = 0;
+  float* const sAff = nullptr;
   float xv[TPW][2][8];
 #pragma unroll
   for (int tp = 0; tp < TPW; ++tp) {
@@ -445,7 +445,7 @@ chord_fwd_mlp_k(const MixerIn in, const float* __restrict__ V, const float* __re
 
 // V0 = g(data) on the same tiles: the matrix phase only (MLP 0: E -> h -> C), its Y^T tiles stored as rows of V0. A wave takes
 // whole token tiles with all hidden units (waves beyond the tile count idle: one launch per forward, not the hot kernel).
-template <int TGS, bool EDGE, int KIND>
+template <int TGS, bool EDGE>
 __global__ void __launch_bounds__(256, 3)
 chord_mixer_g_k(const MixerIn in, float* __restrict__ out, const unsigned char* __restrict__ images, const int nu, const int E,
                 const Geom gm) {
@@ -453,7 +453,8 @@ chord_mixer_g_k(const MixerIn in, float* __restrict__ out, const unsigned char* 
   constexpr int TR = mlp_step_tile_rows(TGS), TT = TR / 32, NW = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned char* __restrict__ sImg = reinterpret_cast<unsigned char*>(smem);
-  float* __restrict__ sAff = reinterpret_cast<float*>(smem + nu * kImgBytes);
+  constexpr int KIND = 0;  // rows of `data` only (see chord_fwd_mlp_k)
+  float* const sAff = nullptr;
   int b, tile, chunk;
   decode_block(gm, b, tile, chunk);
   const int p0 = tile * TR, N = gm.N, C = gm.C;
@@ -466,10 +467,6 @@ chord_mixer_g_k(const MixerIn in, float* __restrict__ out, const unsigned char* 
     if (v < img_vecs)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(images + 16 * (size_t)v),
                                        (__attribute__((address_space(3))) void*)(sImg + 16 * (v0 + wave64)), 16, 0, 0);
-  }
-  if constexpr (KIND == 1) {
-    stage_affine(in, sAff, E, tid);
-    __syncthreads();
   }
   // the wave's token tiles (t = wv, wv + 4, ...): every tile's data rows are requested before the first barrier, so that their
   // memory latency passes beside the image DMA instead of once per tile (the first form loaded inside the loop: 57 us for a

@@ -13,11 +13,12 @@ namespace {
 
 constexpr int kLdsPerCuBytes = 160 * 1024;
 
-template <int L, int TGS, bool RES, bool EDGE, int KIND>
-hipError_t launch_kind(const FwdMlpArgs& a) {
+template <int L, int TGS, bool RES, bool EDGE>
+hipError_t launch_one(const FwdMlpArgs& a) {
+  if (a.in.kind != 0) return hipErrorInvalidValue;  // rows of `data` only (recipes: mixer_lds.h)
   using Cfg = MlpStepCfg<L, TGS>;
-  auto kern = chord_fwd_mlp_k<L, TGS, RES, EDGE, KIND>;
-  int lds = Cfg::img_off + a.nu * kImgBytes + 512;  // + the affine recipe's table
+  auto kern = chord_fwd_mlp_k<L, TGS, RES, EDGE>;
+  int lds = Cfg::img_off + a.nu * kImgBytes;
   if (a.wg_per_cu > 0) {  // occupancy limiter: asking for just over 160 KB / (n + 1) caps a CU at n workgroups
     const int floor_bytes = kLdsPerCuBytes / (a.wg_per_cu + 1) + 256;
     if (floor_bytes > lds) lds = floor_bytes;
@@ -34,16 +35,6 @@ hipError_t launch_kind(const FwdMlpArgs& a) {
   hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(256), lds, a.stream, a.in, a.V, a.res, a.out, a.images, a.nu, a.E, a.gm,
                      a.offs, a.ablate);
   return hipGetLastError();
-}
-
-template <int L, int TGS, bool RES, bool EDGE>
-hipError_t launch_one(const FwdMlpArgs& a) {
-  switch (a.in.kind) {
-    case 0: return launch_kind<L, TGS, RES, EDGE, 0>(a);
-    case 1: return launch_kind<L, TGS, RES, EDGE, 1>(a);
-    case 2: return launch_kind<L, TGS, RES, EDGE, 2>(a);
-    default: return hipErrorInvalidValue;
-  }
 }
 
 template <int L, int TGS>
@@ -73,7 +64,8 @@ template hipError_t launch_fwd_mlp<PSF_TGS>(int L, const FwdMlpArgs& a);
 
 template <int TGS>
 hipError_t launch_mixer_g(const FwdMlpArgs& a) {
-  const int lds = a.nu * kImgBytes + 512;
+  if (a.in.kind != 0) return hipErrorInvalidValue;
+  const int lds = a.nu * kImgBytes;
   auto launch = [&](auto kern) {
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -82,12 +74,7 @@ hipError_t launch_mixer_g(const FwdMlpArgs& a) {
     hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(256), lds, a.stream, a.in, a.out, a.images, a.nu, a.E, a.gm);
     return hipGetLastError();
   };
-  switch (a.in.kind) {
-    case 0: return a.edge ? launch(chord_mixer_g_k<TGS, true, 0>) : launch(chord_mixer_g_k<TGS, false, 0>);
-    case 1: return a.edge ? launch(chord_mixer_g_k<TGS, true, 1>) : launch(chord_mixer_g_k<TGS, false, 1>);
-    case 2: return a.edge ? launch(chord_mixer_g_k<TGS, true, 2>) : launch(chord_mixer_g_k<TGS, false, 2>);
-    default: return hipErrorInvalidValue;
-  }
+  return a.edge ? launch(chord_mixer_g_k<TGS, true>) : launch(chord_mixer_g_k<TGS, false>);
 }
 
 template hipError_t launch_mixer_g<PSF_TGS>(const FwdMlpArgs& a);

@@ -77,7 +77,7 @@ template <typename T, int L, int TGS, int R, int NT, bool DMA, bool RES, bool ED
 __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* __restrict__ V,
                                              const T* __restrict__ res, T* __restrict__ out, const Geom& gm,
                                              const Offsets& offs, const int64_t w_total, char* smem, int b, int p0,
-                                             int chunk, int mis, int64_t e_al, T* __restrict__ wfar, int far_k0) {
+                                             int chunk, int mis, int64_t e_al) {
   using Cfg = FwdWinCfg<T, L, TGS, R, NT>;
   constexpr int VEC = Cfg::VEC, TG = Cfg::TG, RS = Cfg::RS, TR = Cfg::TR;
   constexpr int KN = Cfg::KN, NF = Cfg::NF;
@@ -213,16 +213,6 @@ __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* _
     __syncthreads();  // (hipcc drains vmcnt here: the DMA'd tiles and the register loads have all landed)
   }
 
-  // ---- (3b) training: link-major side copy of W's far columns for the dV kernel (include/psf_chord.h) ----
-  //      w_far[b][k - k0][p] = W[b][p][k]: the tile is in LDS, a column is TR consecutive floats of the copy
-  if (wfar != nullptr && chunk == 0) {  // wave-uniform
-    const int nfar = L - far_k0;
-    for (int t = tid; t < rows_here; t += NT) {
-      T* __restrict__ dst = wfar + (int64_t)b * nfar * N + p0 + t;
-      for (int k = far_k0; k < L; ++k) dst[(int64_t)(k - far_k0) * N] = sWf[mis + t * L + k];
-    }
-  }
-
   // ---- (4) accumulate, links ascending ----
 #pragma unroll
   for (int j = 0; j < R; ++j) {
@@ -261,8 +251,7 @@ __device__ __forceinline__ void fwd_win_body(const T* __restrict__ W, const T* _
 template <typename T, int L, int TGS, int R, int NT, bool DMA, bool RES, int MODE>
 __global__ void __launch_bounds__(NT)
 chord_fwd_win_k(const T* __restrict__ W, const T* __restrict__ V, const T* __restrict__ res,
-                T* __restrict__ out, const Geom gm, const Offsets offs, const int64_t w_total, T* __restrict__ wfar,
-                const int far_k0) {
+                T* __restrict__ out, const Geom gm, const Offsets offs, const int64_t w_total) {
   using Cfg = FwdWinCfg<T, L, TGS, R, NT>;
   constexpr int VEC = Cfg::VEC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -273,8 +262,7 @@ chord_fwd_win_k(const T* __restrict__ W, const T* __restrict__ V, const T* __res
   const int64_t e_lo = ((int64_t)b * gm.N + p0) * L;  // first W element of the tile in the flat buffer
   const int mis = (int)(((reinterpret_cast<uintptr_t>(W) / sizeof(T)) + (uint64_t)e_lo) & (VEC - 1));
   const int64_t e_al = e_lo - mis;                    // element index of chunk 0 (-mis at the buffer start)
-  fwd_win_body<T, L, TGS, R, NT, DMA, RES, MODE == 1, MODE == 2>(W, V, res, out, gm, offs, w_total, smem, b, p0, chunk, mis, e_al, wfar,
-                                                 far_k0);
+  fwd_win_body<T, L, TGS, R, NT, DMA, RES, MODE == 1, MODE == 2>(W, V, res, out, gm, offs, w_total, smem, b, p0, chunk, mis, e_al);
 }
 
 }  // namespace psf

@@ -38,7 +38,7 @@ hipError_t launch_one(const FwdWinArgs& a) {
     }
   }
   hipLaunchKernelGGL(kern, dim3(a.gm.nblocks), dim3(NT), lds, a.stream, a.W, a.V, a.res, a.out, a.gm,
-                     a.offs, a.w_total, a.wfar, a.far_k0);
+                     a.offs, a.w_total);
   return hipGetLastError();
 }
 
@@ -72,8 +72,7 @@ template <int TGS, int NT>
 hipError_t launch_fwd_win(int rows, int L, const FwdWinArgs& a) {
   static_assert(kWinLmin == 4 && kWinLmax == 20, "keep the PSF_CASE list in step with kWinLmin/kWinLmax");
   static_assert(win_pair_compiled(TGS, NT), "not a compiled (TGS, NT) pair");
-  if (rows == 1) return launch_L<TGS, 1, NT>(L, a);
-  if (rows == 2) return launch_L<TGS, 2, NT>(L, a);
+  if (rows == 2) return launch_L<TGS, 2, NT>(L, a);  // (the only compiled rows per thread: fwd_window_launch.h)
   return hipErrorInvalidValue;
 }
 

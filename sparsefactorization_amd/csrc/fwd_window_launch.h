@@ -18,19 +18,16 @@ constexpr int kWinTgsMax = 6;               // TG = 1 << TGS <= 64 lanes share a
 // (32 channels = one 128-byte line per row chunk; wider rows are split into channel chunks) at 1024 threads,
 // i.e. 256-row tiles. For C >= 64 that turns all but L-10 links into near links (see fwd_window.h).
 constexpr int kWideTgs = 3, kWideThreads = 1024;
-// ... and 512 threads for rows of exactly 32 channels (8 lanes per row): 128-row tiles with 2 rows per thread, one far link
-// fewer than the 64-row tiles of 256 threads (knob "fwd_wide" = 3; measured in profiles/r04ai_*).
-constexpr int kFwdMidTgs = 3, kFwdMidThreads = 512;
+// (Round 4 also built 512 threads for rows of exactly 32 channels — equal at the genome and IMDb shapes, profiles/r04ai_* —
+// and round 5 removed it: no automatic rule selected it.)
 constexpr bool win_pair_compiled(int tgs, int nt) {
-  return (nt == 256 && tgs >= 0 && tgs <= kWinTgsMax) || (nt == kWideThreads && tgs == kWideTgs) ||
-         (nt == kFwdMidThreads && tgs == kFwdMidTgs);
+  return (nt == 256 && tgs >= 0 && tgs <= kWinTgsMax) || (nt == kWideThreads && tgs == kWideTgs);
 }
 
-// Rows per thread R that are compiled, and the default.
+// Rows per thread: the forward and dV kernels are compiled for R = 2 (dV also 512 threads x 1 row), dW for R = 1.
 // r01 measurements (us per launch): cfg2 (C=8) R=2 27.5 < R=1 29.1; cfg3 (C=128) R=2 16.1 < R=4 16.9 < R=8 19.8;
-// cfg4 (C=32) R=1 6.0 ~ R=2 6.1 < R=4 6.4.
-constexpr bool win_rows_compiled(int r) { return r == 1 || r == 2; }
-constexpr int win_default_rows(int /*tgs*/) { return 2; }
+// cfg4 (C=32) R=1 6.0 ~ R=2 6.1 < R=4 6.4; dV R=2 31.3 vs R=1 32.7; dW R=1 22.9 vs R=2 28.7. The other instances were
+// reachable through tuning knobs only ("fwd_rows", "bwd_rows") and went with them in round 5.
 
 struct FwdWinArgs {
   const float* W;
@@ -42,8 +39,6 @@ struct FwdWinArgs {
   int64_t w_total;  // B*N*L
   bool edge;        // true: the launch contains tiles that are not full (EDGE = true kernels)
   int wg_per_cu;    // 0: whatever fits; n > 0: at most n workgroups per CU (enforced by requesting more LDS)
-  float* wfar;      // training: link-major side copy of W's columns >= far_k0 ([B, L-far_k0, N]), or nullptr
-  int far_k0;
   hipStream_t stream;
 };
 

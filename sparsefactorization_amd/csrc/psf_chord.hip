@@ -43,14 +43,11 @@ int fail_hip(hipError_t e, const char* what) {
 std::atomic<int> g_fwd_variant{0};  // 0 auto, 1 generic, 2 window
 std::atomic<int> g_bwd_variant{0};  // 0 auto, 1 generic
 std::atomic<int> g_xcd_remap{1};
-std::atomic<int> g_fwd_rows{0};     // 0 = default, else rows per thread (R) of the window kernel
 // 1 = full tiles on the predicate-free kernel + the ragged last tiles in a second small launch, except on small
 // problems (one predicated launch); 2 = always two launches; 0 = always one predicated launch
 std::atomic<int> g_fwd_split{1};
-std::atomic<int> g_bwd_rows{0};     // 0 = default, else rows per thread (R) of the backward window kernels
-// dV workgroup: 0 = auto, 1 = 256 threads (rows per thread from bwd_rows), 2 = 512 threads x 1 row (TGS <= 3)
+// dV workgroup: 0 = auto (512 threads x 1 row for rows of <= 8 channels), 1 = 256 threads x 2 rows
 std::atomic<int> g_dv_threads{0};
-std::atomic<int> g_bwd_fused_nt{1};  // 1 = 256 threads (default: tile = 256 >> tgs rows), 0 = 512 threads
 std::atomic<int> g_bwd_fused{1};  // 0 = never, 1 = auto, 2 = wherever the fused step kernel applies
 std::atomic<int> g_dw_variant{0};   // dW: 0 = auto (chunk-looping kernel for C >= 32), 1 = whole-row window kernel, 2 = chunk forced
 std::atomic<int> g_dw_tgs{0};       // chunk-looping dW: 0 = auto, 4 = 8 lanes per row chunk, 5 = 16 lanes
@@ -90,12 +87,11 @@ struct Knob {
 };
 Knob g_knobs[] = {
     {"fwd_variant", &g_fwd_variant, 0, 2}, {"bwd_variant", &g_bwd_variant, 0, 1}, {"xcd_remap", &g_xcd_remap, 0, 1},
-    {"fwd_rows", &g_fwd_rows, 0, 8},       {"fwd_split", &g_fwd_split, 0, 2},     {"bwd_rows", &g_bwd_rows, 0, 8},
+    {"fwd_split", &g_fwd_split, 0, 2},
     {"fwd_wide", &g_fwd_wide, 0, 4},
     {"dw_variant", &g_dw_variant, 0, 2},
-    {"dv_threads", &g_dv_threads, 0, 2},
+    {"dv_threads", &g_dv_threads, 0, 1},
     {"bwd_fused", &g_bwd_fused, 0, 2},
-    {"bwd_fused_nt", &g_bwd_fused_nt, 0, 1},
     {"bwd_fused_wg_limit", &g_bwd_fused_wg_limit, 0, 5},
     {"dw_tgs", &g_dw_tgs, 0, 5},
     {"fwd_wg_limit", &g_fwd_wg_limit, 0, 4},
@@ -117,7 +113,7 @@ Knob g_knobs[] = {
 // a psf_set_tuning from another thread changes the next call, never the middle of one; `walk_backwards` (zigzag of a chain's
 // odd steps) travels in it too instead of in thread-local state.
 struct Tuning {
-  int fwd_variant, bwd_variant, xcd_remap, fwd_rows, fwd_split, bwd_rows, dv_threads, bwd_fused_nt, bwd_fused, dw_variant,
+  int fwd_variant, bwd_variant, xcd_remap, fwd_split, dv_threads, bwd_fused, dw_variant,
       dw_tgs, chain_fused, chain_cc, fwd_wide, fwd_wg_limit, bwd_fused_wg_limit, chain_zigzag, mixer_wg_limit, mixer_ablate, mixer_lds, bwd_ablate;
   bool walk_backwards;
 };
@@ -125,8 +121,8 @@ struct Tuning {
 Tuning snapshot() {
   Tuning t;
   t.fwd_variant = g_fwd_variant.load(), t.bwd_variant = g_bwd_variant.load(), t.xcd_remap = g_xcd_remap.load();
-  t.fwd_rows = g_fwd_rows.load(), t.fwd_split = g_fwd_split.load(), t.bwd_rows = g_bwd_rows.load();
-  t.dv_threads = g_dv_threads.load(), t.bwd_fused_nt = g_bwd_fused_nt.load(), t.bwd_fused = g_bwd_fused.load();
+  t.fwd_split = g_fwd_split.load();
+  t.dv_threads = g_dv_threads.load(), t.bwd_fused = g_bwd_fused.load();
   t.dw_variant = g_dw_variant.load(), t.dw_tgs = g_dw_tgs.load(), t.chain_fused = g_chain_fused.load();
   t.chain_cc = g_chain_cc.load(), t.fwd_wide = g_fwd_wide.load(), t.fwd_wg_limit = g_fwd_wg_limit.load();
   t.bwd_fused_wg_limit = g_bwd_fused_wg_limit.load(), t.chain_zigzag = g_chain_zigzag.load();
@@ -239,7 +235,6 @@ struct WinPick {
 
 hipError_t launch_win(const WinPick& pk, int L, const FwdWinArgs& a) {
   if (pk.nt == kWideThreads) return pk.tgs == kWideTgs ? launch_fwd_win<kWideTgs, kWideThreads>(pk.rows, L, a) : hipErrorInvalidValue;
-  if (pk.nt == kFwdMidThreads) return pk.tgs == kFwdMidTgs ? launch_fwd_win<kFwdMidTgs, kFwdMidThreads>(pk.rows, L, a) : hipErrorInvalidValue;
   PSF_TGS_SWITCH(launch_fwd_win, (pk.rows, L, a))
 }
 
@@ -249,8 +244,6 @@ hipError_t launch_dv(const WinPick& pk, int L, const BwdWinArgs& a) {
     switch (pk.tgs) {
       case 0: return launch_dv_win<0, kDvMidThreads>(pk.rows, L, a);
       case 1: return launch_dv_win<1, kDvMidThreads>(pk.rows, L, a);
-      case 2: return launch_dv_win<2, kDvMidThreads>(pk.rows, L, a);
-      case 3: return launch_dv_win<3, kDvMidThreads>(pk.rows, L, a);
       default: return hipErrorInvalidValue;
     }
   }
@@ -258,22 +251,22 @@ hipError_t launch_dv(const WinPick& pk, int L, const BwdWinArgs& a) {
 }
 #undef PSF_TGS_SWITCH
 
-hipError_t launch_fused_step(int tgs, int L, const BwdWinArgs& a, int nt) {
+hipError_t launch_fused_step(int tgs, int L, const BwdWinArgs& a) {
   switch (tgs) {
-    case 0: return launch_bwd_fused<0>(L, a, nt);
-    case 1: return launch_bwd_fused<1>(L, a, nt);
-    case 2: return launch_bwd_fused<2>(L, a, nt);
-    case 3: return launch_bwd_fused<3>(L, a, nt);
+    case 0: return launch_bwd_fused<0>(L, a);
+    case 1: return launch_bwd_fused<1>(L, a);
+    case 2: return launch_bwd_fused<2>(L, a);
+    case 3: return launch_bwd_fused<3>(L, a);
     default: return hipErrorInvalidValue;
   }
 }
 
-hipError_t launch_fused_edge_step(int tgs, int L, const BwdWinArgs& a, int nt) {
+hipError_t launch_fused_edge_step(int tgs, int L, const BwdWinArgs& a) {
   switch (tgs) {
-    case 0: return launch_bwd_fused_edge<0>(L, a, nt);
-    case 1: return launch_bwd_fused_edge<1>(L, a, nt);
-    case 2: return launch_bwd_fused_edge<2>(L, a, nt);
-    case 3: return launch_bwd_fused_edge<3>(L, a, nt);
+    case 0: return launch_bwd_fused_edge<0>(L, a);
+    case 1: return launch_bwd_fused_edge<1>(L, a);
+    case 2: return launch_bwd_fused_edge<2>(L, a);
+    case 3: return launch_bwd_fused_edge<3>(L, a);
     default: return hipErrorInvalidValue;
   }
 }
@@ -286,7 +279,7 @@ bool pick_fused_edge_step(const Tuning& tn, const void* dZ, const void* V, const
                           int64_t v_bstride, const Offsets& offs, WinPick* pk) {
   if (tn.bwd_fused != 1 || L < kWinLmin || L > kWinLmax || (C != 4 && C != 8 && C != 16 && C != 32)) return false;
   const int tgs = C == 4 ? 0 : C == 8 ? 1 : C == 16 ? 2 : 3;
-  const int nt = tn.bwd_fused_nt ? 256 : kDvMidThreads;
+  const int nt = 256;
   const int TR = nt >> tgs;
   if (N < 2 * (int64_t)TR) return false;
   if (!aligned_to(dZ, 16) || !aligned_to(V, 16) || !aligned_to(dV, 16)) return false;
@@ -302,13 +295,13 @@ bool pick_fused_edge_step(const Tuning& tn, const void* dZ, const void* V, const
 }
 
 // The fused dV + dW step (bwd_fused.h) applies to full tiles of narrow rows: C = 4 << tgs with tgs <= 3, N a multiple of
-// the tile (512 >> tgs rows) and at least two tiles, chord near offsets, everything 16-byte aligned and chunk-clean.
+// the tile (256 >> tgs rows) and at least two tiles, chord near offsets, everything 16-byte aligned and chunk-clean.
 bool pick_fused_step(const Tuning& tn, const void* dZ, const void* W, const void* V, const void* dW, const void* dV, int64_t B, int64_t N,
                      int32_t L, int64_t C, int64_t v_bstride, const Offsets& offs, WinPick* pk) {
   const int knob = tn.bwd_fused;
   if (!knob || L < kWinLmin || L > kWinLmax || (C != 4 && C != 8 && C != 16 && C != 32)) return false;
   const int tgs = C == 4 ? 0 : C == 8 ? 1 : C == 16 ? 2 : 3;
-  const int nt = tn.bwd_fused_nt ? 256 : kDvMidThreads;
+  const int nt = 256;
   const int TR = nt >> tgs;
   if (N % TR != 0 || N < 2 * (int64_t)TR) return false;
   if (!aligned_to(dZ, 16) || !aligned_to(W, 16) || !aligned_to(V, 16) || !aligned_to(dW, 16) || !aligned_to(dV, 16)) return false;
@@ -396,8 +389,7 @@ bool pick_window(const Tuning& tn, const void* W, int64_t B, int64_t N, int32_t 
   const int64_t CG = C / 4;
   int tgs = ceil_log2(CG) > kWinTgsMax ? kWinTgsMax : ceil_log2(CG);
   int nt = 256;
-  int rows = rows_pref;
-  if (rows <= 0 || !win_rows_compiled(rows)) rows = win_default_rows(tgs);
+  int rows = rows_pref;  // 2 (forward, dV) or 1 (dW): the compiled rows per thread (fwd_window_launch.h)
   const int wide = tn.fwd_wide;
   // Forward, rows of 64..256 channels, sequences up to 4096: 32-channel chunks on 1024-thread workgroups (256-row tiles: two
   // far links at L = 12 instead of five to seven). With the scalar block addresses of round 4 they beat the whole-row tiles that
@@ -408,9 +400,6 @@ bool pick_window(const Tuning& tn, const void* W, int64_t B, int64_t N, int32_t 
   if (chunk_channels && (wide == 1 || auto_wide) && CG >= 16 && N >= 2 * (int64_t)win_tile_rows(kWideTgs, rows, kWideThreads)) {
     tgs = kWideTgs;  // 32-channel chunks on 1024-thread workgroups
     nt = kWideThreads;
-  } else if (forward && wide == 3 && CG == 8 && N >= 2 * (int64_t)win_tile_rows(kFwdMidTgs, rows, kFwdMidThreads)) {
-    tgs = kFwdMidTgs;  // rows of exactly 32 channels on 512-thread workgroups (forward only)
-    nt = kFwdMidThreads;
   } else if (chunk_channels && wide == 2 && CG >= 16) {
     tgs = kWideTgs;  // 32-channel chunks on 256-thread workgroups
   } else if (nt_pref == kDvMidThreads && tgs <= kDvMidTgsMax && N >= 2 * (int64_t)win_tile_rows(tgs, 1, kDvMidThreads)) {
@@ -440,14 +429,13 @@ bool pick_window(const Tuning& tn, const void* W, int64_t B, int64_t N, int32_t 
   return true;
 }
 
-// The dV window kernel's configuration for a shape (also what psf_chord_bwd_far_first_link reports).
+// The dV window kernel's configuration for a shape.
 // default rows per thread (r01 sweep, us at cfg2): dV R=2 31.3 vs R=1 32.7; 512 threads x 1 row per thread instead of
 // 256 x 2 is the same tile at C <= 8 (r02 lab 28.65 vs 29.05 us at cfg2)
 bool pick_dv(const Tuning& tn, const void* W, int64_t B, int64_t N, int32_t L, int64_t C, const Offsets& offs, bool vec_ok, WinPick* pk) {
-  const int knob = tn.bwd_rows;
   const int dvt = tn.dv_threads;
-  const int nt_dv = (dvt == 2 || (dvt == 0 && !knob && C <= 8)) ? kDvMidThreads : 0;
-  return pick_window(tn, W, B, N, L, C, offs, vec_ok, pk, knob ? knob : 2, true, nt_dv);
+  const int nt_dv = (dvt == 0 && C <= 8) ? kDvMidThreads : 0;
+  return pick_window(tn, W, B, N, L, C, offs, vec_ok, pk, 2, true, nt_dv);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -484,11 +472,8 @@ int window_launches(const Tuning& tn, const WinPick& pk, bool all_edge, int64_t 
 }
 
 int fwd_window_f32(const Tuning& tn, const WinPick& pk, const float* W, const float* V, const float* res, float* out, int64_t B,
-                   int64_t N, int32_t L, int64_t C, int64_t v_batch_stride, const Offsets& offs, hipStream_t s,
-                   float* wfar, int far_k0) {
+                   int64_t N, int32_t L, int64_t C, int64_t v_batch_stride, const Offsets& offs, hipStream_t s) {
   FwdWinArgs a;
-  a.wfar = wfar;
-  a.far_k0 = far_k0;
   a.W = W;
   a.V = V;
   a.res = res;
@@ -514,13 +499,9 @@ int fwd_window_f32(const Tuning& tn, const WinPick& pk, const float* W, const fl
                          [&] { return launch_win(pk, L, a); }, "chord_fwd_win launch");
 }
 
-// `wfar` (f32 only): ask the step to leave the link-major side copy of W's columns >= far_k0; *copied reports
-// whether the kernel that ran could write it.
 template <typename T>
 int fwd_impl(const Tuning& tn, const T* W, const T* V, const T* res, T* out, int64_t B, int64_t N, int32_t L, int64_t C,
-             int64_t v_batch_stride, const int64_t* offsets, void* stream, T* wfar = nullptr, int far_k0 = 0,
-             bool* copied = nullptr) {
-  if (copied) *copied = false;
+             int64_t v_batch_stride, const int64_t* offsets, void* stream) {
   if (int rc = check_dims(B, N, L, C, v_batch_stride)) return rc;
   if (B == 0) return PSF_OK;
   if (!W || !V || !out) return fail(PSF_E_NULL, "W, V and out must be non-NULL");
@@ -539,11 +520,8 @@ int fwd_impl(const Tuning& tn, const T* W, const T* V, const T* res, T* out, int
   const int variant = tn.fwd_variant;
   if constexpr (sizeof(T) == 4) {  // the window kernels are compiled for f32 only (f64 exists for gradcheck)
     WinPick pk;
-    if (variant != 1 && pick_window(tn, W, B, N, L, C, offs, vec_ok, &pk, tn.fwd_rows, true, 0, true)) {
-      const bool emit = wfar != nullptr && far_k0 >= 0 && far_k0 < L;
-      if (copied) *copied = emit;
-      return fwd_window_f32(tn, pk, W, V, res, out, B, N, L, C, v_batch_stride, offs, s, emit ? wfar : nullptr, far_k0);
-    }
+    if (variant != 1 && pick_window(tn, W, B, N, L, C, offs, vec_ok, &pk, 2, true, 0, true))
+      return fwd_window_f32(tn, pk, W, V, res, out, B, N, L, C, v_batch_stride, offs, s);
   }
   if (variant == 2)
     return fail(PSF_E_TUNING, "fwd_variant=2 forced but the window kernel does not apply to N=%lld L=%d C=%lld",
@@ -562,7 +540,7 @@ int fwd_impl(const Tuning& tn, const T* W, const T* V, const T* res, T* out, int
 
 template <typename T>
 int bwd_impl(const Tuning& tn, const T* dZ, const T* W, const T* V, T* dW, T* dV, int64_t B, int64_t N, int32_t L, int64_t C,
-             int64_t v_batch_stride, const int64_t* offsets, void* stream, const T* wfar = nullptr, int far_k0 = 0) {
+             int64_t v_batch_stride, const int64_t* offsets, void* stream) {
   if (int rc = check_dims(B, N, L, C, v_batch_stride)) return rc;
   if (B == 0) return PSF_OK;
   if (!dZ) return fail(PSF_E_NULL, "dZ must be non-NULL");
@@ -583,8 +561,7 @@ int bwd_impl(const Tuning& tn, const T* dZ, const T* W, const T* V, T* dW, T* dV
       const int TGmax = 1 << kWinTgsMax;
       WinPick pk;
       // default rows per thread (r01 sweep, us at cfg2): dV R=2 31.3 vs R=1 32.7; dW R=1 22.9 vs R=2 28.7
-      const int knob = tn.bwd_rows;
-      const int rows_dw = knob ? knob : 1;
+      const int rows_dw = 1;
       // dW before dV: dV's output is the next (earlier) step's dZ, read first thing by that step's kernels; writing
       // it last leaves it cache-hot (dV 27.4 -> 26.9 us, dW 20.5 -> 20.4 us in the Order training step)
       const int dwv = tn.dw_variant;
@@ -597,23 +574,19 @@ int bwd_impl(const Tuning& tn, const T* dZ, const T* W, const T* V, T* dW, T* dV
         // tiles (N = 4096, C = 16, B = 64) 26.6 / 25.4; 2048 tiles 12.6 / 13.5 and 14.7 / 15.0: three from 4096 tiles on.
         a.wg_per_cu = tn.bwd_fused_wg_limit ? tn.bwd_fused_wg_limit : (B * (int64_t)pk.tiles_full >= 4096 ? 3 : 0);
         a.ablate = tn.bwd_ablate;
-        if (wfar != nullptr && far_k0 >= 0 && far_k0 <= pk.KN && pk.KN < L) {
-          a.wfar = wfar;
-          a.far_k0 = far_k0;
-        }
         if (int rc = make_geom(tn, B, N, L, C, 4, pk.tgs, pk.TR, false, v_batch_stride, 0, pk.tiles_full, &a.gm)) return rc;
-        hipError_t e = launch_fused_step(pk.tgs, L, a, pk.nt);
+        hipError_t e = launch_fused_step(pk.tgs, L, a);
         if (e != hipSuccess) return fail_hip(e, "chord_bwd_fused");
         dW = nullptr;
         dV = nullptr;
       }
-      if (dW && dV && wfar == nullptr && pick_fused_edge_step(tn, dZ, V, dV, N, L, C, v_batch_stride, offs, &pk)) {
+      if (dW && dV && pick_fused_edge_step(tn, dZ, V, dV, N, L, C, v_batch_stride, offs, &pk)) {
         BwdWinArgs a{dZ, W, dV, Geom{}, offs, w_total, true, s};
         a.V2 = V;
         a.out2 = dW;
         if (int rc = make_geom(tn, B, N, L, C, 4, pk.tgs, pk.TR, false, v_batch_stride, 0, pk.tiles_full + (pk.ragged ? 1 : 0), &a.gm))
           return rc;
-        hipError_t e = launch_fused_edge_step(pk.tgs, L, a, pk.nt);
+        hipError_t e = launch_fused_edge_step(pk.tgs, L, a);
         if (e != hipSuccess) return fail_hip(e, "chord_bwd_fused_edge");
         dW = nullptr;
         dV = nullptr;
@@ -642,10 +615,6 @@ int bwd_impl(const Tuning& tn, const T* dZ, const T* W, const T* V, T* dW, T* dV
       }
       if (dV && pick_dv(tn, W, B, N, L, C, offs, (C % 4 == 0) && aligned_to(dZ, 16) && aligned_to(dV, 16), &pk)) {
         BwdWinArgs a{dZ, W, dV, Geom{}, offs, w_total, false, s};
-        if (wfar != nullptr && far_k0 >= 0 && far_k0 <= pk.KN && pk.KN < L) {  // the copy covers every far link
-          a.wfar = wfar;
-          a.far_k0 = far_k0;
-        }
         int rc = window_launches(tn, pk, pk.all_edge, B, N, L, C, N * C, true, &a.gm, &a.edge,
                                  [&] { return launch_dv(pk, L, a); }, "chord_dv_win");
         if (rc) return rc;
@@ -682,8 +651,7 @@ int bwd_impl(const Tuning& tn, const T* dZ, const T* W, const T* V, T* dW, T* dV
 template <typename T>
 int chain_impl(Tuning tn, const T* const* W_steps, const T* V0, T* const* out_steps, int32_t M, int32_t use_residual,
                int64_t B, int64_t N, int32_t L, int64_t C, int64_t v0_batch_stride, const int64_t* offsets,
-               void* stream, T* const* wfar_steps = nullptr, int far_k0 = 0, uint64_t* copied_mask = nullptr) {
-  if (copied_mask) *copied_mask = 0;
+               void* stream) {
   if (M < 0) return fail(PSF_E_SHAPE, "M must be >= 0");
   if (M == 0) return PSF_OK;
   if (!W_steps || !out_steps || !V0) return fail(PSF_E_NULL, "W_steps, out_steps and V0 must be non-NULL");
@@ -757,11 +725,8 @@ int chain_impl(Tuning tn, const T* const* W_steps, const T* V0, T* const* out_st
     // zigzag: every XCD walks its tile range forwards on even steps and backwards on odd ones, so a launch begins
     // with the tiles whose inputs the previous launch wrote LAST (still in that XCD's L2), not first
     tn.walk_backwards = (m & 1) != 0;
-    bool copied = false;
-    int rc = fwd_impl<T>(tn, W_steps[m], in, use_residual ? V0 : nullptr, out_steps[m], B, N, L, C, stride, offsets,
-                         stream, wfar_steps ? wfar_steps[m] : nullptr, far_k0, &copied);
+    int rc = fwd_impl<T>(tn, W_steps[m], in, use_residual ? V0 : nullptr, out_steps[m], B, N, L, C, stride, offsets, stream);
     if (rc) return rc;
-    if (copied && copied_mask && m < 64) *copied_mask |= (uint64_t)1 << m;
   }
   return PSF_OK;
 }
@@ -918,39 +883,6 @@ int psf_chord_chain_fwd_f64(const double* const* W_steps, const double* V0, doub
   return chain_impl<double>(snapshot(), W_steps, V0, out_steps, M, use_residual, B, N, L, C, v0_batch_stride, offsets, stream);
 }
 
-int32_t psf_chord_bwd_far_first_link(int64_t B, int64_t N, int32_t L, int64_t C) {
-  if (int rc = check_dims(B, N, L, C, N * C)) return rc;
-  const Tuning tn = snapshot();
-  if (tn.bwd_variant == 1 || C % 4 != 0) return L;
-  Offsets offs;
-  make_offsets(N, L, nullptr, &offs);
-  WinPick pk;
-  // a step that wants both gradients may run the fused kernel, whose tile (and first far link) can be shorter than the
-  // dV kernel's: the copy must cover the far links of either
-  int k0 = L;
-  if (pick_fused_step(tn, nullptr, nullptr, nullptr, nullptr, nullptr, B, N, L, C, N * C, offs, &pk) && pk.KN < k0) k0 = pk.KN;
-  if (pick_dv(tn, nullptr, B, N, L, C, offs, true, &pk) && pk.KN < k0) k0 = pk.KN;
-  return k0;
-}
-
-int psf_chord_chain_fwd_far_f32(const float* const* W_steps, const float* V0, float* const* out_steps,
-                                float* const* wfar_steps, int32_t far_k0, uint64_t* copied_mask, int32_t M,
-                                int32_t use_residual, int64_t B, int64_t N, int32_t L, int64_t C,
-                                int64_t v0_batch_stride, const int64_t* offsets, void* stream) {
-  if (wfar_steps && (far_k0 < 0 || far_k0 > L)) return fail(PSF_E_SHAPE, "far_k0 must be in [0, L]");
-  if (wfar_steps && M > 64) return fail(PSF_E_SHAPE, "the far-column side copy is reported for at most 64 steps");
-  // short sequences still take the single-launch LDS chain (forward speed first); it writes no copy: mask stays 0
-  return chain_impl<float>(snapshot(), W_steps, V0, out_steps, M, use_residual, B, N, L, C, v0_batch_stride, offsets, stream,
-                           (wfar_steps && far_k0 < L) ? wfar_steps : nullptr, far_k0, copied_mask);
-}
-
-int psf_chord_spmm_bwd_far_f32(const float* dZ, const float* W, const float* V, float* dW, float* dV, int64_t B,
-                               int64_t N, int32_t L, int64_t C, int64_t v_batch_stride, const int64_t* offsets,
-                               const float* w_far, int32_t far_k0, void* stream) {
-  if (w_far && !aligned_to(w_far, 4)) return fail(PSF_E_ALIGN, "w_far must be aligned to the element size");
-  return bwd_impl<float>(snapshot(), dZ, W, V, dW, dV, B, N, L, C, v_batch_stride, offsets, stream, w_far, far_k0);
-}
-
 int64_t psf_mixer_fwd_workspace(int64_t N, int32_t E, int32_t M, const int32_t* h, int64_t C, int32_t L) {
   MixerPlan mp;
   if (!plan_mixer(N, E, M, h, C, L, &mp)) return -1;
@@ -1037,6 +969,10 @@ int psf_mixer_fwd_in_f32(const psf_mixer_input* in, int64_t B, int64_t N, int32_
     if (e != hipSuccess) return fail_hip(e, "chord_mixer_lds launch");
     return PSF_OK;
   }
+  if (in->kind != PSF_MIXER_IN_DATA)
+    return fail(PSF_E_SHAPE, "psf_mixer_fwd: an input recipe (kind %d) is evaluated by the single-launch kernel only (short sequences, "
+                "psf_mixer_fwd_plan() == 2); for N=%lld write the rows with psf_affine_rows_f32 / psf_embed_tokens_f32 and pass them",
+                (int)in->kind, (long long)N);
   if (!mp.step_ok)
     return fail(PSF_E_TUNING, "psf_mixer_fwd: mixer_lds=0 but only the LDS-resident kernel covers N=%lld C=%lld", (long long)N, (long long)C);
   // the tile geometry of every launch below
@@ -1127,7 +1063,7 @@ int psf_describe_fwd(int64_t B, int64_t N, int32_t L, int64_t C, int32_t elem_by
   WinPick pk;
   const Tuning tn = snapshot();
   const int variant = tn.fwd_variant;
-  if (variant != 1 && elem_bytes == 4 && pick_window(tn, nullptr, B, N, L, C, offs, vec_ok, &pk, tn.fwd_rows, true, 0, true)) {
+  if (variant != 1 && elem_bytes == 4 && pick_window(tn, nullptr, B, N, L, C, offs, vec_ok, &pk, 2, true, 0, true)) {
     snprintf(buf, cap, "chord_fwd_win_k<f32,L=%d,TG=%d,R=%d,NT=%d> TR=%d near=%d far=%d tiles=%s", (int)L,
              1 << pk.tgs, pk.rows, pk.nt, pk.TR, pk.KN, (int)L - pk.KN,
              pk.all_edge ? "edge" : (pk.ragged ? "full+ragged" : (pk.aligned ? "full, aligned (scalar block addresses)" : "full")));

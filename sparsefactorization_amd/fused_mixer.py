@@ -22,24 +22,20 @@ enabled = True  # module-level switch (tests / A-B timing)
 #: weight image per tile, 14 KB per 32 hidden rows, which short tiles (C = 32: 64 rows) and 128-wide hidden layers do not
 #: amortise — and the short sequences that run as one LDS-resident launch); "always": wherever the shape is covered; "never".
 route = "auto"
-#: Evaluate the embedding lookup inside the mixer kernels (Recipe.tokens) instead of materialising ``data`` with
-#: psf_embed_tokens_f32 first. Off: the lookup makes the table and positional loads depend on the token load, which lengthens
-#: every workgroup's load phase — 712 against 609 + 28 us at Temporal Order's shape (N = 16384, B = 40), 1040 against 885 + 42 at
-#: B = 64 (profiles/r04h_mixer_bench.log).
-tokens_in_kernel = False
-#: Evaluate the affine input layer (Recipe.affine: Adding's init_linear) inside the mixer kernels instead of writing ``data``
-#: with psf_affine_rows_f32 (one 25 us pass) first. Off since the step kernel's request phase went on its instruction diet
-#: (round 4): reading the 128-byte data row costs it ~150 vector instructions per wave, evaluating 32 features from two inputs
-#: ~375, and the vector unit is what bounds that kernel — PSFNet forward at N = 16384, B = 64: 0.97 ms with the recipe in the
-#: kernels, 0.82 with the rows written once (bench.py e2e_forward; the Order network, whose rows come from
-#: psf_embed_tokens_f32, is the same kernel sequence).
-affine_in_kernel = False
+#: Hand the single-launch kernel (short sequences, csrc/mixer_lds.h) the RECIPE of ``data`` — the affine input layer or the
+#: embedding lookup, include/psf_chord.h: psf_mixer_input — instead of its rows. Off: ``data`` is written once
+#: (psf_affine_rows_f32 / psf_embed_tokens_f32) and passed as rows. The per-step kernels take rows only: evaluating a recipe
+#: inside them measured slower than the one pass that writes the rows (712 against 609 + 28 us at Temporal Order's shape,
+#: 0.97 against 0.82 ms per Adding forward; profiles/r04h_mixer_bench.log, r04w_bench_stdout.log) and round 5 removed those
+#: instances (two thirds of that translation unit).
+recipe_in_kernel = False
 
 
 class Recipe:
     """How ``data`` [B, N, E] comes about (include/psf_chord.h: psf_mixer_input): given (``data``), an affine map of a few
     inputs per position (``affine``: init_linear of the Adding network, psf.py:153-154) or an embedding lookup (``tokens``:
-    psf.py:151-152), each optionally plus a positional row. With the last two, ``data`` is never written to memory."""
+    psf.py:151-152), each optionally plus a positional row. The single-launch kernel evaluates the last two itself (``data``
+    is then never written); for the per-step kernels ``rows()`` writes it once."""
 
     def __init__(self, kind, src, weight=None, bias=None, pos=None, K=0, E=None):
         self.kind, self.src, self.weight, self.bias, self.pos, self.K = kind, src, weight, bias, pos, K
@@ -67,6 +63,17 @@ class Recipe:
 
     def tensors(self):
         return [t for t in (self.src, self.weight, self.bias, self.pos) if t is not None]
+
+    def rows(self) -> torch.Tensor:
+        """``data`` [B, N, E] written once: psf_affine_rows_f32 / psf_embed_tokens_f32 (+ the positional rows)."""
+        from .token_linear import _EmbedTokensFn, affine_rows
+        if self.kind == _lib.MIXER_IN_DATA:
+            return self.src
+        with torch.no_grad():
+            if self.kind == _lib.MIXER_IN_AFFINE:
+                x = affine_rows(self.src, self.weight, self.bias)
+                return x if self.pos is None else x + self.pos.unsqueeze(0)
+            return _EmbedTokensFn.apply(self.src, self.weight, self.pos, None)
 
     def ok(self):
         """Shapes and dtypes the library takes; anything else makes the caller materialise ``data`` instead."""
@@ -113,10 +120,6 @@ def eligible_recipe(r: Recipe, g: nn.Module, fs: Sequence[nn.Module]) -> bool:
     """The fused mixer can run from this recipe, nothing needs a gradient, and ``route`` wants it."""
     if not enabled or not r.ok() or torch.is_grad_enabled() and any(t.requires_grad for t in r.tensors() if t.is_floating_point()):
         return False
-    if r.kind == _lib.MIXER_IN_TOKENS and not tokens_in_kernel:
-        return False
-    if r.kind == _lib.MIXER_IN_AFFINE and not affine_in_kernel:
-        return False
     if _needs_grad(torch.empty(0), [g, *fs]):
         return False
     sz = _block_sizes(r.E, g, fs)
@@ -132,6 +135,8 @@ def mixer_forward_in(r: Recipe, g: nn.Module, fs: Sequence[nn.Module], use_resid
     B, N, E = r.B, r.N, r.E
     dev = r.src.device
     lib = _lib.load()
+    if r.kind != _lib.MIXER_IN_DATA and not (recipe_in_kernel and lib.psf_mixer_fwd_plan(N, E, M, h, C, L) == 2):
+        r = Recipe.data(r.rows())  # the per-step kernels take rows (psf_mixer_fwd_plan: 2 = the single-launch kernel runs)
 
     def prep(t, align):
         if t is None:

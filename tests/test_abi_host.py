@@ -121,11 +121,11 @@ def test_entry_points_are_callable_from_two_threads_at_once(lib):
 
     def knob_worker():
         for i in range(3000):
-            if lib.psf_set_tuning(b"fwd_rows", i & 1) != 0:
+            if lib.psf_set_tuning(b"xcd_remap", i & 1) != 0:
                 errors.append("set_tuning")
             if lib.psf_chord_spmm_fwd_f32(None, one, None, two, 1, 8, 4, 4, 32, None, None) != -1 or b"non-NULL" not in lib.psf_last_error():
                 errors.append("null message")
-        lib.psf_set_tuning(b"fwd_rows", 0)
+        lib.psf_set_tuning(b"xcd_remap", 1)
 
     threads = [threading.Thread(target=f) for f in (offsets_worker, validation_worker, knob_worker)]
     for t in threads:

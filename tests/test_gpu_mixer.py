@@ -120,9 +120,10 @@ RECIPE_CASES = [
 
 @pytest.mark.parametrize("name,kind,B,N,E,h,C,L,M,residual,with_pos,K", RECIPE_CASES, ids=[c[0] for c in RECIPE_CASES])
 def test_mixer_from_the_recipe_of_data_matches_the_float64_reference(gpu, name, kind, B, N, E, h, C, L, M, residual, with_pos, K):
-    """psf_mixer_fwd_in_f32: `data` is never materialised — the kernels evaluate the rows they need from the affine input
-    layer (init_linear, psf.py:153-154) or the embedding lookup (+ positional rows, psf.py:151-162). Reference: data in
-    float64 from the same raw inputs, the MLPs in float64, the oracle's f32 chain."""
+    """The mixer from the RECIPE of `data` — the affine input layer (init_linear, psf.py:153-154) or the embedding lookup
+    (+ positional rows, psf.py:151-162): rows written once for the per-step kernels, evaluated in place by the single-launch
+    kernel (psf_mixer_fwd_in_f32; the two cfg1 cases). Reference: data in float64 from the same raw inputs, the MLPs in
+    float64, the oracle's f32 chain."""
     from sparsefactorization_amd import fused_mixer
     g, fs = _blocks(E, h, C, L, M, seed=21)
     gen = torch.Generator().manual_seed(8)
@@ -148,9 +149,15 @@ def test_mixer_from_the_recipe_of_data_matches_the_float64_reference(gpu, name, 
         r = fused_mixer.Recipe.tokens(inp.to(gpu), table.to(gpu), posd)
     with torch.no_grad():
         assert r.ok()
-        got = fused_mixer.mixer_forward_in(r, g, fs, residual).cpu().numpy()
+        got = fused_mixer.mixer_forward_in(r, g, fs, residual).cpu().numpy()  # rows written once, then the mixer
+        fused_mixer.recipe_in_kernel = True  # short sequences: the single-launch kernel evaluates the recipe itself
+        try:
+            got_k = fused_mixer.mixer_forward_in(r, g, fs, residual).cpu().numpy()
+        finally:
+            fused_mixer.recipe_in_kernel = False
     assert np.isfinite(got).all()
     assert rel_inf(got, want) <= TOL, f"{name}: rel {rel_inf(got, want):.3e}"
+    assert rel_inf(got_k, want) <= TOL, f"{name} (recipe in the kernel): rel {rel_inf(got_k, want):.3e}"
 
 
 @pytest.mark.parametrize("K,E,bias", [(2, 32, True), (1, 8, True), (3, 12, False)])
@@ -279,13 +286,11 @@ def test_nets_take_the_fused_mixer_in_inference_and_agree_with_the_unfused_route
             import sparsefactorization_amd.psfnet as pn
             pn.chord_chain = spy
             fused_mixer.route = "always"  # (the automatic rule keeps the Pathfinder widths on the W-through-memory route)
-            fused_mixer.tokens_in_kernel = True
             try:
                 got = net(x)
             finally:
                 pn.chord_chain = orig
                 fused_mixer.route = "auto"
-                fused_mixer.tokens_in_kernel = False
         assert not calls, "the fused mixer path must not run the W-from-memory chain"
         assert rel_inf(got.cpu().numpy(), want.cpu().numpy()) <= 1e-5
         net.train()  # dropout active / gradients wanted: the fused inference path must step aside

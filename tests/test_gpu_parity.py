@@ -55,19 +55,6 @@ def test_forward_step_bit_exact(gpu, B, N, L, C, variant):
         sfa.set_tuning("fwd_variant", 0)
 
 
-@pytest.mark.parametrize("rows", [1, 2, 4, 8])
-@pytest.mark.parametrize("B,N,L,C", [(2, 16384, 15, 8), (2, 2000, 12, 32), (2, 2048, 12, 128), (3, 1100, 11, 8)])
-def test_forward_window_rows_variants(gpu, B, N, L, C, rows):
-    import sparsefactorization_amd as sfa
-    W, V, R = _mk((B, N, L), 4), _mk((B, N, C), 5), _mk((B, N, C), 6)
-    sfa.set_tuning("fwd_rows", rows)
-    try:
-        got = sfa.chord_spmm(_t(W, gpu), _t(V, gpu), _t(R, gpu)).cpu().numpy()
-    finally:
-        sfa.set_tuning("fwd_rows", 0)
-    assert np.array_equal(got, _oracle_fwd(W, V, R))
-
-
 @pytest.mark.parametrize("split", [0, 1, 2])  # one predicated launch / auto / full tiles + ragged tiles in two launches
 @pytest.mark.parametrize("B,N,L,C,shift", [(3, 1101, 11, 8, 0), (3, 1101, 11, 8, 1), (2, 2000, 12, 16, 3),
                                            (1, 515, 9, 32, 2), (5, 777, 13, 8, 1)])
@@ -252,10 +239,11 @@ BWD_WIN_SHAPES = [(3, 16384, 15, 8), (2, 2048, 12, 64), (2, 1101, 11, 8), (2, 20
                   (2, 1024, 12, 32), (2, 777, 9, 16), (2, 640, 10, 260), (5, 1000, 7, 4), (2, 515, 20, 24)]
 
 
-@pytest.mark.parametrize("rows", [1, 2])
+@pytest.mark.parametrize("dv_threads", [0, 1])  # dV: automatic (512 threads x 1 row for C <= 8) / 256 threads x 2 rows
 @pytest.mark.parametrize("B,N,L,C", BWD_WIN_SHAPES)
-def test_backward_window_kernels(gpu, B, N, L, C, rows):
-    """LDS-window dV / dW kernels (full, ragged and all-edge launches) vs the oracle and vs the generic kernels."""
+def test_backward_window_kernels(gpu, B, N, L, C, dv_threads):
+    """LDS-window dV / dW kernels (full, ragged and all-edge launches; the fused step switched off) vs the oracle and vs the
+    generic kernels."""
     import sparsefactorization_amd as sfa
     from sparsefactorization_amd.chord import _launch_bwd
     W, V, dZ = _mk((B, N, L), 41), _mk((B, N, C), 42), _mk((B, N, C), 43)
@@ -264,7 +252,8 @@ def test_backward_window_kernels(gpu, B, N, L, C, rows):
     got = {}
     for variant in (0, 1):
         sfa.set_tuning("bwd_variant", variant)
-        sfa.set_tuning("bwd_rows", rows)
+        sfa.set_tuning("dv_threads", dv_threads)
+        sfa.set_tuning("bwd_fused", 0)
         try:
             gW = torch.full_like(Wt, float("nan"))
             gV = torch.full_like(Vt, float("nan"))
@@ -272,7 +261,8 @@ def test_backward_window_kernels(gpu, B, N, L, C, rows):
             got[variant] = (gW.cpu().numpy(), gV.cpu().numpy())
         finally:
             sfa.set_tuning("bwd_variant", 0)
-            sfa.set_tuning("bwd_rows", 0)
+            sfa.set_tuning("dv_threads", 0)
+            sfa.set_tuning("bwd_fused", 1)
     for variant, (gW, gV) in got.items():
         assert np.array_equal(gV, dV), f"dV variant={variant}"
         assert rel_inf(gW, dF) <= TOL, f"dW variant={variant}"
@@ -348,29 +338,6 @@ def test_backward_dw_chunk_kernel_is_the_default_for_wide_rows(gpu):
                     _launch_bwd(*args)
     finally:
         sfa.set_tuning("dw_variant", 0)
-
-
-@pytest.mark.parametrize("B,N,L,C", [(2, 16384, 15, 32), (2, 4097, 13, 32), (3, 1024, 11, 32), (2, 300, 9, 32)])
-def test_rows_of_32_channels_on_512_thread_tiles(gpu, B, N, L, C):
-    """fwd_wide = 3: the forward step (with and without residual) on 512-thread workgroups, 128-row tiles, bit for bit; the
-    backward is not affected by the knob."""
-    import sparsefactorization_amd as sfa
-    from sparsefactorization_amd.chord import _launch_bwd
-    W, V, R, dZ = _mk((B, N, L), 71), _mk((B, N, C), 72), _mk((B, N, C), 73), _mk((B, N, C), 74)
-    sfa.set_tuning("fwd_wide", 3)
-    try:
-        desc = sfa.describe_fwd(B, N, L, C)
-        got = sfa.chord_spmm(_t(W, gpu), _t(V, gpu), _t(R, gpu)).cpu().numpy()
-        got_nores = sfa.chord_spmm(_t(W, gpu), _t(V, gpu)).cpu().numpy()
-        gV = torch.full((B, N, C), float("nan"), device=gpu)
-        _launch_bwd(_t(dZ, gpu), _t(W, gpu), _t(V, gpu), None, gV, B, N, L, C, N * C, None)
-    finally:
-        sfa.set_tuning("fwd_wide", 0)
-    if N >= 512:
-        assert "NT=512" in desc, desc
-    assert np.array_equal(got, _oracle_fwd(W, V, R)), desc
-    assert np.array_equal(got_nores, _oracle_fwd(W, V)), desc
-    assert np.array_equal(gV.cpu().numpy(), oc.spmul_bwd(dZ, W, V)[1])
 
 
 @pytest.mark.parametrize("wide", [1, 2])
@@ -695,69 +662,6 @@ def test_chain_backward_residual_gradient_one_pass_sum(gpu):
     assert rel_inf(V0a.grad.cpu().numpy(), V0b.grad.cpu().numpy()) <= 1e-6  # autograd adds the M+1 terms in its own order
 
 
-FAR_SHAPES = [(2, 16384, 15, 8), (3, 4097, 13, 8), (2, 5000, 14, 32), (2, 8192, 14, 128), (1, 16385, 15, 16)]
-
-
-@pytest.mark.parametrize("B,N,L,C", FAR_SHAPES)
-def test_far_column_side_copy(gpu, B, N, L, C):
-    """Training forward steps leave w_far[b][k-k0][n] = W[b][n][k] for the links the dV kernel treats as far
-    (include/psf_chord.h, psf_chord_chain_fwd_far_f32); dV computed with that copy is bit-identical to dV without it
-    and to the oracle; full, ragged (N % tile != 0) and wide-row launches."""
-    import ctypes
-    import sparsefactorization_amd as sfa
-    from sparsefactorization_amd import _lib
-    from sparsefactorization_amd.chord import _launch_bwd
-    lib = _lib.load()
-    k0 = lib.psf_chord_bwd_far_first_link(B, N, L, C)
-    assert 2 <= k0 < L, k0
-    M = 3
-    W = [_mk((B, N, L), 110 + m, 0.3) for m in range(M)]
-    V0 = _mk((B, N, C), 120)
-    Wt = [_t(w, gpu) for w in W]
-    V0t = _t(V0, gpu)
-    outs = [torch.empty(B, N, C, device=gpu) for _ in range(M)]
-    fars = [torch.full((B, L - k0, N), float("nan"), device=gpu) if m != 1 else None for m in range(M)]  # step 1: no copy wanted
-    tab = lambda ts: (ctypes.c_void_p * M)(*[t.data_ptr() if t is not None else None for t in ts])  # noqa: E731
-    mask = ctypes.c_uint64(0)
-    rc = lib.psf_chord_chain_fwd_far_f32(tab(Wt), V0t.data_ptr(), tab(outs), tab(fars), k0, ctypes.byref(mask), M, 1,
-                                         B, N, L, C, N * C, None, torch.cuda.current_stream().cuda_stream)
-    _lib.check(rc, "psf_chord_chain_fwd_far_f32")
-    assert mask.value == 0b101
-    for m in (0, 2):
-        assert torch.equal(fars[m], Wt[m][:, :, k0:].transpose(1, 2))
-    # same chain outputs as the plain entry point
-    rows, cols = oc.chord_indices(N, L)
-    want = oc.chain(np.stack([rows, cols]), np.stack(W), V0, True)
-    for m in range(M):
-        assert np.array_equal(outs[m].cpu().numpy(), want[m])
-    # dV with and without the copy
-    dZ = _mk((B, N, C), 130)
-    dZt = _t(dZ, gpu)
-    plain = torch.empty(B, N, C, device=gpu)
-    with_copy = torch.full((B, N, C), float("nan"), device=gpu)
-    _launch_bwd(dZt, Wt[0], V0t, None, plain, B, N, L, C, N * C, None)
-    _launch_bwd(dZt, Wt[0], V0t, None, with_copy, B, N, L, C, N * C, None, fars[0], k0)
-    assert torch.equal(plain, with_copy)
-    assert np.array_equal(with_copy.cpu().numpy(), oc.spmul_bwd(dZ, W[0], V0)[1])
-
-
-def test_chain_backward_is_identical_with_and_without_the_side_copy(gpu):
-    import sparsefactorization_amd as sfa
-    from sparsefactorization_amd import chord
-    B, N, M, C = 2, 16384, 5, 8
-    grads = {}
-    for flag in (True, False):
-        chord.far_copy = flag  # (module default: False)
-        try:
-            Ws = [_t(_mk((B, N, M + 1 + 9), 140 + m, 0.2), gpu).requires_grad_(True) for m in range(M)]  # L = 15
-            V0 = _t(_mk((B, N, C), 150), gpu).requires_grad_(True)
-            sfa.chord_chain(Ws, V0, True).backward(_t(_mk((B, N, C), 151), gpu))
-            grads[flag] = [w.grad for w in Ws] + [V0.grad]
-        finally:
-            chord.far_copy = False
-    assert all(torch.equal(a, b) for a, b in zip(grads[True], grads[False]))
-
-
 def _random_shapes(n, seed):
     rng = np.random.default_rng(seed)
     shapes = []
@@ -796,36 +700,26 @@ FUSED_SHAPES = [(3, 16384, 15, 8), (2, 1024, 12, 32), (2, 2048, 12, 16), (5, 512
                 (2, 128, 7, 32)]
 
 
-@pytest.mark.parametrize("nt", [0, 1])
 @pytest.mark.parametrize("B,N,L,C", FUSED_SHAPES)
-def test_fused_backward_step_kernel(gpu, B, N, L, C, nt):
+def test_fused_backward_step_kernel(gpu, B, N, L, C):
     """chord_bwd_fused_k (csrc/bwd_fused.h): dV and dW of a step from ONE kernel — what backward_host computes with two
-    (spmul/spmul_cuda.cu:114-159) — vs the oracle: dV bit-exact, dW <= 1e-5; 256- and 512-thread tiles, with and without
-    the link-major side copy of W's far columns, a broadcast V (v_batch_stride = 0), and the same numbers as the
-    two-kernel path (bwd_fused = 0). Shapes the fused kernel does not take fall back silently (smallest N here)."""
+    (spmul/spmul_cuda.cu:114-159) — vs the oracle: dV bit-exact, dW <= 1e-5; a broadcast V (v_batch_stride = 0), and the same
+    numbers as the two-kernel path (bwd_fused = 0). Shapes the fused kernel does not take fall back silently (smallest N here)."""
     import sparsefactorization_amd as sfa
-    from sparsefactorization_amd import _lib
     from sparsefactorization_amd.chord import _launch_bwd
     W, V, dZ = _mk((B, N, L), 81), _mk((B, N, C), 82), _mk((B, N, C), 83)
     Wt, Vt, dZt = _t(W, gpu), _t(V, gpu), _t(dZ, gpu)
     dF, dV = oc.spmul_bwd(dZ, W, V)
-    k0 = _lib.load().psf_chord_bwd_far_first_link(B, N, L, C)
-    far = Wt[:, :, k0:].permute(0, 2, 1).contiguous() if 0 <= k0 < L else None
-    sfa.set_tuning("bwd_fused_nt", nt)
     try:
         results = []
-        for fused, use_far in ((1, False), (1, True), (0, False)):
-            if use_far and far is None:
-                continue
+        for fused in (1, 0):
             sfa.set_tuning("bwd_fused", fused)
             gW = torch.full_like(Wt, float("nan"))
             gV = torch.full_like(Vt, float("nan"))
-            _launch_bwd(dZt, Wt, Vt, gW, gV, B, N, L, C, N * C, None, far if use_far else None, k0 if use_far else 0)
-            assert np.array_equal(gV.cpu().numpy(), dV), (fused, use_far)
-            assert rel_inf(gW.cpu().numpy(), dF) <= TOL, (fused, use_far)
-            if fused:
-                results.append(gW)
-        assert all(torch.equal(results[0], r) for r in results[1:])  # the side copy changes no bit of dW either
+            _launch_bwd(dZt, Wt, Vt, gW, gV, B, N, L, C, N * C, None)
+            assert np.array_equal(gV.cpu().numpy(), dV), fused
+            assert rel_inf(gW.cpu().numpy(), dF) <= TOL, fused
+            results.append(gW)
         # broadcast first operand (the attention-map chain's unbatched start, pathfinder_inference.py:57,75-81)
         sfa.set_tuning("bwd_fused", 1)
         dFb, dVb = oc.spmul_bwd(dZ, W, np.broadcast_to(V[:1], V.shape).copy())
@@ -835,15 +729,13 @@ def test_fused_backward_step_kernel(gpu, B, N, L, C, nt):
         assert np.array_equal(gV.cpu().numpy(), dVb) and rel_inf(gW.cpu().numpy(), dFb) <= TOL
     finally:
         sfa.set_tuning("bwd_fused", 1)
-        sfa.set_tuning("bwd_fused_nt", 1)
 
 
 FUSED_EDGE_SHAPES = [(2, 4097, 13, 32), (2, 1025, 11, 32), (1, 16385, 15, 8), (3, 777, 9, 16), (2, 643, 10, 4), (2, 1024, 12, 32)]
 
 
-@pytest.mark.parametrize("nt", [0, 1])
 @pytest.mark.parametrize("B,N,L,C", FUSED_EDGE_SHAPES)
-def test_fused_backward_step_general_instance(gpu, B, N, L, C, nt):
+def test_fused_backward_step_general_instance(gpu, B, N, L, C):
     """chord_bwd_fused_edge_k (csrc/bwd_fused.h): the fused step for any sequence length (LRA's CLS-token column makes
     N = 2^k + 1, LRA/listops_training.py:65-72), for W / dW buffers that start anywhere (views into larger buffers, one
     float off a 16-byte boundary) and for far offsets that are no multiples of the tile (last case: aligned N, odd far
@@ -854,7 +746,7 @@ def test_fused_backward_step_general_instance(gpu, B, N, L, C, nt):
     off = None
     if N % 64 == 0:  # aligned length: make the far offsets odd so that only the general instance applies
         KN = 2
-        t = (256 if nt else 512) >> {4: 0, 8: 1, 16: 2, 32: 3}[C]
+        t = 256 >> {4: 0, 8: 1, 16: 2, 32: 3}[C]
         while t > 1:
             KN, t = KN + 1, t >> 1
         KN = min(KN, L)
@@ -864,7 +756,6 @@ def test_fused_backward_step_general_instance(gpu, B, N, L, C, nt):
     Wbig[1:] = _t(W, gpu).reshape(-1)
     Wt = Wbig[1:].view(B, N, L)  # 4 bytes off a 16-byte boundary
     Vt, dZt = _t(V, gpu), _t(dZ, gpu)
-    sfa.set_tuning("bwd_fused_nt", nt)
     try:
         got = {}
         for fused in (1, 0):
@@ -880,5 +771,4 @@ def test_fused_backward_step_general_instance(gpu, B, N, L, C, nt):
         assert torch.equal(got[1][1], got[0][1])
     finally:
         sfa.set_tuning("bwd_fused", 1)
-        sfa.set_tuning("bwd_fused_nt", 1)
 
