@@ -30,7 +30,12 @@ roofline.peak_measured / frac_of_measured = the same achieved rate against what 
 e2e_forward = SURVEY.md §8(d)'s end-to-end variant (one GPU): the real PSFNet (seed 42) on generated Adding / Temporal-Order
   batches at N = 16384, B = 64, both routes of the mixer (W through memory; W computed inside each chain step).
 shapes = the other timed shapes of SURVEY.md §8(d) (cfg1, cfg3 reference and BASELINE wording, cfg4 chain and attention map,
-  genome-like): us per step and algorithmic-bytes fraction, forward and fused backward (one GPU).
+  genome-like): us per step and algorithmic-bytes fraction, forward and fused backward (one GPU), twice: `*_cache_resident`
+  (one operand set re-used: it sits in the 256 MB Infinity Cache — NOT an HBM rate) and `*_rotating` (operand sets spanning
+  2.5 x the Infinity Cache: the fraction of the HBM roofline); `*_counters`: memory-side bytes per launch of the same kernels
+  from the committed per-shape counter summary, when it was collected on these kernel sources.
+devices = every rank's HIP device as the library sees it (PCI bus id, XCDs, CUs); distinct_pci_devices must equal n_gpus in a
+  real multi-GPU run.
 train = the data-parallel leg (BASELINE.json configs[4]): Temporal Order N = 16384, B = 40 per
   GPU, full training step of the reference loop (psf_utils.py:62-71) with ONE flat RCCL gradient all-reduce;
   tokens/s over all ranks and the mean device time of the all-reduce. Not part of the headline's timed region.
@@ -364,6 +369,18 @@ def run_rank(args) -> int:
     ev_ms = ev0.elapsed_time(ev1)
     assert torch.isfinite(out).all()
 
+    # which device each rank ran on, as the library's HIP runtime names it: a multi-GPU record must show `world` distinct PCI
+    # bus ids (and 8 XCDs / 256 CUs each) — checkable from the line alone
+    with torch.cuda.device(device):
+        try:
+            from sparsefactorization_amd import _lib as _psf_lib
+            my_dev = f"rank={rank} local_rank={local_rank} {_psf_lib.device_info()}"
+        except Exception as exc:
+            my_dev = f"rank={rank} local_rank={local_rank} unavailable: {exc!r}"
+    devices = [my_dev]
+    if dist is not None:
+        devices = [None] * world
+        dist.all_gather_object(devices, my_dev)
     per_rank_ms = [ev_ms]
     if dist is not None:
         t = torch.tensor([elapsed, ev_ms], device="cpu", dtype=torch.float64)  # the default group is gloo
@@ -440,6 +457,8 @@ def run_rank(args) -> int:
             },
             "preheat_s": PREHEAT_S,
             "rank_ms_per_step": {"min": min(per_rank_ms) / args.steps, "max": max(per_rank_ms) / args.steps},
+            "devices": devices,
+            "distinct_pci_devices": len({d.split("pci=")[1].split()[0] for d in devices if "pci=" in d}),
         }
         if rehearsal():
             line["rehearsal"] = "ranks share GPUs over gloo: plumbing check only, the numbers are meaningless"
@@ -664,24 +683,78 @@ def e2e_forward_leg(device, reps=20):
     return out
 
 
+def pmc_shapes():
+    """Per-shape counter summary of the newest committed profiles/*_bwd_pmc.json (profiles/collect_bwd.sh: forward step, dV, dW
+    and fused backward kernels of the `shapes` leg's shapes) IF it was collected on this tree's kernel sources (csrc_hash);
+    otherwise (None, reason) — as pmc_traffic() does for the headline kernel."""
+    try:
+        from sparsefactorization_amd.build import csrc_hash
+        now = csrc_hash()
+        pdir = os.path.join(ROOT, "profiles")
+        best = None
+        for f in sorted(os.listdir(pdir)):
+            if f.endswith("_bwd_pmc.json"):
+                with open(os.path.join(pdir, f)) as fh:
+                    d = json.load(fh)
+                if "shapes" in d and "csrc_hash" in d:
+                    best = (f, d)
+        if best is None:
+            return None, "no profiles/*_bwd_pmc.json with a csrc_hash"
+        f, d = best
+        if d["csrc_hash"] != now:
+            return None, f"profiles/{f} @ csrc {d['csrc_hash'][:12]} is stale: csrc is now {now[:12]}"
+        return d["shapes"], f"profiles/{f} @ csrc {now[:12]}"
+    except Exception as exc:
+        return None, f"unavailable: {exc!r}"
+
+
+def _counter_traffic(pmc, shape_key, kernel_prefix):
+    """{traffic_bytes, traffic_over_alg, l2_requests_per_row} of the shape's main launch of a kernel family, or None."""
+    if not pmc or shape_key not in pmc:
+        return None
+    best = None
+    for name, k in pmc[shape_key].get("kernels", {}).items():
+        if name.startswith(kernel_prefix) and "traffic_bytes" in k and k.get("calls", 0) >= 50:
+            if best is None or k["calls"] > best[1]["calls"]:
+                best = (name, k)
+    if best is None:
+        return None
+    name, k = best
+    return {"kernel": name, "rocprof_avg_us": k.get("avg_us"), "traffic_bytes": k["traffic_bytes"],
+            "traffic_over_algorithmic": k.get("traffic_over_alg"), "l2_requests_per_row": k.get("tcc_req_per_row"),
+            "l2_hit_rate": k.get("l2_hit_rate")}
+
+
+ROTATE_FOOTPRINT = 640 * 1000 * 1000  # bytes an operand rotation has to span: 2.5 x the 256 MB Infinity Cache
+ROTATE_MAX_SETS = 48
+
+
 def shapes_leg(device):
     """SURVEY.md §8(d) "other timed shapes" (reference shapes: LRA/psf_training_config.py:2-30,60-88, Genome_Clf/
     genome_training_config.py:6-16): us per step and the fraction of 8 TB/s that the step's ALGORITHMIC bytes amount to, for
     the forward chain (bytes 4 B N (L + 2C [+ C residual]) per step) and for one backward step with both gradients (bytes
-    4 B N (2L + 3C)). HIP events over back-to-back calls on one operand set (warm caches); ~1 s of GPU time."""
+    4 B N (2L + 3C)). Two timings each, HIP events over back-to-back calls:
+      * `*_cache_resident`: ONE operand set re-used by every call. Every LRA shape's working set (<= 70 MB) then sits in the
+        256 MB Infinity Cache: the figure is a cache-resident rate, NOT an HBM rate (the round-4 review's point), and is named so;
+      * `*_rotating`: the calls rotate through enough operand sets to span 2.5 x the Infinity Cache (or 48 sets for the tiny
+        cfg1), as a training step or a stream of batches sees them: the fraction of the HBM roofline.
+    `*_counters`: memory-side bytes and L2 requests per row of the same kernels from the newest committed per-shape counter
+    summary, when it was collected on these sources."""
     import torch
     out = {}
     try:
         import sparsefactorization_amd as sfa
         from sparsefactorization_amd import _lib
         from sparsefactorization_amd.chord import _launch_bwd
-        # name, B, N, L, C, residual, attention-map mode (first operand eye(N), unbatched)
-        shapes = [("cfg1_adding_n128", 40, 128, 8, 8, True, False),
-                  ("cfg3_listops_reference", 32, 2000, 12, 128, False, False),
-                  ("cfg3_listops_baseline_wording", 32, 2048, 12, 64, False, False),
-                  ("cfg4_pathfinder_chain", 64, 1024, 12, 32, False, False),
-                  ("cfg4_pathfinder_attention_map", 8, 1024, 12, 1024, False, True),
-                  ("genome_like", 16, 16384, 15, 32, False, False)]
+        pmc, pmc_src = pmc_shapes()
+        out["counters_source"] = pmc_src
+        # name, B, N, L, C, residual, attention-map mode (first operand eye(N), unbatched), key in the counter summary
+        shapes = [("cfg1_adding_n128", 40, 128, 8, 8, True, False, None),
+                  ("cfg3_listops_reference", 32, 2000, 12, 128, False, False, "cfg3_ref"),
+                  ("cfg3_listops_baseline_wording", 32, 2048, 12, 64, False, False, "cfg3_baseline"),
+                  ("cfg4_pathfinder_chain", 64, 1024, 12, 32, False, False, "cfg4"),
+                  ("cfg4_pathfinder_attention_map", 8, 1024, 12, 1024, False, True, None),
+                  ("genome_like", 16, 16384, 15, 32, False, False, "genome_like")]
 
         def timed(fn, n):
             for _ in range(3):
@@ -695,30 +768,71 @@ def shapes_leg(device):
             torch.cuda.synchronize(device)
             return e0.elapsed_time(e1) * 1e3 / n  # us
 
-        for name, B, N, L, C, res, amap in shapes:
+        for name, B, N, L, C, res, amap, pkey in shapes:
             M = L - 1
             g = torch.Generator(device=device).manual_seed(7)
-            Ws = [0.1 * torch.randn(B, N, L, device=device, generator=g) for _ in range(M)]
+            chain_bytes = M * 4 * B * N * L + 4 * B * N * (C if not amap else N)  # the W_m of one chain + its V0
+            sets = max(2, min(ROTATE_MAX_SETS, -(-ROTATE_FOOTPRINT // chain_bytes)))
+            Wsets = [[0.1 * torch.randn(B, N, L, device=device, generator=g) for _ in range(M)] for _ in range(sets)]
             V0 = torch.eye(N, device=device) if amap else torch.randn(B, N, C, device=device, generator=g)
+            V0s = [V0] if amap else [V0] + [torch.randn(B, N, C, device=device, generator=g) for _ in range(sets - 1)]
+            it = [0]
+
+            def chain_rot():
+                s_ = it[0] % sets
+                it[0] += 1
+                sfa.chord_chain(Wsets[s_], V0s[s_ % len(V0s)], res)
+
             with torch.no_grad():
-                t_chain = timed(lambda: sfa.chord_chain(Ws, V0, res), 20)
+                t_chain = timed(lambda: sfa.chord_chain(Wsets[0], V0, res), 20)
+                t_rot = timed(chain_rot, max(20, 2 * sets))
                 fwd_bytes = 4 * B * N * (L + 2 * C + (C if res else 0))
-                entry = {"B": B, "N": N, "L": L, "C": C, "M": M, "residual": res,
-                         "fwd_us_per_step": t_chain / M, "fwd_bytes_per_step": fwd_bytes,
-                         "fwd_frac_of_hbm_peak": fwd_bytes / (t_chain / M * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                entry = {"B": B, "N": N, "L": L, "C": C, "M": M, "residual": res, "fwd_bytes_per_step": fwd_bytes,
+                         "fwd_us_per_step_cache_resident": t_chain / M,
+                         "fwd_frac_of_hbm_peak_cache_resident": fwd_bytes / (t_chain / M * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "fwd_us_per_step_rotating": t_rot / M,
+                         "fwd_frac_of_hbm_peak_rotating": fwd_bytes / (t_rot / M * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "rotation": {"operand_sets": sets, "footprint_MB": sets * chain_bytes / 1e6},
                          "fwd_kernel": _lib.describe_chain_fwd(B, N, L, C, M)}
+                fc = _counter_traffic(pmc, pkey, "chord_fwd_")
+                if fc is not None:
+                    entry["fwd_counters"] = fc
                 if not amap:
-                    V = torch.randn(B, N, C, device=device, generator=g)
+                    step_bytes_in = 4 * B * N * (L + 2 * C)
+                    bsets = max(2, min(ROTATE_MAX_SETS, -(-ROTATE_FOOTPRINT // (2 * step_bytes_in))))
+                    bsets = min(bsets, sets * M)
+                    flatW = [w for ws in Wsets for w in ws][:bsets]
+                    Vs = [torch.randn(B, N, C, device=device, generator=g) for _ in range(bsets)]
                     dZ = torch.randn(B, N, C, device=device, generator=g)
-                    dW, dV = torch.empty_like(Ws[0]), torch.empty_like(V)
-                    t_bwd = timed(lambda: _launch_bwd(dZ, Ws[0], V, dW, dV, B, N, L, C, N * C, None), 40)
+                    dWs = [torch.empty_like(flatW[0]) for _ in range(bsets)]
+                    dVs = [torch.empty_like(Vs[0]) for _ in range(bsets)]
+                    jt = [0]
+
+                    def bwd_rot():
+                        s_ = jt[0] % bsets
+                        jt[0] += 1
+                        _launch_bwd(dZ, flatW[s_], Vs[s_], dWs[s_], dVs[s_], B, N, L, C, N * C, None)
+
+                    t_bwd = timed(lambda: _launch_bwd(dZ, flatW[0], Vs[0], dWs[0], dVs[0], B, N, L, C, N * C, None), 40)
+                    t_brot = timed(bwd_rot, max(40, 2 * bsets))
                     bwd_bytes = 4 * B * N * (2 * L + 3 * C)
-                    entry.update({"bwd_us_per_step": t_bwd, "bwd_bytes_per_step": bwd_bytes,
-                                  "bwd_frac_of_hbm_peak": bwd_bytes / (t_bwd * 1e-6) / 1e9 / HBM_PEAK_GBS})
+                    entry.update({"bwd_bytes_per_step": bwd_bytes, "bwd_us_per_step_cache_resident": t_bwd,
+                                  "bwd_frac_of_hbm_peak_cache_resident": bwd_bytes / (t_bwd * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                  "bwd_us_per_step_rotating": t_brot,
+                                  "bwd_frac_of_hbm_peak_rotating": bwd_bytes / (t_brot * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                  "bwd_rotation_operand_sets": bsets})
+                    bc = _counter_traffic(pmc, pkey, "chord_bwd_fused") or _counter_traffic(pmc, pkey, "chord_dv_")
+                    if bc is not None:
+                        entry["bwd_counters"] = bc
+                    del Vs, dWs, dVs, flatW
             out[name] = entry
-            del Ws, V0
+            del Wsets, V0, V0s
             torch.cuda.empty_cache()
-        out["backward_step_vs_stream"] = backward_vs_stream(device, timed)
+        bvs = backward_vs_stream(device, timed)
+        bc = _counter_traffic(pmc, "order_train", "chord_bwd_fused")
+        if bc is not None:
+            bvs["counters"] = bc  # (cache-resident operands under the profiler: its traffic is the memory side of L2, not HBM alone)
+        out["backward_step_vs_stream"] = bvs
     except Exception as exc:
         out["error"] = repr(exc)
     return out

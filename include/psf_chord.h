@@ -78,6 +78,13 @@ const char* psf_last_error(void);
 const char* psf_build_info(void);
 
 /*
+ * The calling thread's current HIP device, as the library sees it: "pci=<domain:bus:device.function> xcds=<n> cus=<n>
+ * name=<marketing name>" into buf (NUL-terminated, truncated to len). One rank per GPU prints this into its benchmark line
+ * so that a multi-GPU record shows N distinct devices (bench.py: "devices"). Touches the GPU (hipGetDevice).
+ */
+int psf_device_info(char* buf, int32_t len);
+
+/*
  * Chord link offsets — the integer pattern of get_chord_indices_assym (SyntheticExperiments/psf.py:7-32):
  * offsets_out[0] = 0, offsets_out[k] = 2^(k-1) mod N for 1 <= k < L. Host-only, no GPU needed.
  */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Workload for the backward-kernel counter passes: `iters` launches of dV alone, then of dW alone, then of the step that
-wants both (the fused kernel, csrc/bwd_fused.h, where it applies), at one shape.
+"""Workload for the per-shape counter passes: `iters` launches of dV alone, then of dW alone, then of the step that wants both
+(the fused kernel, csrc/bwd_fused.h, where it applies), then of the forward step, at one shape.
 
     python3 profiles/bwd_pmc_run.py B N L C [iters]
 
@@ -32,6 +32,10 @@ def main():
     torch.cuda.synchronize()
     for _ in range(iters):
         chord._launch_bwd(dZ, W, V, dW, dV, B, N, L, C, N * C, None)
+    torch.cuda.synchronize()
+    out = torch.empty_like(V)
+    for _ in range(iters):  # (round 5) the forward step of the shape too, no residual: counters for every forward instance
+        chord._launch_fwd(W, V, None, out, B, N, L, C, N * C, None)
     torch.cuda.synchronize()
     print(f"done B={B} N={N} L={L} C={C} iters={iters} alg_bytes={4 * B * N * (L + 2 * C)}")
 

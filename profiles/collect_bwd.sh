@@ -1,5 +1,6 @@
 #!/usr/bin/env bash
-# rocprofv3 evidence for the backward kernels (chord_dv_win_k / chord_dw_win_k) at cfg2 and cfg3_ref.
+# rocprofv3 evidence for the backward kernels (chord_dv_win_k / chord_dw_win_k / chord_bwd_fused_k) and, since round 5, the forward
+# step kernel of every shape of bench.py's `shapes` leg.
 #     bash profiles/collect_bwd.sh <tag>        e.g. r02_bwd  -> gpurun_out/prof_<tag>/<shape>/<pass>/
 # One --kernel-trace --stats pass and one pass per --pmc group (never combined), program directly after `--`.
 set -u
@@ -18,7 +19,7 @@ run() {  # shape-name, pass-name, "B N L C", rocprofv3 args...
   return $rc
 }
 
-for spec in "cfg2:64 16384 15 8" "cfg3_ref:32 2000 12 128"; do
+for spec in "cfg2:64 16384 15 8" "order_train:40 16384 15 8" "genome_like:16 16384 15 32" "cfg3_ref:32 2000 12 128" "cfg3_baseline:32 2048 12 64" "cfg4:64 1024 12 32"; do
   shape=${spec%%:*}; dims=${spec#*:}
   run $shape stats "$dims" --kernel-trace --stats &&
   run $shape pmc_fetch "$dims" --pmc FETCH_SIZE &&

@@ -15,7 +15,8 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHAPES = {"cfg2": (64, 16384, 15, 8), "cfg3_ref": (32, 2000, 12, 128)}
+SHAPES = {"cfg2": (64, 16384, 15, 8), "order_train": (40, 16384, 15, 8), "genome_like": (16, 16384, 15, 32),
+          "cfg3_ref": (32, 2000, 12, 128), "cfg3_baseline": (32, 2048, 12, 64), "cfg4": (64, 1024, 12, 32)}
 
 
 def short(name: str) -> str:
@@ -27,7 +28,9 @@ def short(name: str) -> str:
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02_bwd"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-    out = {"tag": tag, "shapes": {}}
+    sys.path.insert(0, ROOT)
+    from sparsefactorization_amd.build import csrc_hash
+    out = {"tag": tag, "csrc_hash": csrc_hash(), "shapes": {}}  # (bench.py attaches these numbers only to the sources they came from)
     md = [f"# rocprofv3 summary, backward kernels — {tag}", "",
           "Workload: `python3 profiles/bwd_pmc_run.py B N L C 100` (100 launches of dV alone, 100 of dW alone, 100 of the fused "
           "step where it applies — its algorithmic bytes are 4BN(2L+3C)); one "
@@ -63,7 +66,8 @@ def main():
             c = k.get("counters_per_launch", {})
             row = [f"`{name}`", str(k.get("calls", "")), f"{k.get('avg_us', float('nan')):.2f}"]
             fused = "fused" in name
-            full = k.get("calls", 0) >= 50 and ("false>" in name or fused)  # the main (full-tile) launch of the shape
+            fwd = "chord_fwd_" in name
+            full = k.get("calls", 0) >= 50 and ("false>" in name or fused or fwd)  # the main (full-tile) launch of the shape
             if "avg_us" in k and full:
                 tbs = (4 * B * N * (2 * L + 3 * C) if fused else alg) / k["avg_us"] / 1e6  # the fused step: 4BN(2L+3C)
                 k["alg_tbs"], k["frac"] = tbs, tbs / 8.0

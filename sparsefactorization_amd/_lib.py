@@ -25,6 +25,7 @@ SIGNATURES = {
     "psf_version": ([], ctypes.c_int),
     "psf_last_error": ([], ctypes.c_char_p),
     "psf_build_info": ([], ctypes.c_char_p),
+    "psf_device_info": ([ctypes.c_char_p, c_i32], ctypes.c_int),
     "psf_chord_offsets": ([c_i64, c_i32, _I64P], ctypes.c_int),
     "psf_chord_indices": ([c_i64, c_i32, _I64P, _I64P], ctypes.c_int),
     "psf_chord_spmm_fwd_f32": (_STEP, ctypes.c_int),
@@ -193,3 +194,10 @@ def describe_chain_fwd(B: int, N: int, L: int, C: int, M: int) -> str:
 
 def build_info() -> str:
     return load().psf_build_info().decode()
+
+
+def device_info() -> str:
+    """The calling thread's current HIP device as the library sees it (PCI bus id, XCDs, CUs, name)."""
+    buf = ctypes.create_string_buffer(256)
+    check(load().psf_device_info(buf, 256), "psf_device_info")
+    return buf.value.decode()

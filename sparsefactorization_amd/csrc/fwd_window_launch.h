@@ -20,6 +20,8 @@ constexpr int kWinTgsMax = 6;               // TG = 1 << TGS <= 64 lanes share a
 constexpr int kWideTgs = 3, kWideThreads = 1024;
 // (Round 4 also built 512 threads for rows of exactly 32 channels — equal at the genome and IMDb shapes, profiles/r04ai_* —
 // and round 5 removed it: no automatic rule selected it.)
+// (... and for the chunks of wider rows in round 5: 3-8 % slower than the 1024-thread chunks at N <= 4096, 3 % faster at
+// N = 16384 x 64 channels, profiles/r05m_fwd_wide_mid.log — not kept either.)
 constexpr bool win_pair_compiled(int tgs, int nt) {
   return (nt == 256 && tgs >= 0 && tgs <= kWinTgsMax) || (nt == kWideThreads && tgs == kWideTgs);
 }

@@ -396,7 +396,12 @@ bool pick_window(const Tuning& tn, const void* W, int64_t B, int64_t N, int32_t 
   // rounds 1-3 measured faster: N = 2048, B = 32: C = 64 10.7 -> 9.0 us per step, C = 96 16.7 -> 14.3, C = 128 19.5 -> 18.3,
   // C = 192 29.9 -> 25.7, C = 256 36.1 -> 33.9; N = 4096: +2..5 %; C = 512: equal; N = 16384, C = 64, B = 8: 23.7 -> 25.7 (slower)
   // (profiles/r04ak_fwd_wide_rule_sweep.log). The backward kernels keep their configuration.
-  const bool auto_wide = forward && wide == 0 && CG >= 16 && CG <= 64 && N <= 4096;
+  // Round 5, with operands rotating beyond the Infinity Cache as a training step has them (profiles/r05m_fwd_wide_mid.log, us per
+  // step, chunks / whole rows): N = 2048, C = 64: 10.5 / 11.8; N = 2048, C = 128: 20.8 / 22.0; N = 4096, C = 64: 21.7 / 22.6; C = 256:
+  // 21.2 / 21.9 — but ListOps' N = 2000, C = 128: 23.9 / 21.1: 2000 is no multiple of the 256-row chunk tile (every tile then takes the
+  // per-lane request form) and a multiple of the whole-row tile. So: chunks only where their tiles divide N or the whole-row tiles do not.
+  const int64_t tr_whole = win_tile_rows(tgs, rows, 256), tr_chunk = win_tile_rows(kWideTgs, rows, kWideThreads);
+  const bool auto_wide = forward && wide == 0 && CG >= 16 && CG <= 64 && N <= 4096 && (N % tr_chunk == 0 || N % tr_whole != 0);
   if (chunk_channels && (wide == 1 || auto_wide) && CG >= 16 && N >= 2 * (int64_t)win_tile_rows(kWideTgs, rows, kWideThreads)) {
     tgs = kWideTgs;  // 32-channel chunks on 1024-thread workgroups
     nt = kWideThreads;
@@ -822,6 +827,22 @@ const char* psf_build_info(void) {
          " | csrc=" PSF_CSRC_HASH  // build.csrc_hash() of the sources this library was built from (_lib.load compares)
 #endif
       ;
+}
+
+int psf_device_info(char* buf, int32_t len) {
+  if (!buf || len < 1) return fail(PSF_E_NULL, "buf is NULL or empty");
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail_hip(e, "hipGetDevice");
+  char pci[64] = "?";
+  (void)hipDeviceGetPCIBusId(pci, (int)sizeof(pci), dev);
+  int xcds = 0, cus = 0;
+  (void)hipDeviceGetAttribute(&xcds, hipDeviceAttributeNumberOfXccs, dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  hipDeviceProp_t prop;
+  const char* name = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.name : "?";
+  snprintf(buf, (size_t)len, "pci=%s xcds=%d cus=%d name=%s", pci, xcds, cus, name);
+  return PSF_OK;
 }
 
 int psf_chord_offsets(int64_t N, int32_t L, int64_t* offsets_out) {
