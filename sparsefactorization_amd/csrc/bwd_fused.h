@@ -60,6 +60,7 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
   V4* __restrict__ sZ = reinterpret_cast<V4*>(smem);
   V4* __restrict__ sV = reinterpret_cast<V4*>(smem + Cfg::win_bytes);
   using FC = BwdFusedCfg<L, TGS, NT>;
+  constexpr bool kNtOut = TGS >= 2;  // rows of >= 16 channels store dV and dW non-temporally (see the dV store)
   V4* __restrict__ sWV = reinterpret_cast<V4*>(smem + 2 * Cfg::win_bytes);
   const T* __restrict__ sWF = reinterpret_cast<const T*>(sWV);
   T* __restrict__ sOutF = reinterpret_cast<T*>(sWV);  // the dW tile image: written after the last read of the W tiles
@@ -164,8 +165,20 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) axpy_rn<T, VEC>(acc, farW[f], farZ[f]);
-    if (!(ABL & 64) || acc.e[0] == T(12345.678))
-      stg<T, VEC>(sbase(reinterpret_cast<char*>(dV + ((int64_t)b * N + q0) * C)) + lane_off(voff), acc);
+    if (!(ABL & 64) || acc.e[0] == T(12345.678)) {
+      // Rows of >= 16 channels: dV and dW leave non-temporally. A sequence's dZ + V + W is 5 MB at N = 16384, C = 32 — the size of
+      // an XCD's L2, where the tiles re-read them through eight far links; outputs parked there push them out (counters: 174 MB
+      // read per step where 83 are algorithmic, profiles/r05k_shapes_summary.md). us per step, rotating operands, one process:
+      // C = 32: 47.5 -> 42.9 (N = 4096: 22.4 -> 20.8), C = 16: 26.6 -> 23.9; C = 8: 42.3 -> 40.7 alone but 2.19 vs 2.19 ms in the
+      // Order training step, where the next step reads this dV at once: left as it is (profiles/r05n_bwd_nt_store*.log).
+      if constexpr (kNtOut) {
+        using F4 = float __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(F4{acc.e[0], acc.e[1], acc.e[2], acc.e[3]},
+                                    reinterpret_cast<PSF_GLOBAL F4*>(sbase(reinterpret_cast<char*>(dV + ((int64_t)b * N + q0) * C)) + lane_off(voff)));
+      } else {
+        stg<T, VEC>(sbase(reinterpret_cast<char*>(dV + ((int64_t)b * N + q0) * C)) + lane_off(voff), acc);
+      }
+    }
   }
   // (5) dW row dots (the tile's dZ rows are the upper half of the dZ window)
   T dots[L];
@@ -210,7 +223,7 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
   for (int n = 0; n < FC::passes; ++n) {
     const int i = n * NT + tid;
     if (n < FC::full || i < FC::tile_vecs) {
-      if constexpr ((ABL & 128) != 0) {
+      if constexpr ((ABL & 128) != 0 || kNtOut) {
         using F4 = float __attribute__((ext_vector_type(4)));
         __builtin_nontemporal_store(*reinterpret_cast<const F4*>(&sOutV[i]), reinterpret_cast<PSF_GLOBAL F4*>(ob + ((uint32_t)(n * NT) * 16u + vo)));
       } else {
