@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define PSF_ABI_VERSION 1
+#define PSF_ABI_VERSION 2 /* 2 (round 5): the three "far" training entries are gone, psf_device_info is new, per-step mixer kernels take rows only */
 
 #define PSF_MAX_LINKS 64 /* L <= 64: N = 2^63 would need 64 links */
 

@@ -11,7 +11,7 @@ from typing import Optional, Sequence
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libpsf_chord.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LINKS = 64
 
 c_i32, c_i64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p

@@ -134,7 +134,9 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
   }
   // (3b) far-link W elements: element (src0 + pl) of the link's column of row-major W. (Reading them from a link-major side
   //      copy — consecutive rows consecutive floats, the contiguous layout the round-4 review asked for — did not move this
-  //      step: 44.6 vs 43.8 us in the training step, profiles/r03aj_farcopy_in_step_ab.log; the copy was removed in round 5.)
+  //      step: 44.6 vs 43.8 us in the training step, profiles/r03aj_farcopy_in_step_ab.log; the copy was removed in round 5. Nor
+  //      do fewer instructions: lane g of a row loading link f + g and the row's lanes swapping by DPP — NF / TG loads instead of
+  //      NF — is 4-15 % SLOWER, profiles/r05o_bwd_farw_pack.log. Without these loads the step is 5 us shorter, r04o_bwd_ablate.log.)
   if constexpr (!(ABL & 2)) {
 #pragma unroll
     for (int f = 0; f < NF; ++f)

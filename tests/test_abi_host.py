@@ -33,7 +33,7 @@ def test_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name), f"libpsf_chord.so does not export {name}"
     assert sorted(_lib.SIGNATURES) == declared  # the ctypes table binds exactly the header
-    assert lib.psf_version() == 1
+    assert lib.psf_version() == 2
     assert b"gfx950" in lib.psf_build_info()
 
 
