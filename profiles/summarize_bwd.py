@@ -31,7 +31,7 @@ def main():
     sys.path.insert(0, ROOT)
     from sparsefactorization_amd.build import csrc_hash
     out = {"tag": tag, "csrc_hash": csrc_hash(), "shapes": {}}  # (bench.py attaches these numbers only to the sources they came from)
-    md = [f"# rocprofv3 summary, backward kernels — {tag}", "",
+    md = [f"# rocprofv3 summary, per shape: forward step, dV, dW and fused backward kernels — {tag}", "",
           "Workload: `python3 profiles/bwd_pmc_run.py B N L C 100` (100 launches of dV alone, 100 of dW alone, 100 of the fused "
           "step where it applies — its algorithmic bytes are 4BN(2L+3C)); one "
           "`--kernel-trace --stats` pass and one pass per `--pmc` group. Traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB.", ""]
