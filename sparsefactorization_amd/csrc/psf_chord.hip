@@ -947,6 +947,10 @@ int psf_mixer_fwd_in_f32(const psf_mixer_input* in, int64_t B, int64_t N, int32_
     return fail(PSF_E_SHAPE, "psf_mixer_fwd: shape outside the fused path (N=%lld E=%d M=%d C=%lld L=%d; see psf_mixer_fwd_workspace)",
                 (long long)N, (int)E, (int)M, (long long)C, (int)L);
   if (int rc = check_dims(B, N, L, C, N * C)) return rc;
+  if (in->kind != PSF_MIXER_IN_DATA && !(mp.lds_ok && g_mixer_lds.load() && B <= 0x7fffffff))  // (before anything is launched)
+    return fail(PSF_E_SHAPE, "psf_mixer_fwd: an input recipe (kind %d) is evaluated by the single-launch kernel only (short sequences, "
+                "psf_mixer_fwd_plan() == 2); for N=%lld write the rows with psf_affine_rows_f32 / psf_embed_tokens_f32 and pass them",
+                (int)in->kind, (long long)N);
   if (B == 0) return PSF_OK;
   if (workspace_bytes < (int64_t)mp.units * kX3ImageBytes || !aligned_to(workspace, 16))
     return fail(PSF_E_SHAPE, "psf_mixer_fwd: workspace too small (psf_mixer_fwd_workspace) or not 16-byte aligned");
@@ -990,10 +994,6 @@ int psf_mixer_fwd_in_f32(const psf_mixer_input* in, int64_t B, int64_t N, int32_
     if (e != hipSuccess) return fail_hip(e, "chord_mixer_lds launch");
     return PSF_OK;
   }
-  if (in->kind != PSF_MIXER_IN_DATA)
-    return fail(PSF_E_SHAPE, "psf_mixer_fwd: an input recipe (kind %d) is evaluated by the single-launch kernel only (short sequences, "
-                "psf_mixer_fwd_plan() == 2); for N=%lld write the rows with psf_affine_rows_f32 / psf_embed_tokens_f32 and pass them",
-                (int)in->kind, (long long)N);
   if (!mp.step_ok)
     return fail(PSF_E_TUNING, "psf_mixer_fwd: mixer_lds=0 but only the LDS-resident kernel covers N=%lld C=%lld", (long long)N, (long long)C);
   // the tile geometry of every launch below

@@ -165,6 +165,15 @@ def test_mixer_entry_point_states_its_limits_without_touching_the_gpu(lib):
     assert f(one, 1, 16384, 32, 2, tab, tab, tab, tab, h, 8, 15, 1, two, (vp * 2)(32, 32), three, ws, None) == -3  # out aliases V0
     assert f(one, 1, 16384, 32, 2, tab, tab, tab, tab, h, 8, 15, 1, two, (vp * 2)(64, 64), three, ws, None) == -3  # step in == out
     assert f(one, 0, 16384, 32, 2, tab, tab, tab, tab, h, 8, 15, 1, two, outs, three, ws, None) == 0        # empty batch
+    # an input recipe (psf_mixer_input kinds 1, 2) is evaluated by the single-launch kernel only: on the per-step path the entry
+    # says so, names the two row-writing entry points, and has launched nothing
+    from sparsefactorization_amd import _lib
+    rec = _lib.MixerInput(_lib.MIXER_IN_TOKENS, 6, 16, 32, None, None)
+    g = lib.psf_mixer_fwd_in_f32
+    assert g(ctypes.byref(rec), 1, 16384, 32, 2, tab, tab, tab, tab, h, 8, 15, 1, two, outs, three, ws, None) == -2
+    assert b"psf_embed_tokens_f32" in lib.psf_last_error() and b"single-launch" in lib.psf_last_error()
+    for gone in ("psf_chord_chain_fwd_far_f32", "psf_chord_spmm_bwd_far_f32", "psf_chord_bwd_far_first_link"):
+        assert not hasattr(lib, gone), f"{gone} was removed in ABI version 2"
 
 
 def test_producer_entry_points_validate_before_touching_the_gpu(lib):

@@ -86,6 +86,9 @@ def test_bench_two_rank_rehearsal_replays_the_step_from_a_graph(gpu):
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "rehearsal" in line
+    # every rank names its device as the library's HIP runtime sees it; the rehearsal's two ranks share the one GPU
+    assert len(line["devices"]) == 2 and all("pci=" in d and "xcds=8" in d and "cus=256" in d for d in line["devices"]), line["devices"]
+    assert line["distinct_pci_devices"] == 1
     tr = line["train"]
     assert "error" not in tr, tr
     assert tr["hip_graph"] == "fwd+bwd" and tr["global_batch"] == 80 and tr["allreduce_us"] is not None
