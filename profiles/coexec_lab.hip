@@ -138,6 +138,78 @@ double run_inwave(int wps, int iters, int km, int kv, float* out) {
   return ms * 1e-3 * 2.4e9 / iters;
 }
 
+// What a producer-MLP wave does that the phases above do not: FLAGS bit 0 the vector phase starts from the accumulator (a data
+// dependency on the MFMA chain), bit 1 every MFMA's operands come out of LDS (ds_read_b128 + wait), bit 2 a workgroup barrier
+// per iteration. Scalar v_fma vector phase; waves in step.
+template <int FLAGS, bool DO_M, bool DO_V>
+__global__ void __launch_bounds__(256) lab_real_k(float* out, int iters, int km, int kv, float seed) {
+  __shared__ bf16x8 sOp[2 * 256];
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = seed * r;
+  bf16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (__bf16)(seed + threadIdx.x + i), b[i] = (__bf16)(seed * 2.f - i);
+  sOp[threadIdx.x] = a, sOp[256 + threadIdx.x] = b;
+  __syncthreads();
+  float r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = seed * (j + 1) + 0.25f;
+  for (int it = 0; it < iters; ++it) {
+    if (DO_M)
+      for (int m = 0; m < km; ++m) {
+        if (FLAGS & 2) a = sOp[(threadIdx.x + m) & 255], b = sOp[256 + ((threadIdx.x + 2 * m) & 255)];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      }
+    if (DO_V) {
+      if (FLAGS & 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += acc[j];
+      }
+      vphase<FMA>(r, kv);
+      if ((FLAGS & 1) && DO_M) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j + 8] = r[j];  // ... and the next chain from the vector results
+      }
+    }
+    if (FLAGS & 4) __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) s += acc[q];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += r[j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int FLAGS, bool DO_M, bool DO_V>
+double run_real(int wps, int iters, int km, int kv, float* out) {
+  const int blocks = 256 * wps;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL((lab_real_k<FLAGS, DO_M, DO_V>), dim3(blocks), dim3(256), 0, 0, out, iters, km, kv, 0.001f);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((lab_real_k<FLAGS, DO_M, DO_V>), dim3(blocks), dim3(256), 0, 0, out, iters, km, kv, 0.001f);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e-3 * 2.4e9 / iters;
+}
+
+template <int FLAGS>
+void sweep_real(const char* name, int wps, int km, int kv, float* out) {
+  const int iters = 400;
+  const double m = run_real<FLAGS, true, false>(wps, iters, km, kv, out);
+  const double v = run_real<FLAGS, false, true>(wps, iters, km, kv, out);
+  const double both = run_real<FLAGS, true, true>(wps, iters, km, kv, out);
+  printf("%-44s %d waves/SIMD  %2d MFMA + %3d v_fma:  matrix alone %7.0f  vector alone %7.0f  together %7.0f   (sum %7.0f, max %7.0f)\n",
+         name, wps, km, kv, m, v, both, m + v, m > v ? m : v);
+}
+
 template <int CLS, bool PHASED, bool DO_M, bool DO_V>
 double run(int wps, int iters, int km, int kv, float* out) {
   const int blocks = 256 * wps;  // 256-thread workgroups: one wave per SIMD each; blockIdx / 256 = which "layer" of waves
@@ -168,9 +240,20 @@ void sweep(const char* name, int wps, int km, int kv, float* out) {
          name, wps, km, kv, m, v, both, phased, inwave, m + v, m > v ? m : v);
 }
 
-int main() {
+int main(int argc, char** argv) {
   float* out;
   hipMalloc(&out, 4096 * 256 * sizeof(float));
+  if (argc > 1) {  // "real": what a producer wave adds to the picture
+    for (int wps : {2, 4}) {
+      sweep_real<0>("independent phases", wps, 12, 192, out);
+      sweep_real<1>("vector phase depends on the chain", wps, 12, 192, out);
+      sweep_real<2>("MFMA operands from LDS", wps, 12, 192, out);
+      sweep_real<4>("barrier per iteration", wps, 12, 192, out);
+      sweep_real<3>("dependency + LDS operands", wps, 12, 192, out);
+      sweep_real<7>("dependency + LDS operands + barrier", wps, 12, 192, out);
+    }
+    return 0;
+  }
   for (int wps : {2, 4}) {
     sweep<FMA>("v_fma", wps, 12, 96, out);
     sweep<FMA>("v_fma", wps, 12, 192, out);
