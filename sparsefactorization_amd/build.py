@@ -116,6 +116,16 @@ def _unit_table():
 LINT_UNITS = ("fwd_window", "fwd_mlp_step", "mixer_lds", "mlp_wide", "mlp_fwd", "mlp_bwd")  # (+ the other MFMA units: R0, R2, R3)
 
 
+def _unit_weight(unit) -> int:
+    """Rough compile cost of a unit (seconds on this container), for the order in which the pool starts them."""
+    name = os.path.basename(unit[0])
+    for prefix, w in (("fwd_mlp_step", 30), ("mlp_bwd", 28), ("fwd_chain_lds", 26), ("mlp_wide", 24), ("fwd_window", 16),
+                      ("bwd_window_mid", 14), ("bwd_window", 12), ("mixer_lds", 10), ("mlp_fwd", 8), ("psf_chord", 8)):
+        if name.startswith(prefix):
+            return w
+    return 3
+
+
 def built_hash(path: str = LIB_PATH):
     """The ``csrc=<sha256>`` a library carries in its psf_build_info string (read from the file: no dlopen), or None."""
     import re
@@ -171,8 +181,13 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
     os.makedirs(OBJ_DIR, exist_ok=True)
     units = _units()
     jobs = jobs or min(len(units), max(1, (os.cpu_count() or 2)))
+    # longest units first (the pool takes them in order: a 25 s unit started last would be the build's tail)
+    order = sorted(range(len(units)), key=lambda i: -_unit_weight(units[i]))
     with ThreadPoolExecutor(max_workers=jobs) as pool:
-        objs = list(pool.map(lambda u: _compile(u, cc, verbose), units))
+        done = list(pool.map(lambda i: _compile(units[i], cc, verbose), order))
+    objs = [None] * len(units)
+    for i, o in zip(order, done):
+        objs[i] = o
     link = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(link), file=sys.stderr)
