@@ -427,13 +427,6 @@ int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float
  *   key "mlp_variant": psf_mlp_fwd_f32: 0 = auto (default: the split-bf16 kernel for E <= 32, else the f32-MFMA
  *                      kernel), 1 = f32 MFMA with streamed weights, 2 = f32 MFMA with LDS-resident weights,
  *                      3 = split-bf16 (each f32 operand as three exact bf16 terms, six product terms: f32 accuracy)
- *   key "mlp_bwd_variant": psf_mlp_bwd_f32: 0 = auto (default) = 3 = split-bf16 on dual-use LDS planes: all five GEMMs
- *                      on the bf16 matrix pipe, every operand split once, transposed operands by ds_read_b64_tr_b16;
- *                      1 = all-f32-MFMA kernel; 2 = the first split-bf16 kernel (steps 1, 2, 6 on bf16, the token
- *                      contractions on the f32 instruction); 4 = the same arithmetic as 3 with the two waves of a SIMD in
- *                      different roles (a producer wave: GELU and splits; a consumer wave: the contractions over tokens),
- *                      handed over through LDS counters without workgroup barriers — measured 8 % slower than 3
- *                      (one wave alone issues vector instructions at half the SIMD's rate) and kept as a record
  *   key "mlp_fwd_store": split-bf16 MLP forward: 1 = finished output tiles are stored straight from the accumulator registers
  *                      (default), 0 = through an LDS transposition as contiguous bursts (the first form; equal bits)
  *   key "bwd_fused_wg_limit": fused backward step: 0 = automatic (default): three workgroups per CU on launches of >= 4096

@@ -8,7 +8,6 @@
 #include <cstdio>
 #include <vector>
 
-std::atomic<int> psf_g_mlp_bwd_variant{3};
 extern "C" int psf_internal_fail(int code, const char* message) {
   std::printf("psf_internal_fail(%d): %s\n", code, message);
   return code;
@@ -61,12 +60,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  #ifdef PSF_LAB_ROLES
-  for (int variant : {3, 4, 3, 4}) {
-#else
-  for (int variant : {4, 3, 4, 3}) {
-#endif
-    psf_g_mlp_bwd_variant.store(variant);
+  for (int rep = 0; rep < 4; ++rep) {
     for (int it = 0; it < 3; ++it)
       if (psf_mlp_bwd_f32(X, T, E, K, A.data(), a.data(), B.data(), h.data(), O.data(), dY.data(), dX, dA.data(), da.data(),
                           dB.data(), db.data(), ws, ws_bytes, nullptr) != 0)
@@ -79,7 +73,7 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    std::printf("variant %d: %.3f ms per call\n", variant, ms / 10);
+    std::printf("mlp_bwd_x3p_k: %.3f ms per call\n", ms / 10);
 #ifdef PSF_PS_GUARD
     {
       unsigned int stuck = 0;

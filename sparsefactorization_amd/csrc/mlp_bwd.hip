@@ -31,15 +31,12 @@
 //
 // Limits: E <= 32 (multiple of 4), h <= 128, O <= 32, K <= 32; anything else stays on autograd.
 //
-// Three kernels share that structure (knob mlp_bwd_variant = 1, 2, 3; 0 = auto -> 3):
-//   mlp_bwd_k      all five GEMMs on v_mfma_f32_32x32x2_f32. That instruction occupies the vector ALU's datapath
-//                  (profiles/r01_mfmalab.log: MFMA cycles and VALU cycles add), so a tile-unit costs 72 x 64 MFMA
-//                  cycles PLUS ~2400 VALU cycles: 1.17 ms at Order N=16384, B=40.
-//   mlp_bwd_x3_k   steps 1, 2, 6 on v_mfma_f32_32x32x16_bf16 with the exact three-way bf16 split
-//                  of mlp_x3_common.h; the token contractions (steps 4, 5) stay on the f32 instruction, their operands
-//                  re-laid through f32 LDS tiles: 1.03 ms.
-//   mlp_bwd_x3p_k  (default) all five GEMMs on the bf16 pipe, every operand split ONCE into bf16 planes in LDS that serve
-//                  both orientations (row reads and ds_read_b64_tr_b16, mlp_planes.h): 0.86 ms. See the comment above it.
+// The kernel: mlp_bwd_x3p_k — all five GEMMs on the bf16 pipe, every operand split ONCE into bf16 planes in LDS that serve
+// both orientations (row reads and ds_read_b64_tr_b16, mlp_planes.h): 0.70 ms at Order N = 16384, B = 40. See the comment above
+// it. (Rounds 1-2 built two predecessors — all five GEMMs on v_mfma_f32_32x32x2_f32, which occupies the vector ALU's datapath:
+// 1.17 ms; steps 1, 2, 6 on the bf16 pipe with the token contractions left on the f32 instruction: 1.03 ms — and round 3 a
+// variant with the SIMD's two waves in producer / consumer roles, 8 % slower: profiles/r02h_*.log, r03ai_mlp_bwd_roles.log. They
+// stayed selectable by knob until round 5 removed them: 1 270 of this file's 1 890 lines.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -50,7 +47,6 @@
 #include "mlp_x3_common.h"
 
 extern "C" int psf_internal_fail(int code, const char* message);
-extern std::atomic<int> psf_g_mlp_bwd_variant;  // psf_chord.hip: tuning knob "mlp_bwd_variant"
 
 namespace {
 
@@ -64,9 +60,6 @@ using psf_x3::split_pack8_pk;
 
 constexpr int kMaxMlps = 32;
 constexpr int kMaxUnits = 128;
-constexpr int kImg = 32 * 33 + 32 + 32 * 33;  // sA [32][33] | sa [32] | sB [32 o][33]  = 2144 floats
-constexpr int kOffSa = 32 * 33;
-constexpr int kOffSb = kOffSa + 32;
 constexpr int kPart = 1024 + 1024 + 64 + 64;  // per (group, unit): dA [j][e] | dB^T [j][o] | da [half][j] | db [half][o]
 constexpr int kSlices = 64;                   // stage-1 reduction slices
 static_assert(kPart % 4 == 0, "the stage-1 reduction reads the partial sums as float4");
@@ -85,8 +78,7 @@ constexpr int kXOffAT = kXOffSa + 128;              // 7808
 constexpr int kXFragTerm = 2 * 2 * 32 * 16;         // 2048
 constexpr int kXOffBT = kXOffAT + 3 * kXFragTerm;   // 13952
 constexpr int kXImgBytes = kXOffBT + 3 * kXFragTerm;  // 20096
-constexpr int kXImgVecs = kXImgBytes / 16;          // 1256
-constexpr int kImgFloatsMax = kXImgBytes / 4 > kImg ? kXImgBytes / 4 : kImg;  // workspace slot per unit, either variant
+constexpr int kImgFloatsMax = kXImgBytes / 4;  // workspace slot per unit (sized for the first split-bf16 image: the planes image is smaller)
 
 struct BwdMlp {
   const float* A;   // [h, E]
@@ -116,15 +108,12 @@ struct BwdArgs {
   int32_t E, K, U;
 };
 
-// y = GELU(x) = x Phi(x) and dy/dx = Phi(x) + x phi(x) for a PAIR of values on packed f32 math (v_pk_fma_f32 /
-// v_pk_mul_f32: two elements per instruction; here VALU cycles add to the f32-MFMA cycles). Phi by Abramowitz &
+// y = GELU(x) = x Phi(x) and dy/dx = Phi(x) + x phi(x). Phi by Abramowitz &
 // Stegun 26.2.17 (|error| <= 7.5e-8): t = 1/(1 + 0.2316419 |x|), q = phi(x) (b1 t + ... + b5 t^5), Phi = x >= 0 ?
 // 1 - q : q, with 1/sqrt(2 pi) folded into the b's; E = exp(-x^2/2) = phi(x) sqrt(2 pi) serves both results.
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-// The same on single values. Packed f32 VALU (v_pk_fma_f32 ...) halves the instruction count but is slow beside MFMAs
+// On single values: packed f32 VALU (v_pk_fma_f32 ...) halves the instruction count but is slow beside MFMAs
 // (MI355X_MICROARCH.md constants table: one v_pk_fma_f32 costs +22 cycles against two v_fma_f32 next to a bf16 MFMA): the
-// kernels whose matrix work runs on the separate bf16 pipe while a sibling wave does this arithmetic use the scalar form
-// (planes kernel 0.873 -> 0.844 ms, profiles/r02ah_nopk.log), the f32-MFMA kernel (shared datapath anyway) the packed one.
+// planes kernel 0.873 -> 0.844 ms with the scalar form (profiles/r02ah_nopk.log; profiles/coexec_lab.hip measures why).
 __device__ __forceinline__ void gelu_and_grad1(float x, float& y, float& dydx) {
   const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.2316419f, 1.0f));
   float p = fmaf(0.53070271f, t, -0.72657602f);
@@ -138,614 +127,6 @@ __device__ __forceinline__ void gelu_and_grad1(float x, float& y, float& dydx) {
   y = x * Phi;
   dydx = fmaf(x * 0.39894228040143267794f, E, Phi);
 }
-__device__ __forceinline__ void gelu_and_grad2(f32x2 x, f32x2& y, f32x2& dydx) {
-  f32x2 t;
-  t.x = __builtin_amdgcn_rcpf(fmaf(fabsf(x.x), 0.2316419f, 1.0f));
-  t.y = __builtin_amdgcn_rcpf(fmaf(fabsf(x.y), 0.2316419f, 1.0f));
-  const f32x2 B5 = {0.53070271f, 0.53070271f}, B4 = {-0.72657602f, -0.72657602f}, B3 = {0.71070687f, 0.71070687f},
-              B2 = {-0.14224837f, -0.14224837f}, B1 = {0.12741479f, 0.12741479f};
-  f32x2 p = __builtin_elementwise_fma(B5, t, B4);
-  p = __builtin_elementwise_fma(p, t, B3);
-  p = __builtin_elementwise_fma(p, t, B2);
-  p = __builtin_elementwise_fma(p, t, B1);
-  p = p * t;
-  const f32x2 c2 = {-0.72134752044448170368f, -0.72134752044448170368f};
-  const f32x2 arg = (x * x) * c2;
-  f32x2 E;
-  E.x = __builtin_amdgcn_exp2f(arg.x);
-  E.y = __builtin_amdgcn_exp2f(arg.y);
-  const f32x2 half2 = {0.5f, 0.5f}, inv_sqrt_2pi = {0.39894228040143267794f, 0.39894228040143267794f};
-  f32x2 dlt = half2 - p * E;  // 0.5 - q >= 0
-  dlt.x = copysignf(dlt.x, x.x);
-  dlt.y = copysignf(dlt.y, x.y);
-  const f32x2 Phi = half2 + dlt;
-  y = x * Phi;
-  dydx = __builtin_elementwise_fma(x * inv_sqrt_2pi, E, Phi);
-}
-
-__global__ void __launch_bounds__(256) mlp_bwd_pack_k(const BwdArgs a) {
-  const int u = blockIdx.x;
-  const BwdMlp d = a.m[a.unit[u] & 0xff];
-  const int ht = 32 * (int)(a.unit[u] >> 8), E = a.E;
-  float* img = a.images + (int64_t)u * kImg;
-  for (int i = threadIdx.x; i < kImg; i += 256) {
-    float v = 0.f;
-    if (i < kOffSa) {
-      const int j = i / 33, e = i - j * 33;
-      if (ht + j < d.h && e < E) v = d.A[(ht + j) * E + e];
-    } else if (i < kOffSb) {
-      const int j = i - kOffSa;
-      if (ht + j < d.h) v = d.a[ht + j];
-    } else {
-      const int q = i - kOffSb, o = q / 33, j = q - o * 33;
-      if (o < d.O && j < 32 && ht + j < d.h) v = d.B[o * d.h + ht + j];
-    }
-    img[i] = v;
-  }
-}
-
-// Rows [t0, t0+32) of a row-major [T, W] array (W <= 32) into the wave's scratch S[tok][33]; rows >= T read as 0.
-// The tile is one contiguous burst of 32*W floats. VEC4 needs W % 4 == 0 and a 16-byte-aligned base.
-template <bool VEC4>
-__device__ __forceinline__ void tile_to_scratch(const float* __restrict__ base, int64_t T, int W, int64_t t0, float* S, int lane) {
-  const int64_t rows_left = T - t0;
-  const int n = (int)(rows_left >= 32 ? 32 : (rows_left > 0 ? rows_left : 0)) * W;
-  const float* src = base + t0 * W;
-  if (VEC4) {
-    for (int f = 4 * lane; f < 32 * W; f += 256) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < n) v = *reinterpret_cast<const float4*>(src + f);
-      const int tok = f / W, col = f - tok * W;
-      float* s = S + tok * 33 + col;
-      s[0] = v.x;
-      s[1] = v.y;
-      s[2] = v.z;
-      s[3] = v.w;
-    }
-  } else {
-    const int q64 = 64 / W, r64 = 64 - q64 * W;
-    int tok = lane / W, col = lane - tok * W;
-    for (int f = lane; f < 32 * W; f += 64) {
-      S[tok * 33 + col] = f < n ? src[f] : 0.f;
-      tok += q64;
-      col += r64;
-      if (col >= W) {
-        col -= W;
-        ++tok;
-      }
-    }
-  }
-}
-
-// launch_bounds(256, 2): two workgroups (8 waves) per CU need <= 256 registers per lane; hipcc then spills ~30
-// registers, all but four scratch accesses of which sit in the per-block prologue / epilogue, not in the unit loop.
-// Unbounded it takes 352 registers (one wave per SIMD, every LDS round trip exposed): 2.46 ms vs the bounded build
-// at Order N=16384, B=40.
-// NDY: registers of the dY prefetch = ceil(32 * max O / 64): 8 for O <= 16, else 16.
-template <int TPW, int NDY>
-__global__ void __launch_bounds__(256, 2)
-mlp_bwd_k(const BwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int c = lane & 31, half = lane >> 5;
-  // per wave: the TPW X tiles [tok][33] (B operand of step 5, read per use: keeping that orientation in registers
-  // too cost 32 of them and pushed the unit loop into scratch spills), the dY tile [tok][SD], the re-layout tile
-  constexpr int SD = NDY == 8 ? 17 : 33;  // odd strides: conflict-free by row and by column
-  constexpr int kImgBufs = NDY == 8 ? 2 : 1;  // O > 16: one image buffer so that two workgroups still fit a CU
-  constexpr int kWaveLds = TPW * 32 * 33 + 32 * SD + 32 * 33;
-  float* SX = lds + kImgBufs * kImg + wv * kWaveLds;
-  float* S1 = SX + TPW * 32 * 33;  // dY tile
-  float* S2 = S1 + 32 * SD;        // re-layout of Hpost^T / G; dX^T at the end
-  const int E = a.E, U = a.U;
-  const int64_t tiles = (a.T + 31) / 32;
-  const int64_t tiles_per_block = 4 * TPW;
-  constexpr int img_vecs = kImg / 4;
-
-  auto stage = [&](int u) {
-    const float* src = a.images + (int64_t)u * kImg;
-    float* dst = lds + (kImgBufs == 2 ? (u & 1) : 0) * kImg;
-    for (int v0 = 0; v0 < img_vecs; v0 += 256) {
-      const int v = v0 + tid;
-      if (v < img_vecs)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * v),
-                                         (__attribute__((address_space(3))) void*)(dst + 4 * (v0 + (tid & ~63))), 16, 0, 0);
-    }
-  };
-
-  for (int64_t blk = blockIdx.x; blk * tiles_per_block < tiles; blk += gridDim.x) {
-    float xr[TPW][16];
-    f32x16 dxa[TPW];
-    int64_t t0[TPW];
-#pragma unroll
-    for (int tp = 0; tp < TPW; ++tp) {
-      t0[tp] = (blk * tiles_per_block + wv * TPW + tp) * 32;
-      float* sx = SX + tp * 32 * 33;
-      tile_to_scratch<true>(a.X, a.T, E, t0[tp], sx, lane);
-      if (E < 32)
-        for (int i = lane; i < 32 * 32; i += 64)
-          if ((i & 31) >= E) sx[(i >> 5) * 33 + (i & 31)] = 0.f;  // columns >= E read as zero
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) xr[tp][kk] = sx[c * 33 + 2 * kk + half];  // X[tok = c][e = 2kk+half]
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dxa[tp][r] = 0.f;
-    }
-    float* part = a.partials + (blk * (int64_t)U) * kPart;  // one partial slot per workgroup
-    // dY tiles are fetched one tile-unit ahead into registers (element lane + 64 i of the 32*O-float burst): with two
-    // waves per SIMD a load consumed right after its issue exposes the whole memory latency once per tile-unit.
-    float dyn[NDY];
-    auto dy_fetch = [&](int u2, int64_t t02) {
-      const BwdMlp& d2 = a.m[a.unit[u2] & 0xff];
-      const int W = d2.O;
-      const int64_t rows_left = a.T - t02;
-      const int n = (int)(rows_left >= 32 ? 32 : (rows_left > 0 ? rows_left : 0)) * W;
-      const float* src = d2.dY + t02 * W;
-#pragma unroll
-      for (int i = 0; i < NDY; ++i) {
-        const int f = lane + 64 * i;
-        dyn[i] = f < n ? src[f] : 0.f;
-      }
-    };
-    auto dy_commit = [&](int W) {  // registers -> S1[tok][33]
-      const int q64 = 64 / W, r64 = 64 - q64 * W;
-      int tok = lane / W, col = lane - tok * W;
-#pragma unroll
-      for (int i = 0; i < NDY; ++i) {
-        if (lane + 64 * i < 32 * W) S1[tok * SD + col] = dyn[i];
-        tok += q64;
-        col += r64;
-        if (col >= W) {
-          col -= W;
-          ++tok;
-        }
-      }
-    };
-    dy_fetch(0, t0[0]);
-    if (kImgBufs == 2) {
-      __syncthreads();  // the previous block's last unit is done with both image buffers
-      stage(0);
-    }
-
-    for (int u = 0; u < U; ++u) {
-      __syncthreads();  // image u has landed (hipcc drains vmcnt before the barrier); unit u-1 is finished
-      if (kImgBufs == 2) {
-        if (u + 1 < U) stage(u + 1);
-      } else {
-        stage(u);
-        __syncthreads();
-      }
-      const float* sA = lds + (kImgBufs == 2 ? (u & 1) : 0) * kImg;
-      const float* sa = sA + kOffSa;
-      const float* sB = sA + kOffSb;
-      const BwdMlp& d = a.m[a.unit[u] & 0xff];
-      const int O = d.O;
-
-      f32x16 dA, dBT;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dA[r] = dBT[r] = 0.f;
-      float da = 0.f, db = 0.f;
-
-#pragma unroll
-      for (int tp = 0; tp < TPW; ++tp) {
-        dy_commit(O);
-        if (tp + 1 < TPW)
-          dy_fetch(u, t0[tp + 1 < TPW ? tp + 1 : 0]);
-        else if (u + 1 < U)
-          dy_fetch(u + 1, t0[0]);
-        if (t0[tp] >= a.T) continue;  // wave-uniform
-        // 1. Hpre^T
-        f32x16 acc1, acc3;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc1[r] = sa[cd_row(r, half)];
-          acc3[r] = 0.f;
-        }
-        const float* arow = sA + c * 33 + half;
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * kk], xr[tp][kk], acc1, 0, 0, 0);
-        // 2. dHpost^T: A operand B[o = 2kk+half][j = c], B operand dY[tok = c][o = 2kk+half]
-#pragma unroll 1
-        for (int kk = 0; 2 * kk < O; ++kk) {
-          const int o = 2 * kk + half;
-          const float dyv = o < O ? S1[c * SD + o] : 0.f;
-          acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(sB[o * 33 + c], dyv, acc3, 0, 0, 0);
-        }
-        // 3. GELU and its derivative; Hpost^T -> S2[j][tok]
-        float g[16];
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          f32x2 y, dy;
-          gelu_and_grad2(f32x2{acc1[r], acc1[r + 1]}, y, dy);
-          S2[cd_row(r, half) * 33 + c] = y.x;
-          S2[cd_row(r + 1, half) * 33 + c] = y.y;
-          g[r] = acc3[r] * dy.x;  // G = dHpre^T
-          g[r + 1] = acc3[r + 1] * dy.y;
-        }
-        // 4. dB^T += Hpost^T[j = c][tok = 2kk+half] · dY[tok = 2kk+half][o = c]
-        {
-          float dbs = 0.f;
-#pragma unroll
-          for (int kk = 0; kk < 16; ++kk) {
-            const int q = 2 * kk + half;
-            const float dyt = c < O ? S1[q * SD + c] : 0.f;
-            dbs += dyt;
-            dBT = __builtin_amdgcn_mfma_f32_32x32x2f32(S2[c * 33 + q], dyt, dBT, 0, 0, 0);
-          }
-          db += dbs;
-        }
-        // 5. dA += G[j = c][tok = 2kk+half] · X[tok = 2kk+half][e = c]   (G re-laid through S2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 33 + c] = g[r];
-        {
-          float das = 0.f;
-#pragma unroll
-          for (int kk = 0; kk < 16; ++kk) {
-            const float gt = S2[c * 33 + 2 * kk + half];
-            das += gt;
-            dA = __builtin_amdgcn_mfma_f32_32x32x2f32(gt, SX[tp * 32 * 33 + (2 * kk + half) * 33 + c], dA, 0, 0, 0);
-          }
-          da += das;
-        }
-        // 6. dX^T += A_u^T · G: k-step r pairs hidden rows {row(r,0), row(r,1)}
-        if (a.dX) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            dxa[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[cd_row(r, half) * 33 + c], g[r], dxa[tp], 0, 0, 0);
-        }
-      }
-      // Combine the four waves' partial sums through LDS (fixed order w = 0..3) and flush once per workgroup: a
-      // quarter of the partial-buffer traffic of per-wave flushes (1.3 GB at Order N=16384, B=40, whose fixed-order
-      // reduction alone took 0.38 ms).
-      float* pu = part + (int64_t)u * kPart;
-      const float* wave0 = lds + kImgBufs * kImg + TPW * 32 * 33;  // wave 0's S1; wave w's is + w * kWaveLds
-      auto sum4 = [&](int off) {  // off: float offset from a wave's S1, 16-byte aligned
-        float4 acc = *reinterpret_cast<const float4*>(wave0 + off);
-#pragma unroll
-        for (int w = 1; w < 4; ++w) {
-          const float4 v = *reinterpret_cast<const float4*>(wave0 + w * kWaveLds + off);
-          acc.x += v.x;
-          acc.y += v.y;
-          acc.z += v.z;
-          acc.w += v.w;
-        }
-        return acc;
-      };
-#pragma unroll
-      for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 32 + c] = dA[r];
-      S1[lane] = da;
-      S1[64 + lane] = db;
-      __syncthreads();
-      *reinterpret_cast<float4*>(pu + wv * 256 + 4 * lane) = sum4(32 * SD + wv * 256 + 4 * lane);
-      if (wv == 0 && lane < 32) *reinterpret_cast<float4*>(pu + 2048 + 4 * lane) = sum4(4 * lane);  // da [2][32] | db [2][32]
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 32 + c] = dBT[r];
-      __syncthreads();
-      *reinterpret_cast<float4*>(pu + 1024 + wv * 256 + 4 * lane) = sum4(32 * SD + wv * 256 + 4 * lane);
-    }
-    __syncthreads();  // all combine reads of S2 are done before the dX epilogue reuses it
-
-    if (a.dX) {
-#pragma unroll
-      for (int tp = 0; tp < TPW; ++tp) {
-        if (t0[tp] >= a.T) continue;
-        // dX^T tile -> S2[tok][e] -> one contiguous burst
-#pragma unroll
-        for (int r = 0; r < 16; ++r) S2[c * 33 + cd_row(r, half)] = dxa[tp][r];
-        const int64_t rem = a.T - t0[tp];
-        const int n_el = (int)(rem < 32 ? rem : 32) * E;
-        float* xt = a.dX + t0[tp] * E;
-        const int q64 = 64 / E, r64 = 64 - q64 * E;
-        int tok = lane / E, e = lane - tok * E;
-        for (int f = lane; f < n_el; f += 64) {
-          xt[f] = S2[tok * 33 + e];
-          tok += q64;
-          e += r64;
-          if (e >= E) {
-            e -= E;
-            ++tok;
-          }
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// split-bf16 variant
-// ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) mlp_bwd_x3_pack_k(const BwdArgs a) {
-  using psf_x3::bf16_bits;
-  using psf_x3::split3;
-  const int u = blockIdx.x;
-  const BwdMlp d = a.m[a.unit[u] & 0xff];
-  const int ht = 32 * (int)(a.unit[u] >> 8), E = a.E;
-  unsigned char* img = reinterpret_cast<unsigned char*>(a.images) + (size_t)u * kXImgBytes;
-  uint16_t* img16 = reinterpret_cast<uint16_t*>(img);
-  float* img32 = reinterpret_cast<float*>(img);
-  for (int i = threadIdx.x; i < 32 * 40; i += 256) {  // A terms [j][e] (the pad columns are written as zeros)
-    const int j = i / 40, e = i - j * 40;
-    const float v = (e < E && ht + j < d.h) ? d.A[(ht + j) * E + e] : 0.f;
-    uint32_t t1, t2, t3;
-    split3(v, t1, t2, t3);
-    img16[(0 * kXATerm + j * kXARow) / 2 + e] = bf16_bits(t1);
-    img16[(1 * kXATerm + j * kXARow) / 2 + e] = bf16_bits(t2);
-    img16[(2 * kXATerm + j * kXARow) / 2 + e] = bf16_bits(t3);
-  }
-  for (int j = threadIdx.x; j < 32; j += 256) img32[kXOffSa / 4 + j] = ht + j < d.h ? d.a[ht + j] : 0.f;
-  for (int q = threadIdx.x; q < 2 * 2 * 32 * 8; q += 256) {
-    const int i = q & 7, col = (q >> 3) & 31, hf = (q >> 8) & 1, s = q >> 9;
-    uint32_t t1, t2, t3;
-    // A^T: [s][half][e = col][i] = A[ht + rho][e]
-    const int rho = (i & 3) + 16 * s + 8 * (i >> 2) + 4 * hf;
-    const float va = (col < E && ht + rho < d.h) ? d.A[(ht + rho) * E + col] : 0.f;
-    split3(va, t1, t2, t3);
-    img16[(kXOffAT + 0 * kXFragTerm) / 2 + q] = bf16_bits(t1);
-    img16[(kXOffAT + 1 * kXFragTerm) / 2 + q] = bf16_bits(t2);
-    img16[(kXOffAT + 2 * kXFragTerm) / 2 + q] = bf16_bits(t3);
-    // B^T: [s][half][j = col][i] = B[o = 16 s + 8 half + i][ht + j]
-    const int o = 16 * s + 8 * hf + i;
-    const float vb = (o < d.O && ht + col < d.h) ? d.B[o * d.h + ht + col] : 0.f;
-    split3(vb, t1, t2, t3);
-    img16[(kXOffBT + 0 * kXFragTerm) / 2 + q] = bf16_bits(t1);
-    img16[(kXOffBT + 1 * kXFragTerm) / 2 + q] = bf16_bits(t2);
-    img16[(kXOffBT + 2 * kXFragTerm) / 2 + q] = bf16_bits(t3);
-  }
-}
-
-__device__ __forceinline__ Frag3 load_frag3(const unsigned char* p, int term_stride) {
-  Frag3 f;
-  f.t1 = *reinterpret_cast<const bf16x8*>(p);
-  f.t2 = *reinterpret_cast<const bf16x8*>(p + term_stride);
-  f.t3 = *reinterpret_cast<const bf16x8*>(p + 2 * term_stride);
-  return f;
-}
-
-// 512 threads: eight waves share one unit image. launch_bounds(512, 1): one workgroup (two waves per SIMD) per CU,
-// <= 256 registers per lane. Steps 4 and 5 (the contractions over tokens) stay on the f32 instruction. (Builds with those
-// two steps on bf16 through a second split per orientation, and with four waves per workgroup and two workgroups per CU,
-// were measured and removed: 1.90 ms spilled / no gain)
-template <int TPW, int NDY>
-__global__ void __launch_bounds__(512, 1)
-mlp_bwd_x3_k(const BwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int c = lane & 31, half = lane >> 5;
-  constexpr int SD = NDY == 8 ? 17 : 33;      // odd strides: conflict-free by row and by column
-  constexpr int NW = 8;
-  constexpr int kImgBufs = NDY == 8 ? 2 : 1;  // O > 16 (wider dY tiles): one image buffer (LDS)
-  constexpr int NS2 = NDY == 8 ? 1 : 2;       // k-steps of step 2 (16 outputs each)
-  constexpr int kWaveLds = TPW * 32 * 33 + 32 * SD + 32 * 33;
-  float* lds_f = reinterpret_cast<float*>(lds_raw + kImgBufs * kXImgBytes);
-  float* SX = lds_f + wv * kWaveLds;  // the wave's X tiles [tok][33] (B operand of step 5)
-  float* S1 = SX + TPW * 32 * 33;     // dY tile [tok][SD]
-  float* S2 = S1 + 32 * SD;           // re-layout of Hpost^T / G; dX^T at the end
-  const int E = a.E, U = a.U;
-  const int64_t tiles = (a.T + 31) / 32;
-  const int64_t tiles_per_block = NW * TPW;
-  const unsigned char* images = reinterpret_cast<const unsigned char*>(a.images);
-
-  auto stage = [&](int u) {
-    const unsigned char* src = images + (size_t)u * kXImgBytes;
-    unsigned char* dst = lds_raw + (kImgBufs == 2 ? (u & 1) : 0) * kXImgBytes;
-    for (int v0 = 0; v0 < kXImgVecs; v0 += 64 * NW) {
-      const int v = v0 + tid;
-      if (v < kXImgVecs)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * v),
-                                         (__attribute__((address_space(3))) void*)(dst + 16 * (v0 + (tid & ~63))), 16, 0, 0);
-    }
-  };
-
-  for (int64_t blk = blockIdx.x; blk * tiles_per_block < tiles; blk += gridDim.x) {
-    Frag3 xf[TPW][2];  // X fragments: k-step s covers e = 16 s + 8 half + (0..7) of the lane's token (B operand, step 1)
-    f32x16 dxa[TPW];
-    int64_t t0[TPW];
-#pragma unroll
-    for (int tp = 0; tp < TPW; ++tp) {
-      t0[tp] = (blk * tiles_per_block + wv * TPW + tp) * 32;
-      float* sx = SX + tp * 32 * 33;
-      tile_to_scratch<true>(a.X, a.T, E, t0[tp], sx, lane);
-      if (E < 32)
-        for (int i = lane; i < 32 * 32; i += 64)
-          if ((i & 31) >= E) sx[(i >> 5) * 33 + (i & 31)] = 0.f;  // columns >= E read as zero
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = sx[c * 33 + 16 * s + 8 * half + i];
-        xf[tp][s] = split_pack8(v);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dxa[tp][r] = 0.f;
-    }
-    float* part = a.partials + (blk * (int64_t)U) * kPart;  // one partial slot per workgroup
-    float dyn[NDY];
-    auto dy_fetch = [&](int u2, int64_t t02) {
-      const BwdMlp& d2 = a.m[a.unit[u2] & 0xff];
-      const int W = d2.O;
-      const int64_t rows_left = a.T - t02;
-      const int n = (int)(rows_left >= 32 ? 32 : (rows_left > 0 ? rows_left : 0)) * W;
-      const float* src = d2.dY + t02 * W;
-#pragma unroll
-      for (int i = 0; i < NDY; ++i) {
-        const int f = lane + 64 * i;
-        dyn[i] = f < n ? src[f] : 0.f;
-      }
-    };
-    auto dy_commit = [&](int W) {  // registers -> S1[tok][SD]
-      const int q64 = 64 / W, r64 = 64 - q64 * W;
-      int tok = lane / W, col = lane - tok * W;
-#pragma unroll
-      for (int i = 0; i < NDY; ++i) {
-        if (lane + 64 * i < 32 * W) S1[tok * SD + col] = dyn[i];
-        tok += q64;
-        col += r64;
-        if (col >= W) {
-          col -= W;
-          ++tok;
-        }
-      }
-    };
-    dy_fetch(0, t0[0]);
-    if (kImgBufs == 2) {
-      __syncthreads();  // the previous block's last unit is done with both image buffers
-      stage(0);
-    }
-
-    for (int u = 0; u < U; ++u) {
-      __syncthreads();  // image u has landed (hipcc drains vmcnt before the barrier); unit u-1 is finished
-      if (kImgBufs == 2) {
-        if (u + 1 < U) stage(u + 1);
-      } else {
-        stage(u);
-        __syncthreads();
-      }
-      const unsigned char* img = lds_raw + (kImgBufs == 2 ? (u & 1) : 0) * kXImgBytes;
-      const float* sa = reinterpret_cast<const float*>(img + kXOffSa);
-      const BwdMlp& d = a.m[a.unit[u] & 0xff];
-      const int O = d.O;
-
-      f32x16 dA, dBT;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dA[r] = dBT[r] = 0.f;
-      float da = 0.f, db = 0.f;
-
-#pragma unroll
-      for (int tp = 0; tp < TPW; ++tp) {
-        dy_commit(O);
-        if (tp + 1 < TPW)
-          dy_fetch(u, t0[tp + 1 < TPW ? tp + 1 : 0]);
-        else if (u + 1 < U)
-          dy_fetch(u + 1, t0[0]);
-        // wave-uniform. (Computing past-the-end tiles on zeros instead, so that the wave's two tiles form ONE basic block
-        // the scheduler can interleave, was tried: hipcc then overlaps both tiles' live ranges and spills, 1.05 -> 1.51 ms.)
-        if (t0[tp] >= a.T) continue;
-        // 1. Hpre^T = A_u X^T + a_u on the bf16 pipe
-        f32x16 acc1, acc3;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc1[r] = sa[cd_row(r, half)];
-          acc3[r] = 0.f;
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          acc1 = mfma6(load_frag3(img + c * kXARow + 32 * s + 16 * half, kXATerm), xf[tp][s], acc1);
-        // 2. dHpost^T = B_u^T dY^T: B operand = dY[tok = c][o = 16 s + 8 half + i], split here
-#pragma unroll
-        for (int s = 0; s < NS2; ++s) {
-          float dv[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int o = 16 * s + 8 * half + i;
-            dv[i] = o < O ? S1[c * SD + o] : 0.f;
-          }
-          acc3 = mfma6(load_frag3(img + kXOffBT + ((s * 2 + half) * 32 + c) * 16, kXFragTerm), split_pack8_pk(dv), acc3);
-        }
-        // 3. GELU and its derivative; Hpost^T -> S2[j][tok]
-        float g[16];
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          f32x2 y, dy;
-          gelu_and_grad2(f32x2{acc1[r], acc1[r + 1]}, y, dy);
-          S2[cd_row(r, half) * 33 + c] = y.x;
-          S2[cd_row(r + 1, half) * 33 + c] = y.y;
-          g[r] = acc3[r] * dy.x;  // G = dHpre^T
-          g[r + 1] = acc3[r + 1] * dy.y;
-        }
-        {
-          // 4. dB^T += Hpost^T[j = c][tok = 2kk+half] · dY[tok = 2kk+half][o = c] on the f32 instruction. (Reading the
-          //    operands of four MFMAs ahead of them was tried: at two tiles per wave the 16 extra live registers go to
-          //    scratch, 1.05 -> 1.52 ms.)
-          {
-            float dbs = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-              const int q = 2 * kk + half;
-              const float dyt = c < O ? S1[q * SD + c] : 0.f;
-              dbs += dyt;
-              dBT = __builtin_amdgcn_mfma_f32_32x32x2f32(S2[c * 33 + q], dyt, dBT, 0, 0, 0);
-            }
-            db += dbs;
-          }
-          // 5. dA += G[j = c][tok = 2kk+half] · X[tok = 2kk+half][e = c]   (G re-laid through S2)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 33 + c] = g[r];
-          {
-            float das = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-              const float gt = S2[c * 33 + 2 * kk + half];
-              das += gt;
-              dA = __builtin_amdgcn_mfma_f32_32x32x2f32(gt, SX[tp * 32 * 33 + (2 * kk + half) * 33 + c], dA, 0, 0, 0);
-            }
-            da += das;
-          }
-        }
-        // 6. dX^T += A_u^T · G on the bf16 pipe: the lane's registers g[8s..8s+7] are its B fragment of k-step s
-        if (a.dX) {
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            float gv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) gv[i] = g[8 * s + i];
-            dxa[tp] = mfma6(load_frag3(img + kXOffAT + ((s * 2 + half) * 32 + c) * 16, kXFragTerm), split_pack8_pk(gv), dxa[tp]);
-          }
-        }
-      }
-      // Combine the eight waves' partial sums through LDS (fixed order w = 0..7) and flush once per workgroup.
-      float* pu = part + (int64_t)u * kPart;
-      const float* wave0 = lds_f + TPW * 32 * 33;  // wave 0's S1; wave w's is + w * kWaveLds
-      auto sum8 = [&](int off) {  // off: float offset from a wave's S1, 16-byte aligned
-        float4 acc = *reinterpret_cast<const float4*>(wave0 + off);
-#pragma unroll
-        for (int w = 1; w < NW; ++w) {
-          const float4 v = *reinterpret_cast<const float4*>(wave0 + w * kWaveLds + off);
-          acc.x += v.x;
-          acc.y += v.y;
-          acc.z += v.z;
-          acc.w += v.w;
-        }
-        return acc;
-      };
-#pragma unroll
-      for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 32 + c] = dA[r];
-      S1[lane] = da;
-      S1[64 + lane] = db;
-      __syncthreads();
-      if (wv < 4) *reinterpret_cast<float4*>(pu + wv * 256 + 4 * lane) = sum8(32 * SD + wv * 256 + 4 * lane);
-      if (wv == NW - 4 && lane < 32) *reinterpret_cast<float4*>(pu + 2048 + 4 * lane) = sum8(4 * lane);  // da [2][32] | db [2][32]
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) S2[cd_row(r, half) * 32 + c] = dBT[r];
-      __syncthreads();
-      if (wv < 4) *reinterpret_cast<float4*>(pu + 1024 + wv * 256 + 4 * lane) = sum8(32 * SD + wv * 256 + 4 * lane);
-    }
-    __syncthreads();  // all combine reads of S2 are done before the dX epilogue reuses it
-
-    if (a.dX) {
-#pragma unroll
-      for (int tp = 0; tp < TPW; ++tp) {
-        if (t0[tp] >= a.T) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) S2[c * 33 + cd_row(r, half)] = dxa[tp][r];
-        const int64_t rem = a.T - t0[tp];
-        const int n_el = (int)(rem < 32 ? rem : 32) * E;
-        float* xt = a.dX + t0[tp] * E;
-        const int q64 = 64 / E, r64 = 64 - q64 * E;
-        int tok = lane / E, e = lane - tok * E;
-        for (int f = lane; f < n_el; f += 64) {
-          xt[f] = S2[tok * 33 + e];
-          tok += q64;
-          e += r64;
-          if (e >= E) {
-            e -= E;
-            ++tok;
-          }
-        }
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // split-bf16 variant on dual-use LDS planes (mlp_planes.h): ALL five GEMMs on the bf16 pipe, every operand split ONCE
 // ------------------------------------------------------------------------------------------------------------------
@@ -773,6 +154,14 @@ constexpr int kPImgBytes = kPOffBT + 3 * kXFragTerm;   // 12416
 constexpr int kPImgVecs = kPImgBytes / 16;             // 776
 constexpr int kPScrBytes = 2 * psf_x3::kPlaneBytes + 512;  // two scratch planes; as f32: combine tile [32][32] | da [2][32] | db [2][32]
 static_assert(kPImgBytes <= kXImgBytes, "the workspace slot per unit is sized for the x3 image");
+
+__device__ __forceinline__ Frag3 load_frag3(const unsigned char* p, int term_stride) {
+  Frag3 f;
+  f.t1 = *reinterpret_cast<const bf16x8*>(p);
+  f.t2 = *reinterpret_cast<const bf16x8*>(p + term_stride);
+  f.t3 = *reinterpret_cast<const bf16x8*>(p + 2 * term_stride);
+  return f;
+}
 
 __global__ void __launch_bounds__(256) mlp_bwd_x3p_pack_k(const BwdArgs a) {
   using psf_x3::bf16_bits;
@@ -1161,524 +550,6 @@ mlp_bwd_x3p_k(const BwdArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// the same arithmetic with the SIMD's two waves in different ROLES (knob mlp_bwd_variant = 4)
-// ------------------------------------------------------------------------------------------------------------------
-// In mlp_bwd_x3p_k every wave runs the whole chain of a tile — matrix steps 1-2, the GELU and the splits on the vector ALU,
-// matrix steps 4-6 — and the SIMD's second wave runs the same chain: each wave's phases wait for each other, both waves
-// meet four workgroup barriers per unit, and the matrix pipe and the vector ALU co-execute for an eighth of the time
-// (profiles/r02ad_mlp_bwd_pmc.json). Here waves 0-3 are PRODUCERS (steps 1, 2, the GELU, the splits, step 6: everything
-// that needs the token on the lane) and waves 4-7 CONSUMERS (the two contractions over tokens, steps 4 and 5, da and db:
-// matrix instructions on transposed LDS reads only, and all weight-gradient sums); wave w and w + 4 share SIMD w
-// (MI355X_MICROARCH.md: a workgroup's waves go to the SIMDs cyclically) and form a PAIR that owns TPW tiles of the block.
-//   * The producer hands each tile-unit over as three pieces through single LDS slots of the pair: the dY terms (D slot),
-//     the Hpost^T terms and the G terms (S slot, one after the other). Hand-over is by sequence counters in LDS that the
-//     partner polls (s_sleep between polls): no workgroup barrier anywhere after the start of the kernel. LDS operations
-//     of one wave execute in order, so "data, then counter" needs no wait on either side.
-//   * The consumers own dA, dB^T, da, db of the unit: the cross-wave combine is among four waves, through the pair's slots
-//     (free at that point), while the producers are already in the next unit's first tile; its arrival and done counters are
-//     LDS atomics.
-//   * The consumers also stage the unit images (LDS-DMA); a producer starts unit g when all four quarters of image g have
-//     landed, a consumer overwrites a buffer when all four producers are done with the unit that used it.
-//   * db = 1^T dY comes off the matrix pipe like da = G 1 (a fragment of ones as the A operand), so the producer has no
-//     per-lane sums and no DPP reduction.
-// All sums keep a fixed order: bit-reproducible. Every wave passes every counter of every (block, unit, tile) exactly once —
-// tiles past the end of the input run as zero tiles — so no wave can wait for a partner that has left.
-constexpr int kPsPairs = 4;
-enum PsFlag : int { kFDReady = 0, kFDFree = 4, kFSReady = 8, kFSFree = 12, kFImgReady = 16, kFUnitDone = 20, kFCombArrive = 24, kFCombDone = 25, kFCount = 32 };
-
-// The counters are addressed as LDS (address space 3): through a generic pointer a volatile access is a FLAT load with
-// s_waitcnt vmcnt(0), which drains the dY prefetch on every poll (first build: 1.2 ms).
-using ps_flag_t = volatile __attribute__((address_space(3))) uint32_t;
-#ifdef PSF_PS_GUARD  // lab builds: a wait that never ends gives up, marks the launch and lets every later wait fall through
-__device__ unsigned int psf_ps_stuck;
-__device__ __forceinline__ void ps_wait_ge(const ps_flag_t* f, uint32_t target) {
-  asm volatile("" ::: "memory");
-  int spins = 0;
-  while ((int32_t)(__builtin_amdgcn_readfirstlane(*f) - target) < 0) {
-    __builtin_amdgcn_s_sleep(1);
-    if (*(volatile unsigned int*)&psf_ps_stuck != 0u) break;
-    if (++spins > (1 << 18)) {
-      psf_ps_stuck = 1u + ((unsigned int)(uintptr_t)f >> 2) % 64u;
-      break;
-    }
-  }
-  asm volatile("" ::: "memory");
-}
-#else
-__device__ __forceinline__ void ps_wait_ge(const ps_flag_t* f, uint32_t target) {
-  asm volatile("" ::: "memory");
-  while ((int32_t)(__builtin_amdgcn_readfirstlane(*f) - target) < 0) __builtin_amdgcn_s_sleep(1);
-  asm volatile("" ::: "memory");
-}
-#endif
-__device__ __forceinline__ void ps_wait4_ge(const ps_flag_t* f, uint32_t target) {
-#pragma unroll
-  for (int i = 0; i < kPsPairs; ++i) ps_wait_ge(f + i, target);
-}
-__device__ __forceinline__ void ps_signal(ps_flag_t* f, uint32_t value) {
-  asm volatile("" ::: "memory");
-  *f = value;
-  asm volatile("" ::: "memory");
-}
-
-// Keeps a computation in the basic block it is written in: hipcc sinks pure arithmetic into the block of its first use,
-// which for values handed over after a poll loop is the far side of the loop — out of the matrix instructions' shadow.
-__device__ __forceinline__ void ps_pin(psf_x3::Split16& x) {
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-    asm volatile("" : "+v"(x.d[t][0]), "+v"(x.d[t][1]), "+v"(x.d[t][2]), "+v"(x.d[t][3]), "+v"(x.d[t][4]), "+v"(x.d[t][5]),
-                      "+v"(x.d[t][6]), "+v"(x.d[t][7]));
-}
-__device__ __forceinline__ void ps_pin(float (&x)[16]) {
-#pragma unroll
-  for (int t = 0; t < 16; t += 8)
-    asm volatile("" : "+v"(x[t]), "+v"(x[t + 1]), "+v"(x[t + 2]), "+v"(x[t + 3]), "+v"(x[t + 4]), "+v"(x[t + 5]), "+v"(x[t + 6]),
-                      "+v"(x[t + 7]));
-}
-
-template <int TPW, int NDY>
-__global__ void __launch_bounds__(512, 1)
-mlp_bwd_ps_k(const BwdArgs a) {
-  using namespace psf_x3;
-  constexpr int NS2 = NDY / 8;
-  constexpr int kDyPlane = NDY == 8 ? 1024 : kPlaneBytes;  // [32 tok][16 o] in 32-byte rows, or a full swizzled plane
-  constexpr int kXBytes = TPW * 3 * kPlaneBytes;
-  constexpr int kPairBytes = kXBytes + 3 * kPlaneBytes + 3 * kDyPlane;
-  static_assert(3 * kPlaneBytes + 3 * kDyPlane >= (2048 + 64) * 4, "the pair's slots hold a consumer's sums for the combine");
-  static_assert(2 * kPImgBytes + kPsPairs * kPairBytes + kFCount * 4 <= 160 * 1024, "LDS");
-  __shared__ __attribute__((aligned(16))) unsigned char img_lds[2 * kPImgBytes];
-  __shared__ __attribute__((aligned(16))) unsigned char pair_lds[kPsPairs * kPairBytes];
-  __shared__ uint32_t flag_lds[kFCount];
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 31, half = lane >> 5;
-  const int pr = wv & 3;
-  const bool producer = wv < 4;
-  unsigned char* XP = pair_lds + pr * kPairBytes;  // the pair's X planes [tile][term]
-  unsigned char* SP = XP + kXBytes;                // S slot: three planes [tok][j], Hpost^T terms or G terms
-  unsigned char* DP = SP + 3 * kPlaneBytes;        // D slot: three dY planes [tok][o]
-  ps_flag_t* F = (ps_flag_t*)flag_lds;
-  const PlaneLane L = plane_lane(lane);
-  const int E = a.E, U = a.U;
-  const int64_t tiles = (a.T + 31) / 32;
-  const int64_t tiles_per_block = kPsPairs * TPW;
-  const unsigned char* images = reinterpret_cast<const unsigned char*>(a.images);
-  if (tid < kFCount) flag_lds[tid] = 0u;
-  __syncthreads();
-
-  uint32_t n = 0;  // tile-units of this pair so far (= pieces of the D slot; the S slot has had 2 n)
-  uint32_t g = 0;  // units of this workgroup so far: image g lives in buffer g & 1
-  for (int64_t blk = blockIdx.x; blk * tiles_per_block < tiles; blk += gridDim.x) {
-    const bool last_block = (blk + gridDim.x) * tiles_per_block >= tiles;
-    const int64_t tile0 = blk * tiles_per_block + pr * TPW;  // the pair's first tile
-    if (producer) {
-      // ---------------------------------------------------------------------------------------------- producer
-      // Software pipeline over the pair's U x TPW tile-units (i = u TPW + tp): while the vector ALU runs the GELU and the
-      // splits of tile-unit i, the matrix pipe runs steps 1 and 2 of tile-unit i + 1. A dependent MFMA blocks the wave's
-      // in-order issue until its predecessor retires, so the two only overlap when they alternate in the instruction
-      // stream (sched_group_barrier below).
-      const int NI = U * TPW;
-      float dyn[NDY];
-      // The lane's token, outputs 16 s + 8 half + (0..7). Loads only, no use of the values here (see mlp_bwd_x3p_k): rows past
-      // T and outputs past O read an in-bounds neighbour instead. The unit's dY pointer and width are fetched from the
-      // kernel arguments one step ahead (dy_unit): two dependent scalar loads in front of the address arithmetic cost a
-      // tile-unit ~400 clocks.
-      const float* dy_base = nullptr;
-      int dy_w = 0;
-      auto dy_unit = [&](int u2) {
-        const BwdMlp& d2 = a.m[a.unit[u2] & 0xff];
-        dy_base = d2.dY;
-        dy_w = d2.O;
-      };
-      auto dy_fetch = [&](int tp2) {
-        const int W = dy_w;
-        const int64_t tok = (tile0 + tp2) * 32 + c;
-        const float* src = dy_base + (tok < a.T ? tok : 0) * W;
-#pragma unroll
-        for (int s = 0; s < NS2; ++s)
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int o = 16 * s + 8 * half + i;
-            dyn[8 * s + i] = src[o < W ? o : 0];
-          }
-      };
-      auto dy_split = [&](int i2, Frag3 (&out)[NS2]) {  // consumes dyn
-        const int tp2 = i2 % TPW;
-        const int64_t t02 = (tile0 + tp2) * 32;
-        if (t02 + 32 > a.T) {  // wave-uniform: the partial tile and tiles past the end
-#pragma unroll
-          for (int i = 0; i < NDY; ++i) dyn[i] = t02 + c < a.T ? dyn[i] : 0.f;
-        }
-#pragma unroll
-        for (int s = 0; s < NS2; ++s) {
-          const float v[8] = {dyn[8 * s], dyn[8 * s + 1], dyn[8 * s + 2], dyn[8 * s + 3],
-                              dyn[8 * s + 4], dyn[8 * s + 5], dyn[8 * s + 6], dyn[8 * s + 7]};
-          out[s] = split_pack8(v);
-        }
-#pragma unroll
-        for (int s = 0; s < NS2; ++s) asm volatile("" : "+v"(out[s].t1), "+v"(out[s].t2), "+v"(out[s].t3) : : "memory");
-      };
-      auto bias_acc = [&](const unsigned char* img) {
-        f32x16 acc;
-        const float4* sa4 = reinterpret_cast<const float4*>(img + kPOffSa + 64 * half);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 v = sa4[q];
-          acc[4 * q] = v.x;
-          acc[4 * q + 1] = v.y;
-          acc[4 * q + 2] = v.z;
-          acc[4 * q + 3] = v.w;
-        }
-        return acc;
-      };
-      dy_unit(0);
-      dy_fetch(0);
-      ps_wait_ge(F + kFSFree + pr, 2u * n);  // the consumer has read the previous block's X planes for the last time
-#pragma unroll
-      for (int tp = 0; tp < TPW; ++tp) {
-        const int64_t tok = (tile0 + tp) * 32 + c;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int e0 = 16 * s + 8 * half;
-          float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-          if (tok < a.T && e0 < E) lo = *reinterpret_cast<const float4*>(a.X + tok * E + e0);
-          if (tok < a.T && e0 + 4 < E) hi = *reinterpret_cast<const float4*>(a.X + tok * E + e0 + 4);
-          const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-          const Frag3 f = split_pack8(v);
-          unsigned char* xp = XP + tp * 3 * kPlaneBytes + L.row[s];
-          *reinterpret_cast<bf16x8*>(xp) = f.t1;
-          *reinterpret_cast<bf16x8*>(xp + kPlaneBytes) = f.t2;
-          *reinterpret_cast<bf16x8*>(xp + 2 * kPlaneBytes) = f.t3;
-        }
-      }
-      // prologue: steps 1 and 2 of tile-unit 0
-      f32x16 acc1, acc3;
-      Frag3 dy3[NS2];
-      ps_wait4_ge(F + kFImgReady, g + 1u);  // all four quarters of image g have landed
-      {
-        const unsigned char* img = img_lds + (g & 1u) * kPImgBytes;
-        acc1 = bias_acc(img);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const Frag3 wa{row_frag(img, L, s), row_frag(img + kPlaneBytes, L, s), row_frag(img + 2 * kPlaneBytes, L, s)};
-          const Frag3 xb{row_frag(XP, L, s), row_frag(XP + kPlaneBytes, L, s), row_frag(XP + 2 * kPlaneBytes, L, s)};
-          acc1 = mfma6(wa, xb, acc1);
-        }
-        dy_split(0, dy3);
-        if (TPW == 1 && U > 1) dy_unit(1);
-        dy_fetch(TPW > 1 ? 1 : 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < NS2; ++s)
-          acc3 = mfma6(load_frag3(img + kPOffBT + ((s * 2 + half) * 32 + c) * 16, kXFragTerm), dy3[s], acc3);
-        if (TPW == 1) ps_signal(F + kFUnitDone + pr, g + 1u);
-      }
-      int un = 0, tpn = 0;  // unit and tile of tile-unit i + 1 (clamped to the last one)
-      int u2 = TPW > 1 ? 0 : (U > 1 ? 1 : 0), tp2 = TPW > 1 ? 1 : 0;  // ... of tile-unit i + 2, whose dY is fetched in step i
-      for (int i = 0; i < NI; ++i, ++n) {
-#ifdef PSF_X3P_TRACE
-        const bool trace_on = blockIdx.x == 300 && i / TPW == 5 && i % TPW < 2;
-        const int tslot = 8 * (i % TPW);
-#endif
-        PSF_TRACE(tslot + 0);
-        if (i + 2 < NI) {
-          if (++tp2 == TPW) {
-            tp2 = 0;
-            dy_unit(++u2);  // scalar loads now, used in A2
-          }
-        }
-        const bool next = i + 1 < NI;
-        if (next) {
-          if (++tpn == TPW) tpn = 0, ++un;
-          if (tpn == 0) ps_wait4_ge(F + kFImgReady, g + (uint32_t)un + 1u);  // the next unit's image has landed
-        }
-        const unsigned char* imgn = img_lds + ((g + (uint32_t)un) & 1u) * kPImgBytes;
-        const unsigned char* xpn = XP + tpn * 3 * kPlaneBytes;
-        PSF_TRACE(tslot + 1);
-        // A1: GELU and its derivative of tile-unit i, split of Hpost^T  ||  step 1 of tile-unit i + 1
-        f32x16 acc1n = bias_acc(imgn);
-        Frag3 wa[2], xb[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          wa[s] = Frag3{row_frag(imgn, L, s), row_frag(imgn + kPlaneBytes, L, s), row_frag(imgn + 2 * kPlaneBytes, L, s)};
-          xb[s] = Frag3{row_frag(xpn, L, s), row_frag(xpn + kPlaneBytes, L, s), row_frag(xpn + 2 * kPlaneBytes, L, s)};
-        }
-        // Source order IS the issue order here (sched_barrier after every step): the GELU of one pair of values (or the
-        // split of two pairs), then one matrix instruction, which runs while the next step's vector work issues.
-        // The two counters the hand-over needs are read NOW and looked at after the block: a poll costs an LDS round trip
-        // even when the partner is long done.
-        const uint32_t d_free_early = F[kFDFree + pr], s_free_early = F[kFSFree + pr];
-        float y[16], gg[16];
-        Split16 ys;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < 12; ++m) {
-          if (m < 8) {
-            float d0, d1;
-            gelu_and_grad1(acc1[2 * m], y[2 * m], d0);
-            gelu_and_grad1(acc1[2 * m + 1], y[2 * m + 1], d1);
-            gg[2 * m] = acc3[2 * m] * d0;  // G = dHpre^T
-            gg[2 * m + 1] = acc3[2 * m + 1] * d1;
-          } else {
-            split16_pair(y[4 * (m - 8)], y[4 * (m - 8) + 1], ys, 2 * (m - 8));
-            split16_pair(y[4 * (m - 8) + 2], y[4 * (m - 8) + 3], ys, 2 * (m - 8) + 1);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (m < 6) acc1n = mfma6_term(wa[0], xb[0], acc1n, m);
-          else acc1n = mfma6_term(wa[1], xb[1], acc1n, m - 6);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        ps_pin(ys);
-        ps_pin(gg);
-        asm volatile("" : "+v"(acc1n));
-        PSF_TRACE(tslot + 2);
-        // hand-over 1: the dY terms of tile-unit i (split one iteration ago)
-        if ((int32_t)(__builtin_amdgcn_readfirstlane(d_free_early) - n) < 0) ps_wait_ge(F + kFDFree + pr, n);
-        if (NDY == 8) {
-          unsigned char* dp = DP + 32 * c + 16 * half;
-          *reinterpret_cast<bf16x8*>(dp) = dy3[0].t1;
-          *reinterpret_cast<bf16x8*>(dp + kDyPlane) = dy3[0].t2;
-          *reinterpret_cast<bf16x8*>(dp + 2 * kDyPlane) = dy3[0].t3;
-        } else {
-#pragma unroll
-          for (int s = 0; s < NS2; ++s) {
-            *reinterpret_cast<bf16x8*>(DP + L.row[s]) = dy3[s].t1;
-            *reinterpret_cast<bf16x8*>(DP + kDyPlane + L.row[s]) = dy3[s].t2;
-            *reinterpret_cast<bf16x8*>(DP + 2 * kDyPlane + L.row[s]) = dy3[s].t3;
-          }
-        }
-        ps_signal(F + kFDReady + pr, n + 1u);
-        PSF_TRACE(tslot + 3);
-        // hand-over 2: Hpost^T
-        if ((int32_t)(__builtin_amdgcn_readfirstlane(s_free_early) - 2u * n) < 0) ps_wait_ge(F + kFSFree + pr, 2u * n);
-        store_acc_plane(SP, L, ys, 0);
-        store_acc_plane(SP + kPlaneBytes, L, ys, 1);
-        store_acc_plane(SP + 2 * kPlaneBytes, L, ys, 2);
-        ps_signal(F + kFSReady + pr, 2u * n + 1u);
-        PSF_TRACE(tslot + 4);
-        // A2: split of the next tile-unit's dY and of G  ||  step 2 of tile-unit i + 1
-        const uint32_t s_free_early2 = F[kFSFree + pr];
-        Frag3 bt[NS2];
-#pragma unroll
-        for (int s = 0; s < NS2; ++s) bt[s] = load_frag3(imgn + kPOffBT + ((s * 2 + half) * 32 + c) * 16, kXFragTerm);
-        if (i % TPW == 1) PSF_TRACE(16);
-        dy_split(i + 1 < NI ? i + 1 : NI - 1, dy3);
-        if (i % TPW == 1) PSF_TRACE(17);
-        dy_fetch(tp2);
-        if (i % TPW == 1) PSF_TRACE(18);
-        f32x16 acc3n;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc3n[r] = 0.f;
-        Split16 gs;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {  // one matrix instruction of step 2, then one pair of G split
-          if (m < 6 * NS2 && m < 6) acc3n = mfma6_term(bt[0], dy3[0], acc3n, m);
-          else if (NS2 == 2 && m < 8) acc3n = mfma6_term(bt[NS2 - 1], dy3[NS2 - 1], acc3n, m - 6);
-          __builtin_amdgcn_sched_barrier(0);
-          split16_pair(gg[2 * m], gg[2 * m + 1], gs, m);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (NS2 == 2) {
-#pragma unroll
-          for (int k = 2; k < 6; ++k) acc3n = mfma6_term(bt[NS2 - 1], dy3[NS2 - 1], acc3n, k);
-        }
-        ps_pin(gs);
-        asm volatile("" : "+v"(acc3n));
-        PSF_TRACE(tslot + 5);
-        if (next && tpn == TPW - 1) ps_signal(F + kFUnitDone + pr, g + (uint32_t)un + 1u);  // image reads of that unit: all issued
-        // hand-over 3: G
-        if ((int32_t)(__builtin_amdgcn_readfirstlane(s_free_early2) - (2u * n + 1u)) < 0) ps_wait_ge(F + kFSFree + pr, 2u * n + 1u);
-        PSF_TRACE(tslot + 6);
-        store_acc_plane(SP, L, gs, 0);
-        store_acc_plane(SP + kPlaneBytes, L, gs, 1);
-        store_acc_plane(SP + 2 * kPlaneBytes, L, gs, 2);
-        ps_signal(F + kFSReady + pr, 2u * n + 2u);
-        acc1 = acc1n;
-        acc3 = acc3n;
-      }
-      g += (uint32_t)U;
-    } else {
-      // ---------------------------------------------------------------------------------------------- consumer
-      // quarter pr of image `unit` -> buffer `buf` by LDS-DMA (inline assembly: see mlp_bwd_x3p_k)
-      auto stage = [&](int unit, uint32_t buf) {
-        const unsigned char* src = images + (size_t)unit * kXImgBytes;
-        unsigned char* dst = img_lds + buf * kPImgBytes;
-        for (int v0 = 0; v0 < kPImgVecs; v0 += 64 * kPsPairs) {
-          const int v = v0 + 64 * pr + lane;
-          const uint32_t lds_at = __builtin_amdgcn_readfirstlane(
-              (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)(dst + 16 * (v0 + 64 * pr))));
-          uint32_t m0_saved;
-          if (v < kPImgVecs)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(m0_saved) : "s"(lds_at), "v"(src + 16 * v) : "memory");
-        }
-      };
-      float* part = a.partials + (blk * (int64_t)U) * kPart;
-      float* SCR = reinterpret_cast<float*>(SP);  // the pair's two slots as one f32 area for the combine
-      const float* SCR0 = reinterpret_cast<const float*>(pair_lds + kXBytes);
-      const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
-      int dtr[2];  // transposed read of a 32-byte-row dY plane: rows 8 half + 4 t + q, columns 4 p .. 4 p + 3 (NDY == 8)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) dtr[t] = 32 * (8 * half + 4 * t + ((lane >> 2) & 3)) + 8 * (lane & 3);
-      f32x16 dxa[TPW];
-#pragma unroll
-      for (int tp = 0; tp < TPW; ++tp)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dxa[tp][r] = 0.f;
-      for (int u = 0; u < U; ++u, ++g) {
-#ifdef PSF_X3P_TRACE
-        const bool trace_on = blockIdx.x == 300 && u == 5;
-#endif
-        PSF_TRACE(30);
-        if (g == 0) {
-          stage(0, 0u);
-          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-          ps_signal(F + kFImgReady + pr, 1u);
-        }
-        const bool has_next = u + 1 < U || !last_block;
-        if (has_next) {
-          ps_wait4_ge(F + kFUnitDone, g);  // every producer is done with unit g - 1, whose image buffer this one takes
-          stage(u + 1 < U ? u + 1 : 0, (g + 1u) & 1u);
-        }
-        const unsigned char* img = img_lds + (g & 1u) * kPImgBytes;
-        const bool first_block_of_mlp = (a.unit[u] >> 8) == 0;
-        f32x16 dA, dBT, dav, dbv;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dA[r] = dBT[r] = dav[r] = dbv[r] = 0.f;
-#pragma unroll
-        for (int tp = 0; tp < TPW; ++tp, ++n) {
-          const unsigned char* xp = XP + tp * 3 * kPlaneBytes;
-          Frag3 yb[2], ha[2], ga[2], gb[2];
-          if (tp < 2) PSF_TRACE(8 * tp + 0);
-          ps_wait_ge(F + kFDReady + pr, n + 1u);
-          if (tp < 2) PSF_TRACE(8 * tp + 1);
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            if (NDY == 8) {
-              yb[s].t1 = join8(tr_read(DP + dtr[0] + 512 * s), tr_read(DP + dtr[1] + 512 * s));
-              yb[s].t2 = join8(tr_read(DP + kDyPlane + dtr[0] + 512 * s), tr_read(DP + kDyPlane + dtr[1] + 512 * s));
-              yb[s].t3 = join8(tr_read(DP + 2 * kDyPlane + dtr[0] + 512 * s), tr_read(DP + 2 * kDyPlane + dtr[1] + 512 * s));
-            } else {
-              yb[s].t1 = tr_frag(DP, L, s), yb[s].t2 = tr_frag(DP + kDyPlane, L, s), yb[s].t3 = tr_frag(DP + 2 * kDyPlane, L, s);
-            }
-          }
-          if (tp + 1 < TPW) ps_signal(F + kFDFree + pr, n + 1u);  // (a unit's last tile: after the combine)
-          ps_wait_ge(F + kFSReady + pr, 2u * n + 1u);
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-            ha[s].t1 = tr_frag(SP, L, s), ha[s].t2 = tr_frag(SP + kPlaneBytes, L, s), ha[s].t3 = tr_frag(SP + 2 * kPlaneBytes, L, s);
-          ps_signal(F + kFSFree + pr, 2u * n + 1u);
-          if (tp < 2) PSF_TRACE(8 * tp + 2);
-          // 4. dB^T[j][o] += Hpost^T[j][tok] dY[tok][o];  db[o] += 1 dY[tok][o]
-#pragma unroll
-          for (int s = 0; s < 2; ++s) dBT = mfma6(ha[s], yb[s], dBT);
-          if (first_block_of_mlp) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              dbv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, yb[s].t3, dbv, 0, 0, 0);
-              dbv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, yb[s].t2, dbv, 0, 0, 0);
-              dbv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, yb[s].t1, dbv, 0, 0, 0);
-            }
-          }
-          if (tp == 0 && has_next) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's quarter of image g + 1 has landed
-            ps_signal(F + kFImgReady + pr, g + 2u);
-          }
-          if (tp < 2) PSF_TRACE(8 * tp + 3);
-          ps_wait_ge(F + kFSReady + pr, 2u * n + 2u);
-          if (tp < 2) PSF_TRACE(8 * tp + 4);
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            ga[s].t1 = tr_frag(SP, L, s), ga[s].t2 = tr_frag(SP + kPlaneBytes, L, s), ga[s].t3 = tr_frag(SP + 2 * kPlaneBytes, L, s);
-            gb[s].t1 = row_frag(SP, L, s), gb[s].t2 = row_frag(SP + kPlaneBytes, L, s), gb[s].t3 = row_frag(SP + 2 * kPlaneBytes, L, s);
-          }
-          if (tp + 1 < TPW) ps_signal(F + kFSFree + pr, 2u * n + 2u);
-          // 5. dA[j][e] += G[j][tok] X[tok][e],  da[j] += G[j][tok] 1
-          // 6. dX^T[e][tok] += A_u^T[e][j] G[j][tok]   (A^T by transposed reads of the image, G by row reads of its planes)
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const Frag3 xb{tr_frag(xp, L, s), tr_frag(xp + kPlaneBytes, L, s), tr_frag(xp + 2 * kPlaneBytes, L, s)};
-            dA = mfma6(ga[s], xb, dA);
-            dav = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[s].t3, ones, dav, 0, 0, 0);
-            dav = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[s].t2, ones, dav, 0, 0, 0);
-            dav = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[s].t1, ones, dav, 0, 0, 0);
-            if (a.dX) {
-              const Frag3 at{tr_frag(img, L, s), tr_frag(img + kPlaneBytes, L, s), tr_frag(img + 2 * kPlaneBytes, L, s)};
-              dxa[tp] = mfma6(at, gb[s], dxa[tp]);
-            }
-          }
-        }
-        // combine among the four consumers (fixed order 0..3) through the pairs' slots, one partial slot per workgroup
-        PSF_TRACE(16);
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int r = 0; r < 16; ++r) SCR[cd_row(r, half) * 32 + c] = dA[r];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) SCR[1024 + cd_row(r, half) * 32 + c] = dBT[r];
-        if (c == 0) {  // every column of dav is da
-#pragma unroll
-          for (int r = 0; r < 16; ++r) SCR[2048 + cd_row(r, half)] = dav[r];
-        }
-        if (half == 0) SCR[2080 + c] = dbv[0];  // every row of dbv is db
-        asm volatile("" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t*)flag_lds + kFCombArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        PSF_TRACE(17);
-        ps_wait_ge(F + kFCombArrive, 4u * (g + 1u));
-        PSF_TRACE(18);
-        float* pu = part + (int64_t)u * kPart;
-        auto sum4 = [&](int off) {  // off: float offset into a consumer's area, 16-byte aligned
-          float4 acc = *reinterpret_cast<const float4*>(SCR0 + off);
-#pragma unroll
-          for (int w = 1; w < kPsPairs; ++w) {
-            const float4 v = *reinterpret_cast<const float4*>(SCR0 + w * (kPairBytes / 4) + off);
-            acc.x += v.x;
-            acc.y += v.y;
-            acc.z += v.z;
-            acc.w += v.w;
-          }
-          return acc;
-        };
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int at = 512 * pr + 256 * i + 4 * lane;
-          *reinterpret_cast<float4*>(pu + at) = sum4(at);
-        }
-        if (lane < 8) {  // da [2][32] | db [2][32]: the whole sums in row 0
-          const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (pr == 0) *reinterpret_cast<float4*>(pu + 2048 + 4 * lane) = sum4(2048 + 4 * lane);
-          else if (pr == 1) *reinterpret_cast<float4*>(pu + 2112 + 4 * lane) = sum4(2080 + 4 * lane);
-          else if (pr == 2) *reinterpret_cast<float4*>(pu + 2080 + 4 * lane) = zero;
-          else *reinterpret_cast<float4*>(pu + 2144 + 4 * lane) = zero;
-        }
-        asm volatile("" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t*)flag_lds + kFCombDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        PSF_TRACE(19);
-        ps_wait_ge(F + kFCombDone, 4u * (g + 1u));
-        PSF_TRACE(20);
-        ps_signal(F + kFDFree + pr, n);        // the slots go back to the producer
-        ps_signal(F + kFSFree + pr, 2u * n);
-      }
-      if (a.dX) {  // the lane holds dX^T[e = 8 gq + 4 half + (0..3)][tok = c] in registers 4 gq .. 4 gq + 3
-#pragma unroll
-        for (int tp = 0; tp < TPW; ++tp) {
-          const int64_t tok = (tile0 + tp) * 32 + c;
-          if (tok < a.T) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-              const int e0 = 8 * gq + 4 * half;
-              if (e0 < E)
-                *reinterpret_cast<float4*>(a.dX + tok * E + e0) =
-                    make_float4(dxa[tp][4 * gq], dxa[tp][4 * gq + 1], dxa[tp][4 * gq + 2], dxa[tp][4 * gq + 3]);
-            }
-          }
-        }
-      }
-    }
-  }
-}
-
 // stage 1: R1[s][i] = sum over the groups of slice s of P[g][i]   (i < U*kPart; fixed order: four interleaved running sums
 // g = g0 + 0, 1, 2, 3 (mod 4), then ((s0 + s1) + s2) + s3). float4 per thread and four loads in flight per running sum: the
 // rolled scalar loop it replaces had one dependent load in flight per thread (49 us for 167 MB at Order N=16384, B=40).
@@ -1751,9 +622,8 @@ __global__ void __launch_bounds__(256) mlp_bwd_reduce2_k(const BwdArgs a) {
 
 struct Plan {
   int U;
-  int tpw;  // tiles per wave: 2, or 1 for short inputs (keeps >= 2 workgroups per CU in flight)
-  int tpw8;
-  int64_t G, G8;
+  int tpw8;  // tiles per wave: 2, or 1 for short inputs (keeps >= 2 workgroups per CU in flight) and for outputs wider than 16
+  int64_t G8;
   uint8_t unit_k[kMaxUnits], unit_hb[kMaxUnits];
 };
 
@@ -1769,21 +639,19 @@ bool make_plan(int64_t T, int32_t E, int32_t K, const int32_t* h, const int32_t*
     }
   }
   const int64_t tiles = (T + 31) / 32;
-  p->tpw = (tiles + 7) / 8 >= 512 ? 2 : 1;
-  // one workgroup (= one partial slot) per waves*TPW tiles: 4 waves (f32 kernel) or 8 (split-bf16 kernel)
-  p->G = (tiles + 4 * p->tpw - 1) / (4 * p->tpw);
+  const int tpw = (tiles + 7) / 8 >= 512 ? 2 : 1;
+  // one workgroup (= one partial slot) per 8 waves x TPW tiles
   int max_o = 1;
   for (int k = 0; k < K; ++k) max_o = O[k] > max_o ? O[k] : max_o;
   // 512-thread kernels: outputs wider than 16 double the dY registers of a lane and two tiles per wave no longer fit 256
   // registers (70 spilled, 0.417 ms at 4 x O = 32, T = 655 k); one tile per wave fits: 0.397 ms.
-  p->tpw8 = max_o > 16 ? 1 : p->tpw;
+  p->tpw8 = max_o > 16 ? 1 : tpw;
   p->G8 = (tiles + 8 * p->tpw8 - 1) / (8 * p->tpw8);
   return true;
 }
 
-// sized for either kernel variant (the knob may change between the workspace query and the call)
 int64_t workspace_floats(const Plan& p) {
-  const int64_t slots = p.G > p.G8 ? p.G : p.G8;
+  const int64_t slots = p.G8;
   return (int64_t)p.U * kImgFloatsMax + slots * p.U * kPart + (int64_t)kSlices * p.U * kPart;
 }
 
@@ -1819,68 +687,39 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   for (int u = 0; u < kMaxUnits; ++u) {
     args.unit[u] = u < p.U ? ((uint32_t)p.unit_k[u] | ((uint32_t)p.unit_hb[u] << 8)) : 0u;
   }
-  const int variant = psf_g_mlp_bwd_variant.load();
-  const bool x3 = variant == 2;                      // the first split-bf16 form (steps 1, 2, 6 on bf16)
   int max_o = 1;
   for (int k = 0; k < K; ++k) max_o = O[k] > max_o ? O[k] : max_o;
-  const bool roles = variant == 4;                   // producer / consumer waves (mlp_bwd_ps_k)
-  const bool planes = variant == 0 || variant == 3 || roles;  // split-bf16 on dual-use LDS planes (the default)
-  const int ps_tiles = kPsPairs * (max_o <= 16 ? 4 : 3);      // tiles per workgroup of mlp_bwd_ps_k
-  if (planes && dX && (reinterpret_cast<uintptr_t>(dX) & 15) != 0)
+  if (dX && (reinterpret_cast<uintptr_t>(dX) & 15) != 0)
     return psf_internal_fail(PSF_E_ALIGN, "psf_mlp_bwd: dX must be 16-byte aligned");
   float* ws = reinterpret_cast<float*>(workspace);
   args.X = X;
   args.dX = dX;
   args.images = ws;
   args.partials = ws + (int64_t)p.U * kImgFloatsMax;
-  args.stage1 = args.partials + (p.G > p.G8 ? p.G : p.G8) * p.U * kPart;
+  args.stage1 = args.partials + p.G8 * p.U * kPart;
   args.T = T;
-  args.G = roles ? ((T + 31) / 32 + ps_tiles - 1) / ps_tiles : (x3 || planes) ? p.G8 : p.G;
+  args.G = p.G8;
   args.E = E;
   args.K = K;
   args.U = p.U;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (planes) hipLaunchKernelGGL(mlp_bwd_x3p_pack_k, dim3(p.U), dim3(256), 0, s, args);
-  else if (x3) hipLaunchKernelGGL(mlp_bwd_x3_pack_k, dim3(p.U), dim3(256), 0, s, args);
-  else hipLaunchKernelGGL(mlp_bwd_pack_k, dim3(p.U), dim3(256), 0, s, args);
+  hipLaunchKernelGGL(mlp_bwd_x3p_pack_k, dim3(p.U), dim3(256), 0, s, args);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
 
   // every slot of the partial buffer is written exactly once: one workgroup per waves*TPW tiles
   const int64_t blocks = args.G;
   if (blocks > 0x7fffffff) return psf_internal_fail(PSF_E_SHAPE, "psf_mlp_bwd: T too large");
-  auto launch = [&](auto kernel, int waves, size_t img_bytes, int tpw, int sd, int img_bufs) {
-    const size_t lds_bytes = (size_t)img_bufs * img_bytes + sizeof(float) * (size_t)waves * (tpw * 32 * 33 + 32 * sd + 32 * 33);
-    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * waves), lds_bytes, s, args);
-  };
   auto launch_planes = [&](auto kernel, int waves) {  // static LDS: 2 images + 8 x (tpw x 3 planes + scratch) = 160,000 B at tpw = 2
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * waves), 0, s, args);
   };
-  if (roles) {
-    if (max_o <= 16) launch_planes(mlp_bwd_ps_k<4, 8>, 8);
-    else launch_planes(mlp_bwd_ps_k<3, 16>, 8);
-  } else if (planes) {
-    if (max_o <= 16) {
-      if (p.tpw8 == 2) launch_planes(mlp_bwd_x3p_k<2, 8>, 8);
-      else launch_planes(mlp_bwd_x3p_k<1, 8>, 8);
-    } else {
-      launch_planes(mlp_bwd_x3p_k<1, 16>, 8);  // make_plan: one tile per wave when an output is wider than 16
-    }
-  } else if (x3) {
-    if (max_o <= 16) {
-      if (p.tpw8 == 2) launch(mlp_bwd_x3_k<2, 8>, 8, kXImgBytes, 2, 17, 2);
-      else launch(mlp_bwd_x3_k<1, 8>, 8, kXImgBytes, 1, 17, 2);
-    } else {
-      launch(mlp_bwd_x3_k<1, 16>, 8, kXImgBytes, 1, 33, 1);  // make_plan: one tile per wave when an output is wider than 16
-    }
-  } else if (max_o <= 16) {
-    if (p.tpw == 2) launch(mlp_bwd_k<2, 8>, 4, kImg * sizeof(float), 2, 17, 2);
-    else launch(mlp_bwd_k<1, 8>, 4, kImg * sizeof(float), 1, 17, 2);
+  if (max_o <= 16) {
+    if (p.tpw8 == 2) launch_planes(mlp_bwd_x3p_k<2, 8>, 8);
+    else launch_planes(mlp_bwd_x3p_k<1, 8>, 8);
   } else {
-    if (p.tpw == 2) launch(mlp_bwd_k<2, 16>, 4, kImg * sizeof(float), 2, 33, 1);
-    else launch(mlp_bwd_k<1, 16>, 4, kImg * sizeof(float), 1, 33, 1);
+    launch_planes(mlp_bwd_x3p_k<1, 16>, 8);  // make_plan: one tile per wave when an output is wider than 16
   }
+  e = hipGetLastError();
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
   const int64_t n = (int64_t)p.U * kPart;
   hipLaunchKernelGGL(mlp_bwd_reduce1_k, dim3((unsigned)((n / 4 + 255) / 256), kSlices), dim3(256), 0, s, args);

@@ -241,11 +241,6 @@ def test_tuning_knobs(lib):
     sfa.set_tuning("mlp_variant", 0)
     with pytest.raises(sfa.PSFLibraryError):
         sfa.set_tuning("mlp_variant", 4)
-    assert sfa.get_tuning("mlp_bwd_variant") == 0  # 0 auto | 1 f32 MFMA | 2 first split-bf16 form | 3 dual-use LDS planes | 4 roles
-    sfa.set_tuning("mlp_bwd_variant", 4)
-    sfa.set_tuning("mlp_bwd_variant", 0)
-    with pytest.raises(sfa.PSFLibraryError):
-        sfa.set_tuning("mlp_bwd_variant", 5)
     assert sfa.get_tuning("fwd_variant") == 0
     sfa.set_tuning("fwd_variant", 1)
     assert "generic" in sfa.describe_fwd(64, 16384, 15, 8)

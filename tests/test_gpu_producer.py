@@ -183,21 +183,11 @@ MLP_TRAIN_CASES = [  # (T, E, [(h, out), ...])
 ]
 
 
-@pytest.fixture(params=[0, 1, 2, 4], ids=["bwd_auto_bf16x3_planes", "bwd_f32_mfma", "bwd_bf16x3_steps126", "bwd_bf16x3_roles"])
-def mlp_bwd_variant(request):
-    """Every kernel of psf_mlp_bwd_f32 (csrc/mlp_bwd.hip): the exact split-bf16 ones (on dual-use LDS planes = the default; the
-    first form with the token contractions on f32; the producer / consumer form) and the all-f32-MFMA one."""
-    import sparsefactorization_amd as sfa
-    sfa.set_tuning("mlp_bwd_variant", request.param)
-    yield request.param
-    sfa.set_tuning("mlp_bwd_variant", 0)
-
-
 @pytest.mark.parametrize("T,E,layers", MLP_TRAIN_CASES + [
     (131072 + 37, 32, [(32, 8), (32, 15), (32, 15)]),  # long input: two tiles per wave
     (131072 + 5, 32, [(32, 32), (64, 17)]),            # long input, outputs wider than 16: one tile per wave
 ])
-def test_fused_mlp_backward_matches_float64_autograd(gpu, T, E, layers, mlp_bwd_variant):
+def test_fused_mlp_backward_matches_float64_autograd(gpu, T, E, layers):
     """psf_mlp_fwd_f32 + psf_mlp_bwd_f32 under autograd vs float64 autograd through the nn modules they replace.
     Tolerance 2e-5 of max|ref| per tensor: f32 sums over up to T products plus a 1.5e-7 erf approximation."""
     import copy
@@ -266,7 +256,7 @@ def test_fused_mlp_forward_backward_random_shapes(gpu, seed):
             assert rel_inf(p.grad.cpu().numpy(), rp.grad.cpu().numpy()) <= 2e-5, (name, T, E, layers)
 
 
-def test_fused_mlp_backward_partial_outputs_and_frozen_input(gpu, mlp_bwd_variant):
+def test_fused_mlp_backward_partial_outputs_and_frozen_input(gpu):
     """Outputs that receive no gradient count as zero; an input that needs no gradient gets none (dX = NULL: every kernel
     variant skips step 6)."""
     from sparsefactorization_amd import fused_mlp
@@ -308,15 +298,6 @@ def test_fused_mlp_backward_refuses_unaligned_dx(gpu):
                              P([grads[0]]), P([grads[1]]), P([grads[2]]), P([grads[3]]), ws.data_ptr(), ws_bytes,
                              torch.cuda.current_stream(gpu).cuda_stream)
     assert rc != 0 and b"dX must be 16-byte aligned" in lib.psf_last_error()
-    sfa.set_tuning("mlp_bwd_variant", 1)  # the f32-MFMA kernel stores dX element-wise: same call, same numbers
-    try:
-        rc = lib.psf_mlp_bwd_f32(x.data_ptr(), T, E, 1, P([params[0]]), P([params[1]]), P([params[2]]), hs, Os, P([gy]), dX.data_ptr(),
-                                 P([grads[0]]), P([grads[1]]), P([grads[2]]), P([grads[3]]), ws.data_ptr(), ws_bytes,
-                                 torch.cuda.current_stream(gpu).cuda_stream)
-        assert rc == 0
-    finally:
-        sfa.set_tuning("mlp_bwd_variant", 0)
-    assert rel_inf(dX.reshape(T, E).cpu().numpy(), dX_ok.cpu().numpy()) <= 2e-5
 
 
 def test_stacked_first_layer_matches_per_module_path(gpu):
