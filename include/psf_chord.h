@@ -427,14 +427,10 @@ int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float
  *   key "mlp_variant": psf_mlp_fwd_f32: 0 = auto (default: the split-bf16 kernel for E <= 32, else the f32-MFMA
  *                      kernel), 1 = f32 MFMA with streamed weights, 2 = f32 MFMA with LDS-resident weights,
  *                      3 = split-bf16 (each f32 operand as three exact bf16 terms, six product terms: f32 accuracy)
- *   key "mlp_fwd_store": split-bf16 MLP forward: 1 = finished output tiles are stored straight from the accumulator registers
- *                      (default), 0 = through an LDS transposition as contiguous bursts (the first form; equal bits)
  *   key "bwd_fused_wg_limit": fused backward step: 0 = automatic (default): three workgroups per CU on launches of >= 4096
  *                      tiles, as many as fit below (five of 256 threads at C = 8); n = at most n (by requesting more LDS).
  *                      Round-4 kernel, rotating operands: 42.3 (what fits) / 40.9 (three) us at Order B = 40, 12.6 / 13.5 on
  *                      2048 tiles
- *   key "mlp_fwd_tpw": split-bf16 MLP forward, tiles of 32 tokens per wave: 0 = by store form (default: one with the direct
- *                      stores — three workgroups per CU —, round 2's length rule otherwise), 1, 2 = forced (equal bits)
  *   key "wide_fuse"  : psf_mlp_wide_fwd_f32: 1 = the second layers of the MLPs with <= 32 outputs run inside the first
  *                      layers' GEMM epilogue when every MLP has 97..128 hidden rows (default), 0 = always the separate kernel
  *   key "mixer_lds"  : psf_mixer_fwd_*: 1 = short sequences take the single-launch LDS-resident mixer (default), 0 = per-step kernels

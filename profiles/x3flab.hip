@@ -8,8 +8,6 @@
 #include <vector>
 
 #include <atomic>
-std::atomic<int> psf_g_mlp_fwd_tpw{0};
-std::atomic<int> psf_g_mlp_fwd_store{1};  // the library defines this knob in psf_chord.hip
 #include "../sparsefactorization_amd/csrc/mlp_fwd_x3.hip"
 
 #define CK(x)                                                                     \

@@ -13,7 +13,7 @@
 // that is 2 k-steps x 6 = 12 MFMAs of 32 cycles instead of 16 of 64, on a pipe that leaves the VALU free for the
 // GELU and the splitting (4 VALU + 1.5 v_perm per value).
 //
-// Structure (as mlp_fwd.hip): a wave owns TPW tiles of 32 tokens and keeps X's split B-operand fragments in
+// Structure (as mlp_fwd.hip): a wave owns one tile of 32 tokens and keeps X's split B-operand fragments in
 // registers for all MLPs; a hidden layer wider than 32 is processed as 32-row units whose second-GEMM results
 // accumulate in the same registers; weights are packed once per call into LDS images (already split, already in
 // operand order) and stream through two LDS buffers by LDS-DMA, one barrier per unit.
@@ -32,15 +32,12 @@
 #include "mlp_x3_image.h"
 #include "psf_common.h"
 
-#include <atomic>
-extern std::atomic<int> psf_g_mlp_fwd_store;  // psf_chord.hip: tuning knob "mlp_fwd_store"
-extern std::atomic<int> psf_g_mlp_fwd_tpw;    // psf_chord.hip: tuning knob "mlp_fwd_tpw"
 
 namespace {
 
 using namespace psf_x3;
 
-constexpr int kScr = 32 * 36;              // per-wave scratch floats: X staging [tok][36], Y transpose [tok][33]
+constexpr int kScr = 32 * 36;              // per-wave scratch floats: X staging [tok][36]
 
 // 4-byte-aligned vectors: hipcc emits global_store_dwordx4 / x3 / x2 for them (rows of O floats are 16-byte aligned only
 // when O is a multiple of 4; gfx950 stores unaligned vectors)
@@ -100,14 +97,14 @@ __device__ __forceinline__ void store_row_groups(PSF_GLOBAL char* yb, const f32x
 }
 
 
-// DIRECT: finished Y^T tiles leave straight from the accumulator registers (knob "mlp_fwd_store" = 1, the default) instead of
-// through the LDS transposition + contiguous bursts of the first form (0): equal bits, 1-10 % less time
-// (profiles/r03ag_mlp_fwd_store_ab.log; keeping the tile in registers and storing it a unit later, ahead of the next
-// barrier's vmcnt(0), measured the same) — per unit the park + flush were ~2000 of ~7700 clocks of a wave.
-template <int TPW, int MODE>  // MODE: 0 = LDS-transposed bursts, 1 = direct stores at the end of the unit
-__global__ void __launch_bounds__(256, 2)  // <= 256 registers: two workgroups (two waves per SIMD) per CU
+// Finished Y^T tiles leave straight from the accumulator registers at the end of their unit. (Rounds 2-3 parked them in LDS and
+// stored them as contiguous bursts at the start of the next unit — equal bits, 1-10 % more time, profiles/r03ag_mlp_fwd_store_ab.log —
+// and had a second instance with two software-pipelined tiles per wave at two workgroups per CU — 4-6 % slower at every length,
+// r03ak_mlp_fwd_tpw_ab.log, and no faster with a scalar GELU, r05p_x3f_scalar_gelu_tpw.log. Both went in round 5 with their knobs.)
+// One tile per wave: 146 registers, three workgroups (three waves per SIMD) per CU.
+__global__ void __launch_bounds__(256, 2)
 x3_fwd_k(const X3Args a) {
-  constexpr bool DIRECT = MODE != 0;
+  constexpr int TPW = 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int c = lane & 31, half = lane >> 5;
@@ -162,66 +159,6 @@ x3_fwd_k(const X3Args a) {
     __syncthreads();  // the previous block's last unit is done with both image buffers
     stage(0);
 
-    // Deferred Y stores. The vmcnt(0) that hipcc puts before every barrier (needed for the LDS-DMA) also waits for
-    // whatever global stores the wave has in flight: stores issued at the END of a unit made every barrier wait a
-    // full write latency (0.27 of 0.69 ms in an ablation). A finished Y^T tile is therefore parked in the wave's
-    // LDS tile buffer and its global stores are issued at the START of the next unit, a whole unit of arithmetic
-    // ahead of the next barrier.
-    int pend = -1;  // MLP whose Y tiles are parked in sw (wave-uniform)
-    // A tile's burst is 32 O contiguous floats, 16-byte aligned when Y is; lane l stores elements 4 (l + 64 j) .. + 3 as ONE
-    // dwordx4 (j = 0, 1; O > 16: up to 4). Sixteen dword stores per flush made the flush a fifth of a unit (1,950 of 9,200
-    // clocks, profiles/r02ai_x3flab.log): a vector store costs the same issue time whatever its width. Element e sits at
-    // sw[tok * 33 + o], (tok, o) = divmod(e, O); the offsets depend on O only (two values per block in PSFNet: g, then the
-    // link MLPs), so the eight of j = 0, 1 are kept in registers (stepping them per element cost ~200 integer instructions
-    // per tile in a kernel that is VALU-issue-bound).
-    int yoff[8], yoff_O = -1;
-    auto flush = [&]() {
-      const X3Mlp& dp = a.m[pend];
-      const int O = dp.O;
-      if (O != yoff_O) {  // wave-uniform
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int e = 4 * (lane + 64 * (i >> 2)) + (i & 3), tok = e / O;
-          yoff[i] = (tok < 32 ? tok : 31) * 33 + (e - tok * O);  // clamped: lanes past the tile read a valid address
-        }
-        yoff_O = O;
-      }
-      const bool vec_ok = (reinterpret_cast<uintptr_t>(dp.Y) & 15) == 0;  // wave-uniform
-#pragma unroll
-      for (int tp = 0; tp < TPW; ++tp) {
-        if (t0[tp] >= a.T) continue;  // wave-uniform
-        const float* st = sw + tp * kScr;
-        const int64_t rem = a.T - t0[tp];
-        const int n_el = (int)(rem < 32 ? rem : 32) * O;  // one contiguous burst of rows*O floats
-        float* __restrict__ yt = dp.Y + t0[tp] * O;
-        if (vec_ok && rem >= 32) {
-          // all LDS reads are issued before the first store
-          float v[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = st[yoff[i]];
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            if (4 * (lane + 64 * j) < n_el)
-              *reinterpret_cast<float4*>(yt + 4 * (lane + 64 * j)) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-          for (int e = 4 * (lane + 128); e < n_el; e += 256) {  // O > 16 only
-            float w[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int tok = (e + i) / O;
-              w[i] = st[tok * 33 + (e + i - tok * O)];
-            }
-            *reinterpret_cast<float4*>(yt + e) = make_float4(w[0], w[1], w[2], w[3]);
-          }
-        } else {  // the partial tile, or an unaligned Y: element by element
-          for (int e = lane; e < n_el; e += 64) {
-            const int tok = e / O;
-            yt[e] = st[tok * 33 + (e - tok * O)];
-          }
-        }
-      }
-      pend = -1;
-    };
-
     // The lane holds Y^T[o = 8 q + 4 half + (0..3)][tok = c] in registers 4 q .. 4 q + 3: up to four consecutive floats of its
     // token's row go out as one (unaligned) vector store per q — no LDS transposition, no parked tile, no flush. Addresses: the
     // tile's first row as a scalar base, the lane's token and half as one 32-bit offset, the q groups as immediates
@@ -260,9 +197,6 @@ x3_fwd_k(const X3Args a) {
       PSF_FTRACE(1);
       if (u + 1 < U) stage(u + 1);
       PSF_FTRACE(6);
-      if constexpr (!DIRECT) {
-        if (pend >= 0) flush();
-      }
       PSF_FTRACE(2);
       const unsigned char* img = lds_raw + (u & 1) * kImgBytes;
       const float* sa = reinterpret_cast<const float*>(img + kOffSa);
@@ -301,42 +235,7 @@ x3_fwd_k(const X3Args a) {
         return split_pack8(g);
       };
 
-      if constexpr (TPW == 2) {
-        // Software pipeline over the wave's two tiles, ONE basic block. A dependent MFMA blocks the wave's in-order
-        // issue until its predecessor retires, so matrix-pipe work only overlaps with VALU work when the two are
-        // interleaved in the instruction stream: the 12 MFMAs of tile 1's first GEMM are spread through the GELU +
-        // split of tile 0's first half, and each 6-MFMA k-step of the second GEMM through the GELU + split of the
-        // next half (sched_group_barrier: 1 MFMA, then a share of the VALU instructions). Tiles past the end of X
-        // hold zeros and are computed like the others (stores are predicated).
-        f32x16 h0, h1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h0[r] = h1[r] = sa[cd_row(r, half)];
-        h0 = mfma6(wa[0], xf[0][0], h0);
-        h0 = mfma6(wa[1], xf[0][1], h0);
-        h1 = mfma6(wa[0], xf[1][0], h1);
-        h1 = mfma6(wa[1], xf[1][1], h1);
-        const Frag3 f00 = half_gelu(h0, 0);
-        acc2[0] = mfma6(wb[0], f00, acc2[0]);
-        const Frag3 f01 = half_gelu(h0, 1);
-        acc2[0] = mfma6(wb[1], f01, acc2[0]);
-        const Frag3 f10 = half_gelu(h1, 0);
-        acc2[1] = mfma6(wb[0], f10, acc2[1]);
-        const Frag3 f11 = half_gelu(h1, 1);
-        acc2[1] = mfma6(wb[1], f11, acc2[1]);
-        // desired order: 12 MFMA (tile 0, GEMM 1) | 12 x {1 MFMA, 17 VALU} | 3 x 6 x {1 MFMA, 34 VALU} | 6 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 17, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 18; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 34, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-      } else {
+      {
 #pragma unroll
         for (int tp = 0; tp < TPW; ++tp) {
           f32x16 acc1;
@@ -352,19 +251,8 @@ x3_fwd_k(const X3Args a) {
       }
 
       PSF_FTRACE(4);
-      if (MODE == 1 && last) {
-        store_direct((int)(a.unit[u] & 0xff), acc2);
-      } else if (!DIRECT && last) {  // park the Y^T tiles as [tok][o] (stride 33); stored at the start of the next unit
-#pragma unroll
-        for (int tp = 0; tp < TPW; ++tp)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sw[tp * kScr + c * 33 + cd_row(r, half)] = acc2[tp][r];
-        pend = (int)(a.unit[u] & 0xff);
-      }
+      if (last) store_direct((int)(a.unit[u] & 0xff), acc2);
       PSF_FTRACE(5);
-    }
-    if constexpr (!DIRECT) {
-      if (pend >= 0) flush();
     }
   }
 }
@@ -406,29 +294,14 @@ hipError_t psf_x3_mlp_fwd_launch(const float* X, int64_t T, int32_t E, int32_t K
     if (e != hipSuccess) return e;
   }
   const int64_t tiles = (T + 31) / 32;
-  const int mode = psf_g_mlp_fwd_store.load();
-  // Tiles per wave. With the direct stores (mode 1) the one-tile instance needs 146 registers, so THREE workgroups share a CU
-  // (12 waves) where the two-tile instance (226) has two: 4-6 % less time at every length (profiles/r03ak_mlp_fwd_tpw_ab.log).
-  // The LDS-transposing form keeps round 2's rule (two tiles once there are >= 512 workgroups of them).
-  int tpw = 1;
-  if (mode != 1) {
-    tpw = 2;
-    while (tpw > 1 && (tiles + 4 * tpw - 1) / (4 * tpw) < 512) tpw >>= 1;
-  }
-  const int forced_tpw = psf_g_mlp_fwd_tpw.load();  // knob "mlp_fwd_tpw": 0 = the rule above
-  if (forced_tpw == 1 || forced_tpw == 2) tpw = forced_tpw;
-  const int64_t blocks_needed = (tiles + 4 * tpw - 1) / (4 * tpw);
+  const int64_t blocks_needed = (tiles + 3) / 4;  // four waves, one tile each
   const int grid = (int)(blocks_needed < 4096 ? blocks_needed : 4096);
-  const size_t lds = 2 * (size_t)kImgBytes + 4 * (size_t)tpw * kScr * sizeof(float);
-  auto launch = [&](auto kernel) {
-    if (lds > 48 * 1024) {
-      e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return;
-    }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, args);
-  };
-  if (tpw == 2) mode == 1 ? launch(x3_fwd_k<2, 1>) : launch(x3_fwd_k<2, 0>);
-  else mode == 1 ? launch(x3_fwd_k<1, 1>) : launch(x3_fwd_k<1, 0>);
+  const size_t lds = 2 * (size_t)kImgBytes + 4 * (size_t)kScr * sizeof(float);
+  if (lds > 48 * 1024) {
+    e = hipFuncSetAttribute((const void*)x3_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(x3_fwd_k, dim3(grid), dim3(256), lds, s, args);
   if (e != hipSuccess) return e;
   return hipGetLastError();
 }

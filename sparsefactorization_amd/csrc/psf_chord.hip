@@ -74,8 +74,6 @@ std::atomic<int> g_mixer_wg_limit{0};  // step kernel that computes its own W (f
 std::atomic<int> psf_g_mlp_variant{0};
 // Fused producer MLP backward: 0 = auto (= 3), 1 = all-f32-MFMA kernel, 2 = split-bf16 kernel with steps 4 and 5 left on
 // the f32 instruction, 3 = split-bf16 kernel on dual-use LDS planes (all five GEMMs on the bf16 matrix pipe)
-std::atomic<int> psf_g_mlp_fwd_tpw{0};    // split-bf16 MLP forward: tiles per wave, 0 = by input length
-std::atomic<int> psf_g_mlp_fwd_store{1};  // split-bf16 MLP forward: 1 = Y tiles stored straight from the accumulators
 std::atomic<int> psf_g_wide_fuse{1};  // wide producer MLPs: second layers of narrow-output MLPs in the forward GEMM's epilogue
 namespace {
 
@@ -103,8 +101,6 @@ Knob g_knobs[] = {
     {"chain_cc", &g_chain_cc, 0, 1},
     {"mlp_variant", &psf_g_mlp_variant, 0, 3},
     {"wide_fuse", &psf_g_wide_fuse, 0, 1},
-    {"mlp_fwd_store", &psf_g_mlp_fwd_store, 0, 1},
-    {"mlp_fwd_tpw", &psf_g_mlp_fwd_tpw, 0, 2},
 };
 
 // One consistent view of the knobs per entry-point call: every extern "C" function takes ONE snapshot and hands it down, so
