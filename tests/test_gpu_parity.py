@@ -662,6 +662,56 @@ def test_chain_backward_residual_gradient_one_pass_sum(gpu):
     assert rel_inf(V0a.grad.cpu().numpy(), V0b.grad.cpu().numpy()) <= 1e-6  # autograd adds the M+1 terms in its own order
 
 
+LIMIT_SHAPES = [
+    # the ends of what the window kernels are compiled for: L = 4 (N = 8) and L = 20 (N = 2^19), the longest sequences with the
+    # narrowest and with 32-channel rows, a batch of one, 64-bit element offsets between batch elements (B N L > 2^31 is out of
+    # reach of a test; B N C 4 bytes > 2^31 is not: 2 x 2^19 x 512 x 4 = 2.1 GB)
+    (3, 8, 4, 4), (1, 1 << 19, 20, 4), (1, 1 << 18, 19, 32), (2, 1 << 16, 17, 8), (1, (1 << 16) + 1, 17, 8), (2, 1 << 19, 20, 512),
+]
+
+
+@pytest.mark.parametrize("B,N,L,C", LIMIT_SHAPES)
+def test_limit_shapes_forward_and_backward(gpu, B, N, L, C):
+    """Forward step (+ residual) and both gradients at the ends of the compiled ranges, against the oracle (sampled rows for the
+    2 GB case: the oracle is a scalar C loop): forward and dV bit for bit, dW to the parity bar."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.chord import _launch_bwd
+    big = B * N * C > (1 << 27)
+    g = torch.Generator(device=gpu).manual_seed(5)
+    Wt = 0.2 * torch.randn(B, N, L, device=gpu, generator=g)
+    Vt = torch.randn(B, N, C, device=gpu, generator=g)
+    Rt = torch.randn(B, N, C, device=gpu, generator=g)
+    out = sfa.chord_spmm(Wt, Vt, Rt)
+    dZt = torch.randn(B, N, C, device=gpu, generator=g)
+    gW = torch.full((B, N, L), float("nan"), device=gpu)
+    gV = torch.full((B, N, C), float("nan"), device=gpu)
+    _launch_bwd(dZt, Wt, Vt, gW, gV, B, N, L, C, N * C, None)
+    assert torch.isfinite(out).all() and torch.isfinite(gW).all() and torch.isfinite(gV).all()
+    if not big:
+        W, V, R, dZ = (t.cpu().numpy() for t in (Wt, Vt, Rt, dZt))
+        assert np.array_equal(out.cpu().numpy(), _oracle_fwd(W, V, R))
+        dF, dV = oc.spmul_bwd(dZ, W, V)
+        assert np.array_equal(gV.cpu().numpy(), dV)
+        assert rel_inf(gW.cpu().numpy(), dF) <= TOL
+        return
+    # sampled rows of the last batch element (its rows lie beyond 2^31 bytes), in float64 from the definition
+    off = [0] + [(1 << k) % N for k in range(L - 1)]
+    b = B - 1
+    rows = torch.tensor([0, 1, 255, 256, N // 2 - 1, N // 2, N - 257, N - 1], device=gpu)
+    W64, V64, dZ64 = Wt[b].double(), Vt[b].double(), dZt[b].double()
+    want = Rt[b, rows].double()
+    wantW = torch.zeros(len(rows), L, dtype=torch.float64, device=gpu)
+    wantV = torch.zeros(len(rows), C, dtype=torch.float64, device=gpu)
+    for k, o in enumerate(off):
+        src = (rows + o) % N
+        want = want + W64[rows, k, None] * V64[src]
+        wantW[:, k] = (dZ64[rows] * V64[src]).sum(-1)
+        back = (rows - o) % N
+        wantV = wantV + W64[back, k, None] * dZ64[back]
+    for got, ref in ((out[b, rows], want), (gW[b, rows], wantW), (gV[b, rows], wantV)):
+        assert float((got.double() - ref).abs().max() / ref.abs().max()) <= TOL
+
+
 def _random_shapes(n, seed):
     rng = np.random.default_rng(seed)
     shapes = []
