@@ -58,6 +58,11 @@ CASES = [
     ("c4", 2, 1000, 8, 24, 4, 10, 4, False),
     ("two_tiles", 2, 512, 32, 32, 8, 10, 9, True),
     ("h96", 2, 2048, 32, 96, 32, 12, 3, True),
+    # the ends of the compiled ranges: L = 20 (N = 2^19: two steps keep the float64 reference cheap), L = 4, E = 4, C = 16 at
+    # the smallest N with 16-channel rows (two 128-row tiles)
+    ("l20_n512k", 1, 1 << 19, 32, 32, 8, 20, 2, True),
+    ("l4_e4", 3, 512, 4, 8, 4, 4, 3, False),
+    ("c16_two_tiles", 2, 256, 32, 32, 16, 9, 8, True),
     # the single-launch LDS-resident mixer (csrc/mixer_lds.h): BASELINE configs[0] and the other shapes of its plan
     ("cfg1", 40, 128, 32, 32, 8, 8, 7, True),
     ("lds_n512", 3, 512, 32, 32, 8, 10, 9, True),
