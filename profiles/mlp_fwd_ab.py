@@ -39,4 +39,5 @@ for T, B in ((1048576, 64), (655360, 40)):
                 outs[name] = [t.clone() for t in y]
     _lib._lib = new
     same = all(torch.equal(a, b) for a, b in zip(outs["this"], outs["other"]))
-    print(f"T={T}: " + "  ".join(f"{k}: {min(v):.4f} ms" for k, v in res.items()) + f"   bit-equal={same}", flush=True)
+    diff = max(float((a - b).abs().max()) for a, b in zip(outs["this"], outs["other"]))
+    print(f"T={T}: " + "  ".join(f"{k}: {min(v):.4f} ms" for k, v in res.items()) + f"   bit-equal={same}  max |diff| = {diff:.3g}", flush=True)
