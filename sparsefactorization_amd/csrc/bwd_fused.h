@@ -250,6 +250,8 @@ chord_bwd_fused_edge_k(const float* __restrict__ dZ, const float* __restrict__ W
   using Cfg = BwdWinCfg<T, L, TGS, 1, NT>;
   constexpr int VEC = Cfg::VEC, TG = Cfg::TG, TR = Cfg::TR, KN = Cfg::KN, NF = Cfg::NF;
   using V4 = Vec<T, VEC>;
+  using F4 = float __attribute__((ext_vector_type(4)));
+  constexpr bool kNtOut = TGS >= 2;  // rows of >= 16 channels: dV and dW leave non-temporally, as in chord_bwd_fused_k
   extern __shared__ __attribute__((aligned(16))) char smem[];
   V4* __restrict__ sZ = reinterpret_cast<V4*>(smem);
   V4* __restrict__ sV = reinterpret_cast<V4*>(smem + Cfg::win_bytes);
@@ -318,7 +320,14 @@ chord_bwd_fused_edge_k(const float* __restrict__ dZ, const float* __restrict__ W
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) axpy_rn<T, VEC>(acc, farW[f], farZ[f]);
-    if (row_ok) st<T, VEC>(dV + ((int64_t)b * N + q) * C + (int64_t)g * VEC, acc);
+    if (row_ok) {
+      if constexpr (kNtOut) {
+        __builtin_nontemporal_store(F4{acc.e[0], acc.e[1], acc.e[2], acc.e[3]},
+                                    reinterpret_cast<F4*>(dV + ((int64_t)b * N + q) * C + (int64_t)g * VEC));
+      } else {
+        st<T, VEC>(dV + ((int64_t)b * N + q) * C + (int64_t)g * VEC, acc);
+      }
+    }
   }
   // (5) dW row dots (the tile's dZ rows are the upper half of the dZ window)
   T dots[L];
@@ -354,7 +363,8 @@ chord_bwd_fused_edge_k(const float* __restrict__ dZ, const float* __restrict__ W
     if (i < nvec) {
       const int f0 = i * VEC;
       if (f0 >= misO && f0 + VEC <= misO + n_el) {
-        st<T, VEC>(Oal + (int64_t)i * VEC, sOutV[i]);
+        if constexpr (kNtOut) __builtin_nontemporal_store(*reinterpret_cast<const F4*>(&sOutV[i]), reinterpret_cast<F4*>(Oal + (int64_t)i * VEC));
+        else st<T, VEC>(Oal + (int64_t)i * VEC, sOutV[i]);
       } else {
 #pragma unroll
         for (int u = 0; u < VEC; ++u)

@@ -136,12 +136,6 @@ chord_dw_win_k(const T* __restrict__ dZ, const T* __restrict__ V, T* __restrict_
       far[j][f] = ld<T, VEC>(Vb + (int64_t)src * C + (int64_t)cgc * VEC);
     }
     dz[j] = ld<T, VEC>(dZ + ((int64_t)b * N + p) * C + (int64_t)cgc * VEC);
-    if constexpr (EDGE) {
-      if (!cg_ok) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) dz[j].e[i] = T(0);  // lanes past the last channel group add nothing
-      }
-    }
   }
   __syncthreads();
 
@@ -161,6 +155,10 @@ chord_dw_win_k(const T* __restrict__ dZ, const T* __restrict__ V, T* __restrict_
       T part = T(0);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) part = add_rn(part, mul_rn(dz[j].e[i], x.e[i]));
+      // Lanes past the last channel group add nothing — by a select, not by a zero factor: their window slots were never
+      // staged, and whatever an earlier kernel left in that LDS (a NaN or Inf pattern) times zero is NaN. (Until round 5 this
+      // zeroed dz instead: dW rows came out NaN once in a while for C / 4 not a power of two, depending on what had run before.)
+      if constexpr (EDGE) part = cg_ok ? part : T(0);
       if constexpr (sizeof(T) == 4) {
         part = row_group_sum<TG>(part);
       } else {

@@ -291,6 +291,36 @@ def test_backward_window_kernels_launch_modes(gpu, B, N, L, C, split):
         assert rel_inf(gW.cpu().numpy(), dF) <= TOL
 
 
+@pytest.mark.parametrize("B,N,L,C", [(2, 54, 8, 88), (3, 515, 9, 24), (2, 1031, 11, 28), (1, 433, 16, 136), (2, 300, 12, 20)])
+def test_dw_window_kernel_ignores_what_earlier_kernels_left_in_lds(gpu, B, N, L, C):
+    """Rows whose channel groups (C / 4) are not a power of two leave lanes of the dW window kernel idle; their window slots
+    are never staged, so those lanes must drop out of the row sum by a select — a zero factor times a stale NaN is NaN (seen
+    as a dW element that stayed NaN once in many runs, depending on the kernels that had used the CU before). Here the
+    same kernel configuration is first run on all-NaN operands of the padded width, on enough workgroups to leave NaN in
+    every LDS slot of every CU, then on the real shape."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.chord import _launch_bwd
+    Cp = 4 << int(np.ceil(np.log2(C // 4)))  # the same lanes per row, every one of them staging
+    Bp = 4096 * 8 // max(N // 8, 1) + 8
+    nanV = torch.full((Bp, N, Cp), float("nan"), device=gpu)
+    nanW = torch.zeros(Bp, N, L, device=gpu)
+    sink = torch.empty(Bp, N, L, device=gpu)
+    W, V, dZ = _mk((B, N, L), 81), _mk((B, N, C), 82), _mk((B, N, C), 83)
+    dF, dV = oc.spmul_bwd(dZ, W, V)
+    Wt, Vt, dZt = _t(W, gpu), _t(V, gpu), _t(dZ, gpu)
+    sfa.set_tuning("dw_variant", 1)  # the window kernel for the padded width too (its default is the chunk-looping kernel)
+    try:
+        for _ in range(3):
+            _launch_bwd(nanV, nanW, nanV, sink, None, Bp, N, L, Cp, N * Cp, None)
+            gW = torch.full_like(Wt, float("nan"))
+            gV = torch.full_like(Vt, float("nan"))
+            _launch_bwd(dZt, Wt, Vt, gW, gV, B, N, L, C, N * C, None)
+            assert np.array_equal(gV.cpu().numpy(), dV)
+            assert rel_inf(gW.cpu().numpy(), dF) <= TOL
+    finally:
+        sfa.set_tuning("dw_variant", 0)
+
+
 @pytest.mark.parametrize("tgs", [0, 4, 5])  # auto / 8 lanes per row chunk / 16
 @pytest.mark.parametrize("split", [0, 1, 2])
 @pytest.mark.parametrize("B,N,L,C", [(2, 2000, 12, 128), (2, 2048, 12, 64), (3, 1000, 11, 32), (1, 4097, 13, 32),
