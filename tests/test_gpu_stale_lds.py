@@ -1,0 +1,102 @@
+"""GPU: results must not depend on what earlier kernels left in LDS.
+
+Every kernel here stages only what it needs; lanes or rows outside a ragged shape read LDS slots nobody wrote. Such a lane
+must leave a sum by a select — a zero factor times a stale NaN is NaN. (Round 5 found the dW window kernel doing the
+latter: a dW element stayed NaN once in many runs, depending on which kernels had used the CU before;
+test_gpu_parity.py::test_dw_window_kernel_ignores_what_earlier_kernels_left_in_lds pins that kernel.) Here every family of
+kernels is run right after launches that leave NaN in the LDS of every CU: the LDS-resident chain on all-NaN operands
+(2 x 66 KB per CU) and the wide-row forward step on all-NaN rows (its own allocation sizes, so other offsets)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_inf
+from oracle import chord_oracle as oc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+_poison_cache = {}
+
+
+def _poison(gpu):
+    import sparsefactorization_amd as sfa
+    if not _poison_cache:
+        B, N, C, L = 2048, 512, 16, 10
+        _poison_cache["chain"] = ([torch.zeros(B, N, L, device=gpu) for _ in range(2)], torch.full((B, N, C), float("nan"), device=gpu))
+        assert "chord_chain_lds_k" in sfa._lib.describe_chain_fwd(B, N, L, C, 2)
+        _poison_cache["wide"] = (torch.zeros(64, 2048, 12, device=gpu), torch.full((64, 2048, 128), float("nan"), device=gpu))
+    with torch.no_grad():
+        Ws, V0 = _poison_cache["chain"]
+        out = sfa.chord_chain(Ws, V0, True)
+        assert bool(torch.isnan(out[0, 0, 0]))
+        W, V = _poison_cache["wide"]
+        sfa.chord_spmm(W, V)
+
+
+def _t(a, gpu):
+    return torch.from_numpy(a).to(gpu)
+
+
+def _mk(shape, seed, scale=1.0):
+    return (scale * np.random.default_rng(seed).standard_normal(shape)).astype(np.float32)
+
+
+# channel groups that are not a power of two (idle lanes), ragged and tiny N, narrow rows on the fused backward step (aligned
+# and edge instances), rows of >= 32 channels (chunk-looping dW), L at both ends
+SHAPES = [(2, 54, 8, 88), (3, 515, 9, 24), (2, 1031, 11, 28), (1, 433, 16, 136), (2, 300, 12, 20), (2, 2048, 12, 8), (2, 1025, 11, 8),
+          (2, 4097, 13, 32), (2, 1000, 12, 128), (3, 37, 5, 12), (1, 700, 20, 4), (2, 640, 4, 36), (2, 777, 9, 16), (1, 2000, 12, 100)]
+
+
+@pytest.mark.parametrize("B,N,L,C", SHAPES)
+def test_chord_steps_after_nan_in_every_lds(gpu, B, N, L, C):
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.chord import _launch_bwd
+    W, V, R, dZ = _mk((B, N, L), 1, 0.5), _mk((B, N, C), 2), _mk((B, N, C), 3), _mk((B, N, C), 4)
+    Wt, Vt, Rt, dZt = _t(W, gpu), _t(V, gpu), _t(R, gpu), _t(dZ, gpu)
+    dF, dV = oc.spmul_bwd(dZ, W, V)
+    _poison(gpu)
+    got = sfa.chord_spmm(Wt, Vt, Rt).cpu().numpy()
+    assert np.array_equal(got, oc.spmul_fwd(W, V, None) + R)
+    for fused in (1, 0):
+        sfa.set_tuning("bwd_fused", fused)
+        try:
+            _poison(gpu)
+            gW = torch.full_like(Wt, float("nan"))
+            gV = torch.full_like(Vt, float("nan"))
+            _launch_bwd(dZt, Wt, Vt, gW, gV, B, N, L, C, N * C, None)
+        finally:
+            sfa.set_tuning("bwd_fused", 1)
+        assert np.array_equal(gV.cpu().numpy(), dV), fused
+        assert rel_inf(gW.cpu().numpy(), dF) <= TOL, fused
+
+
+@pytest.mark.parametrize("B,N,L,C,M", [(3, 128, 8, 8, 7), (2, 100, 7, 12, 3), (5, 512, 10, 4, 9), (2, 37, 5, 20, 4)])
+def test_lds_resident_chain_after_nan_in_every_lds(gpu, B, N, L, C, M):
+    import sparsefactorization_amd as sfa
+    Ws = np.stack([_mk((B, N, L), 10 + m, 0.3) for m in range(M)])
+    V0 = _mk((B, N, C), 9)
+    rows, cols = oc.chord_indices(N, L)
+    want = oc.chain(np.stack([rows, cols]), Ws, V0, True)[-1]
+    Wts, V0t = [_t(Ws[m], gpu) for m in range(M)], _t(V0, gpu)
+    _poison(gpu)
+    with torch.no_grad():
+        got = sfa.chord_chain(Wts, V0t, True).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("case", ["odd", "c4", "imdb", "lds_c4_h128", "cfg1", "l4_e4"])
+def test_fused_mixer_after_nan_in_every_lds(gpu, case):
+    import test_gpu_mixer as tm
+    args = next(c for c in tm.CASES if c[0] == case)
+    _poison(gpu)
+    tm.test_mixer_matches_the_oracle_chain_fed_with_float64_mlp_w(gpu, *args)
+
+
+@pytest.mark.parametrize("i", [2, 3, 4, 5])
+def test_producer_mlps_after_nan_in_every_lds(gpu, i):
+    import test_gpu_producer as tpd
+    _poison(gpu)
+    tpd.test_fused_mlp_forward_matches_pytorch(gpu, *tpd.MLP_CASES[i])
+    _poison(gpu)
+    tpd.test_fused_mlp_backward_matches_float64_autograd(gpu, *tpd.MLP_TRAIN_CASES[i])
