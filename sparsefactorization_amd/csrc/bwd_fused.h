@@ -60,7 +60,6 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
   V4* __restrict__ sZ = reinterpret_cast<V4*>(smem);
   V4* __restrict__ sV = reinterpret_cast<V4*>(smem + Cfg::win_bytes);
   using FC = BwdFusedCfg<L, TGS, NT>;
-  constexpr bool kNtOut = TGS >= 2;  // rows of >= 16 channels store dV and dW non-temporally (see the dV store)
   V4* __restrict__ sWV = reinterpret_cast<V4*>(smem + 2 * Cfg::win_bytes);
   const T* __restrict__ sWF = reinterpret_cast<const T*>(sWV);
   T* __restrict__ sOutF = reinterpret_cast<T*>(sWV);  // the dW tile image: written after the last read of the W tiles
@@ -168,18 +167,12 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
 #pragma unroll
     for (int f = 0; f < NF; ++f) axpy_rn<T, VEC>(acc, farW[f], farZ[f]);
     if (!(ABL & 64) || acc.e[0] == T(12345.678)) {
-      // Rows of >= 16 channels: dV and dW leave non-temporally. A sequence's dZ + V + W is 5 MB at N = 16384, C = 32 — the size of
-      // an XCD's L2, where the tiles re-read them through eight far links; outputs parked there push them out (counters: 174 MB
-      // read per step where 83 are algorithmic, profiles/r05k_shapes_summary.md). us per step, rotating operands, one process:
-      // C = 32: 47.5 -> 42.9 (N = 4096: 22.4 -> 20.8), C = 16: 26.6 -> 23.9; C = 8: 42.3 -> 40.7 alone but 2.19 vs 2.19 ms in the
-      // Order training step, where the next step reads this dV at once: left as it is (profiles/r05n_bwd_nt_store*.log).
-      if constexpr (kNtOut) {
-        using F4 = float __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store(F4{acc.e[0], acc.e[1], acc.e[2], acc.e[3]},
-                                    reinterpret_cast<PSF_GLOBAL F4*>(sbase(reinterpret_cast<char*>(dV + ((int64_t)b * N + q0) * C)) + lane_off(voff)));
-      } else {
-        stg<T, VEC>(sbase(reinterpret_cast<char*>(dV + ((int64_t)b * N + q0) * C)) + lane_off(voff), acc);
-      }
+      // (Non-temporal dV / dW stores for rows of >= 16 channels were in for a while in round 5: with operands rotating through
+      // 640 MB they take 10 % off the step — C = 32, N = 16384: 47.5 -> 42.9 us, counters 174 -> 117 MB read where 83 are
+      // algorithmic, profiles/r05n_bwd_nt_store*.log — but in the training steps, where the next kernel reads this dV at once,
+      // they cost 0.3-1 %: IMDb 1.556 -> 1.571 ms, Pathfinder 0.943 -> 0.952, genome 1.686 -> 1.690, Order 2.19 = 2.19
+      // (profiles/r05x_lra_step_fused_nt_ab2.log, arms interleaved in one process). The step decides: plain stores.)
+      stg<T, VEC>(sbase(reinterpret_cast<char*>(dV + ((int64_t)b * N + q0) * C)) + lane_off(voff), acc);
     }
   }
   // (5) dW row dots (the tile's dZ rows are the upper half of the dZ window)
@@ -225,12 +218,12 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
   for (int n = 0; n < FC::passes; ++n) {
     const int i = n * NT + tid;
     if (n < FC::full || i < FC::tile_vecs) {
-      if constexpr ((ABL & 128) != 0 || kNtOut) {
-        using F4 = float __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store(*reinterpret_cast<const F4*>(&sOutV[i]), reinterpret_cast<PSF_GLOBAL F4*>(ob + ((uint32_t)(n * NT) * 16u + vo)));
-      } else {
-        stg<T, VEC>(ob + ((uint32_t)(n * NT) * 16u + vo), sOutV[i]);
-      }
+      // The dW tile leaves non-temporally: nothing reads it before the MLP backward at the end of the chain, and parked in
+      // L2 it pushes out the dZ / V rows the tiles re-read through their far links. Training steps, arms interleaved in one
+      // process (profiles/r05x_step_fused_dw_nt_ab2.log): Order 2.104 -> 2.079 ms, Pathfinder 0.964 -> 0.955, genome 1.694 ->
+      // 1.684. dV stays a plain store: the next step reads it at once (see the dV store).
+      using F4 = float __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(*reinterpret_cast<const F4*>(&sOutV[i]), reinterpret_cast<PSF_GLOBAL F4*>(ob + ((uint32_t)(n * NT) * 16u + vo)));
     }
   }
 }
@@ -250,8 +243,6 @@ chord_bwd_fused_edge_k(const float* __restrict__ dZ, const float* __restrict__ W
   using Cfg = BwdWinCfg<T, L, TGS, 1, NT>;
   constexpr int VEC = Cfg::VEC, TG = Cfg::TG, TR = Cfg::TR, KN = Cfg::KN, NF = Cfg::NF;
   using V4 = Vec<T, VEC>;
-  using F4 = float __attribute__((ext_vector_type(4)));
-  constexpr bool kNtOut = TGS >= 2;  // rows of >= 16 channels: dV and dW leave non-temporally, as in chord_bwd_fused_k
   extern __shared__ __attribute__((aligned(16))) char smem[];
   V4* __restrict__ sZ = reinterpret_cast<V4*>(smem);
   V4* __restrict__ sV = reinterpret_cast<V4*>(smem + Cfg::win_bytes);
@@ -320,14 +311,7 @@ chord_bwd_fused_edge_k(const float* __restrict__ dZ, const float* __restrict__ W
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) axpy_rn<T, VEC>(acc, farW[f], farZ[f]);
-    if (row_ok) {
-      if constexpr (kNtOut) {
-        __builtin_nontemporal_store(F4{acc.e[0], acc.e[1], acc.e[2], acc.e[3]},
-                                    reinterpret_cast<F4*>(dV + ((int64_t)b * N + q) * C + (int64_t)g * VEC));
-      } else {
-        st<T, VEC>(dV + ((int64_t)b * N + q) * C + (int64_t)g * VEC, acc);
-      }
-    }
+    if (row_ok) st<T, VEC>(dV + ((int64_t)b * N + q) * C + (int64_t)g * VEC, acc);
   }
   // (5) dW row dots (the tile's dZ rows are the upper half of the dZ window)
   T dots[L];
@@ -363,8 +347,8 @@ chord_bwd_fused_edge_k(const float* __restrict__ dZ, const float* __restrict__ W
     if (i < nvec) {
       const int f0 = i * VEC;
       if (f0 >= misO && f0 + VEC <= misO + n_el) {
-        if constexpr (kNtOut) __builtin_nontemporal_store(*reinterpret_cast<const F4*>(&sOutV[i]), reinterpret_cast<F4*>(Oal + (int64_t)i * VEC));
-        else st<T, VEC>(Oal + (int64_t)i * VEC, sOutV[i]);
+        using F4 = float __attribute__((ext_vector_type(4)));  // non-temporal, as in chord_bwd_fused_k
+        __builtin_nontemporal_store(*reinterpret_cast<const F4*>(&sOutV[i]), reinterpret_cast<F4*>(Oal + (int64_t)i * VEC));
       } else {
 #pragma unroll
         for (int u = 0; u < VEC; ++u)

@@ -274,6 +274,9 @@ chord_dv_win_k(const T* __restrict__ dZ, const T* __restrict__ W, T* __restrict_
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) axpy_rn<T, VEC>(acc, farW[j][f], farZ[j][f]);
+    // (Non-temporal dV / dW stores for rows of >= 64 channels: 4-7 % per step with rotating operands, -1 % in the ListOps
+    // training step where the next kernel reads this dV at once; the dW tile alone non-temporal, as in the fused step:
+    // +0.1 % there — profiles/r05x_bwd_wide_nt_ab.log, r05x_lra_step_nt_ab.log, r05x_step_wide_dw_nt_ab.log. Not taken.)
     if (!EDGE || (q < N && cg_ok)) st<T, VEC>(dV + ((int64_t)b * N + q) * C + (int64_t)cg * VEC, acc);
   }
 }
