@@ -221,7 +221,9 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
       // The dW tile leaves non-temporally: nothing reads it before the MLP backward at the end of the chain, and parked in
       // L2 it pushes out the dZ / V rows the tiles re-read through their far links. Training steps, arms interleaved in one
       // process (profiles/r05x_step_fused_dw_nt_ab2.log): Order 2.104 -> 2.079 ms, Pathfinder 0.964 -> 0.955, genome 1.694 ->
-      // 1.684. dV stays a plain store: the next step reads it at once (see the dV store).
+      // 1.684. dV stays a plain store: the next step reads it at once (see the dV store). (The W tiles fetched with the
+      // non-temporal hint instead — each is read by two tiles only —: Order 2.073 -> 2.079, genome 1.681 -> 1.711: no.
+      // profiles/r05y_step_bwd_w_nt_ab.log)
       using F4 = float __attribute__((ext_vector_type(4)));
       __builtin_nontemporal_store(*reinterpret_cast<const F4*>(&sOutV[i]), reinterpret_cast<PSF_GLOBAL F4*>(ob + ((uint32_t)(n * NT) * 16u + vo)));
     }
