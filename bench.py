@@ -737,7 +737,8 @@ def shapes_leg(device):
       * `*_cache_resident`: ONE operand set re-used by every call. Every LRA shape's working set (<= 70 MB) then sits in the
         256 MB Infinity Cache: the figure is a cache-resident rate, NOT an HBM rate (the round-4 review's point), and is named so;
       * `*_rotating`: the calls rotate through enough operand sets to span 2.5 x the Infinity Cache (or 48 sets for the tiny
-        cfg1), as a training step or a stream of batches sees them: the fraction of the HBM roofline.
+        cfg1), as a training step or a stream of batches sees them: the fraction of the HBM roofline. Backward: W, V and dW
+        rotate; dZ is the dV the launch before wrote (two buffers taking turns), as in the chain's backward.
     `*_counters`: memory-side bytes and L2 requests per row of the same kernels from the newest committed per-shape counter
     summary, when it was collected on these sources."""
     import torch
@@ -803,17 +804,16 @@ def shapes_leg(device):
                     bsets = min(bsets, sets * M)
                     flatW = [w for ws in Wsets for w in ws][:bsets]
                     Vs = [torch.randn(B, N, C, device=device, generator=g) for _ in range(bsets)]
-                    dZ = torch.randn(B, N, C, device=device, generator=g)
+                    zz = [torch.randn(B, N, C, device=device, generator=g), torch.empty(B, N, C, device=device)]
                     dWs = [torch.empty_like(flatW[0]) for _ in range(bsets)]
-                    dVs = [torch.empty_like(Vs[0]) for _ in range(bsets)]
                     jt = [0]
 
-                    def bwd_rot():
+                    def bwd_rot():  # W, V, dW new every launch; dZ = the dV of the launch before (as in the chain's backward)
                         s_ = jt[0] % bsets
                         jt[0] += 1
-                        _launch_bwd(dZ, flatW[s_], Vs[s_], dWs[s_], dVs[s_], B, N, L, C, N * C, None)
+                        _launch_bwd(zz[jt[0] & 1], flatW[s_], Vs[s_], dWs[s_], zz[1 - (jt[0] & 1)], B, N, L, C, N * C, None)
 
-                    t_bwd = timed(lambda: _launch_bwd(dZ, flatW[0], Vs[0], dWs[0], dVs[0], B, N, L, C, N * C, None), 40)
+                    t_bwd = timed(lambda: _launch_bwd(zz[0], flatW[0], Vs[0], dWs[0], zz[1], B, N, L, C, N * C, None), 40)
                     t_brot = timed(bwd_rot, max(40, 2 * bsets))
                     bwd_bytes = 4 * B * N * (2 * L + 3 * C)
                     entry.update({"bwd_bytes_per_step": bwd_bytes, "bwd_us_per_step_cache_resident": t_bwd,
@@ -824,7 +824,7 @@ def shapes_leg(device):
                     bc = _counter_traffic(pmc, pkey, "chord_bwd_fused") or _counter_traffic(pmc, pkey, "chord_dv_")
                     if bc is not None:
                         entry["bwd_counters"] = bc
-                    del Vs, dWs, dVs, flatW
+                    del Vs, dWs, zz, flatW
             out[name] = entry
             del Wsets, V0, V0s
             torch.cuda.empty_cache()
@@ -839,10 +839,11 @@ def shapes_leg(device):
 
 
 def backward_vs_stream(device, timed):
-    """The fused backward step of the Temporal-Order training shape (N = 16384, L = 15, C = 8, B = 40) with its operands rotating
-    through ten sets, as a training step sees them (W_m, V_m and the outputs are new every step; dZ is the previous step's
-    output), beside the library's gather-free streaming kernel with the same byte mix on the same operands
-    (psf_stream_mix_bwd_f32: reads W : V : dZ = 2 : 1 : 1, writes dW : dV = 2 : 1). DESIGN.md 4.3."""
+    """The fused backward step of the Temporal-Order training shape (N = 16384, L = 15, C = 8, B = 40) as the chain's backward
+    runs it: W_m, V_m and dW_m are new every launch (ten sets, 1.4 GB), dZ is the dV the previous launch wrote (two buffers
+    taking turns) — beside the library's gather-free streaming kernel with the same byte mix on the same operands
+    (psf_stream_mix_bwd_f32: reads W : V : dZ = 2 : 1 : 1, writes dW : dV = 2 : 1). DESIGN.md 4.3. (Until round 5 dZ was one
+    fixed buffer and dV rotated with the rest: a launch rule that helps there — non-temporal dV — cost time in the real step.)"""
     import torch
     from sparsefactorization_amd import _lib
     from sparsefactorization_amd.chord import _launch_bwd
@@ -850,9 +851,8 @@ def backward_vs_stream(device, timed):
     g = torch.Generator(device=device).manual_seed(11)
     Ws = [0.1 * torch.randn(B, N, L, device=device, generator=g) for _ in range(sets)]
     Vs = [torch.randn(B, N, C, device=device, generator=g) for _ in range(sets)]
-    dZ = torch.randn(B, N, C, device=device, generator=g)
+    zz = [torch.randn(B, N, C, device=device, generator=g), torch.empty(B, N, C, device=device)]
     dWs = [torch.empty_like(Ws[0]) for _ in range(sets)]
-    dVs = [torch.empty_like(Vs[0]) for _ in range(sets)]
     nv = B * N * C // 4
     sW = [torch.empty(8 * nv, device=device).fill_(0.5) for _ in range(sets)]  # the stream kernel's W-like operands: 2 vectors per V vector
     sdW = [torch.empty(8 * nv, device=device) for _ in range(sets)]
@@ -863,17 +863,17 @@ def backward_vs_stream(device, timed):
     def step():
         s = it[0] % sets
         it[0] += 1
-        _launch_bwd(dZ, Ws[s], Vs[s], dWs[s], dVs[s], B, N, L, C, N * C, None)
+        _launch_bwd(zz[it[0] & 1], Ws[s], Vs[s], dWs[s], zz[1 - (it[0] & 1)], B, N, L, C, N * C, None)
 
     def stream_step():
         s = it[0] % sets
         it[0] += 1
-        _lib.check(lib.psf_stream_mix_bwd_f32(sW[s].data_ptr(), Vs[s].data_ptr(), dZ.data_ptr(), sdW[s].data_ptr(), dVs[s].data_ptr(),
-                                              nv, stream), "psf_stream_mix_bwd_f32")
+        _lib.check(lib.psf_stream_mix_bwd_f32(sW[s].data_ptr(), Vs[s].data_ptr(), zz[it[0] & 1].data_ptr(), sdW[s].data_ptr(),
+                                              zz[1 - (it[0] & 1)].data_ptr(), nv, stream), "psf_stream_mix_bwd_f32")
 
     t_step, t_stream = timed(step, 100), timed(stream_step, 100)
     step_bytes, stream_bytes = 4 * B * N * (2 * L + 3 * C), 112 * nv
-    return {"shape": {"B": B, "N": N, "L": L, "C": C}, "operands": f"rotating through {sets} sets, dZ fixed",
+    return {"shape": {"B": B, "N": N, "L": L, "C": C}, "operands": f"W, V, dW rotating through {sets} sets; dZ = the dV of the previous launch (two buffers)",
             "step_us": t_step, "step_bytes": step_bytes, "step_GBps": step_bytes / t_step / 1e3,
             "step_frac_of_hbm_peak": step_bytes / t_step / 1e3 / HBM_PEAK_GBS,
             "stream_us": t_stream, "stream_bytes": stream_bytes, "stream_GBps": stream_bytes / t_stream / 1e3,
