@@ -8,6 +8,8 @@ set -u
 TAG=${1:-r01}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
+rm -rf "$OUT"  # (gpurun MERGES gpurun_out/ back: delete the local copy of an earlier collection under the same tag too, or the
+              #  summariser averages both)
 mkdir -p "$OUT"
 python3 -c "from sparsefactorization_amd.build import csrc_hash; print(csrc_hash())" > "$OUT/csrc_hash.txt"
 cd /tmp && export TMPDIR=/tmp

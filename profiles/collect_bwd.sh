@@ -7,6 +7,8 @@ set -u
 TAG=${1:-r02_bwd}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
+rm -rf "$OUT"  # (gpurun MERGES gpurun_out/ back: delete the local copy of an earlier collection under the same tag too, or the
+              #  summariser averages both)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
