@@ -742,6 +742,53 @@ def test_limit_shapes_forward_and_backward(gpu, B, N, L, C):
         assert float((got.double() - ref).abs().max() / ref.abs().max()) <= TOL
 
 
+def _special(shape, seed, values, frac=0.02):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(shape).astype(np.float32)
+    flat = x.reshape(-1)
+    n = max(4, int(frac * flat.size))
+    flat[rng.choice(flat.size, n, replace=False)] = np.asarray(values, dtype=np.float32)[rng.integers(0, len(values), n)]
+    return x
+
+
+def _same_bits_or_both_nan(a, b):
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+@pytest.mark.parametrize("B,N,L,C", [(2, 2048, 12, 8), (2, 1025, 11, 32), (2, 300, 9, 20), (1, 16384, 15, 8), (2, 2000, 12, 128),
+                                     (3, 128, 8, 8)])
+def test_special_values_propagate_as_in_the_oracle(gpu, B, N, L, C):
+    """NaN, +-Inf, denormals, the smallest normal, +-0 and values near FLT_MAX scattered over W, V, the residual and dZ: the
+    forward step and dV are the oracle's bits (a NaN where the oracle has one, the same denormal, the same sign of zero) on
+    every kernel family; dW, whose row sums run in another order, has the oracle's NaN / +Inf / -Inf pattern exactly and meets
+    the bar elsewhere as long as no partial sum can overflow (the second value set); with values near FLT_MAX in play an
+    overflow in one summation order and not in the other is legitimate, and only elements finite on both sides are compared."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd.chord import _launch_bwd
+    tame = [np.nan, np.inf, -np.inf, 1e-42, -3e-45, 0.0, -0.0, 1.17549435e-38, 2e-38]
+    for values, strict_dw in ((tame + [3e38, -3e38], False), (tame, True)):
+        W, V, R, dZ = (_special((B, N, L), 1, values), _special((B, N, C), 2, values), _special((B, N, C), 3, values),
+                       _special((B, N, C), 4, values))
+        with np.errstate(all="ignore"):
+            want = _oracle_fwd(W, V, R)
+            dF, dV = oc.spmul_bwd(dZ, W, V)
+        got = sfa.chord_spmm(_t(W, gpu), _t(V, gpu), _t(R, gpu)).cpu().numpy()
+        assert _same_bits_or_both_nan(got, want)
+        gW = torch.full((B, N, L), 7.0, device=gpu)
+        gV = torch.full((B, N, C), 7.0, device=gpu)
+        _launch_bwd(_t(dZ, gpu), _t(W, gpu), _t(V, gpu), gW, gV, B, N, L, C, N * C, None)
+        assert _same_bits_or_both_nan(gV.cpu().numpy(), dV)
+        g = gW.cpu().numpy()
+        if strict_dw:
+            assert np.array_equal(np.isnan(g), np.isnan(dF)) and np.array_equal(np.isposinf(g), np.isposinf(dF))
+            assert np.array_equal(np.isneginf(g), np.isneginf(dF))
+            fin = np.isfinite(dF)
+            assert np.max(np.abs(g[fin] - dF[fin])) <= TOL * np.max(np.abs(dF[fin]))
+        else:  # a partial sum that overflows in one order and not in the other: only rows without such values are comparable
+            clean = (np.abs(np.nan_to_num(dZ, nan=0.0, posinf=0.0, neginf=0.0)).max(-1) < 1e30)[..., None] & np.isfinite(dF) & np.isfinite(g)
+            assert np.max(np.abs(g[clean] - dF[clean])) <= TOL * max(1.0, float(np.max(np.abs(dF[clean]))))
+
+
 def _random_shapes(n, seed):
     rng = np.random.default_rng(seed)
     shapes = []
