@@ -231,8 +231,6 @@ def measured_bandwidth(device):
       step's output, residual, output) re-used from step to step, i.e. resident in the Infinity Cache. This is the
       denominator of ``frac_of_measured``: the same bytes from the same places, with no gather and no LDS.
     GB/s of bytes read + written."""
-    import ctypes
-
     import torch
     from sparsefactorization_amd import _lib
     lib = _lib.load()

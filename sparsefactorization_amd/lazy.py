@@ -25,8 +25,6 @@ them in place in between (the reference loop creates a fresh W per factor and ne
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
-
 import torch
 from torch.utils._pytree import tree_map
 

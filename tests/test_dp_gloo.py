@@ -6,7 +6,6 @@ concatenated (global) batch, including parameters that receive no gradient on a 
 import os
 import socket
 
-import pytest
 import torch
 import torch.multiprocessing as mp
 

@@ -8,7 +8,6 @@ import subprocess
 import sys
 
 import pytest
-import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIMS = os.path.join(ROOT, "sparsefactorization_amd", "shims")

@@ -6,7 +6,6 @@ Reference: the MLPs in float64 torch on the CPU, their outputs rounded to f32, t
 Tolerance: max|a - b| <= 1e-5 max|ref| (BASELINE.json) — the fused path's W carries the split-bf16 GEMMs' ~1e-7 relative
 error instead of the f32 rounding of a float64 result, everything after it is the oracle's arithmetic in the oracle's order.
 """
-import ctypes
 
 import numpy as np
 import pytest

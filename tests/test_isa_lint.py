@@ -3,7 +3,6 @@ hand-written streams: each rule fires on the pattern it guards and stays silent 
 import os
 import textwrap
 
-import pytest
 
 from sparsefactorization_amd import build, isa_lint
 
