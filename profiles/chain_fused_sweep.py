@@ -48,6 +48,6 @@ for B, N, M, C in ((32, 2048, 11, 64), (32, 2000, 11, 128), (32, 2048, 11, 128),
     sfa.set_tuning("chain_fused", 1)
     m = {k: statistics.median(v) for k, v in times.items()}
     print(f"B={B:3d} N={N:5d} L={M + 1:2d} C={C:4d}: per-step {m[0]:7.2f} us   one launch where it fits {m[2]:7.2f} us   automatic {m[1]:7.2f} us   one launch with cc auto / 1: {cc_t[0]:6.2f} / {cc_t[1]:6.2f}   "
-          f"{sfa.describe_chain_fwd(B, N, M + 1, C, M)[:60] if hasattr(sfa, 'describe_chain_fwd') else ''}", flush=True)
+          f"{sfa._lib.describe_chain_fwd(B, N, M + 1, C, M)[:60] if hasattr(sfa, 'describe_chain_fwd') else ''}", flush=True)
     del Ws, V0
     torch.cuda.empty_cache()

@@ -40,11 +40,11 @@ for name, B, N, L, C, res in ([] if mixer_only else SHAPES):
                     print(f"  {name} forward step rep {r}: {where(out, first)}", flush=True)
         print(f"{name}: forward step {bad} of {reps} runs differ", flush=True)
         dW0, dV0 = torch.empty_like(W), torch.empty_like(V)
-        _launch_bwd(dZ, W, V, dW0, dV0, B, N, L, C, N * C, None, None, 0)
+        _launch_bwd(dZ, W, V, dW0, dV0, B, N, L, C, N * C, None)
         bad = 0
         for r in range(reps):
             dW, dV = torch.empty_like(W), torch.empty_like(V)
-            _launch_bwd(dZ, W, V, dW, dV, B, N, L, C, N * C, None, None, 0)
+            _launch_bwd(dZ, W, V, dW, dV, B, N, L, C, N * C, None)
             if not (torch.equal(dW, dW0) and torch.equal(dV, dV0)):
                 bad += 1
                 if bad <= 3:
