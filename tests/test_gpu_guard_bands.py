@@ -2,7 +2,8 @@
 
 Every output tensor is a view into a larger buffer with 256 bytes of NaN on either side (the view itself 16-byte aligned, as
 the window kernels want, and — for the chord step — also one float off, which sends the launch to the general instances).
-After the call the bands must still be NaN and the outputs fully written. Shapes: ragged N, channel groups that are not a power
+After the call the bands must still be NaN and the outputs fully written. The operands sit inside NaN bands too: a kernel that
+reads past an operand's ends and USES what it finds shows it in its result (reads that are discarded stay invisible). Shapes: ragged N, channel groups that are not a power
 of two, the fused backward step (aligned and edge instances), wide rows, the LDS-resident chain, the mixers, the producer
 MLPs with partial token tiles."""
 import numpy as np
@@ -30,6 +31,13 @@ def _bands_intact(buf, span):
     return bool(torch.isnan(buf[:lo]).all()) and bool(torch.isnan(buf[hi:]).all()) and not bool(torch.isnan(buf[lo:hi]).any())
 
 
+def _banded_input(a, gpu, shift=0):
+    """The array inside NaN bands: a kernel that reads past an operand's ends and uses what it finds shows NaN in its result."""
+    _, view, _ = _banded(a.shape, gpu, shift)
+    view.copy_(torch.from_numpy(a))
+    return view
+
+
 def _mk(shape, seed, scale=1.0):
     return (scale * np.random.default_rng(seed).standard_normal(shape)).astype(np.float32)
 
@@ -48,7 +56,7 @@ def test_chord_step_and_gradients_stay_inside_their_outputs(gpu, B, N, L, C, shi
     from sparsefactorization_amd import _lib
     from sparsefactorization_amd.chord import _launch_bwd
     W, V, R, dZ = _mk((B, N, L), 1, 0.5), _mk((B, N, C), 2), _mk((B, N, C), 3), _mk((B, N, C), 4)
-    Wt, Vt, Rt, dZt = _t(W, gpu), _t(V, gpu), _t(R, gpu), _t(dZ, gpu)
+    Wt, Vt, Rt, dZt = (_banded_input(a, gpu, shift) for a in (W, V, R, dZ))
     obuf, out, ospan = _banded((B, N, C), gpu, shift)
     lib = _lib.load()
     s = torch.cuda.current_stream(gpu).cuda_stream
@@ -73,7 +81,7 @@ def test_chain_steps_stay_inside_their_outputs(gpu, B, N, L, C, M):
     V0 = _mk((B, N, C), 9)
     rows, cols = oc.chord_indices(N, L)
     want = oc.chain(np.stack([rows, cols]), Ws, V0, True)
-    Wts, V0t = [_t(Ws[m], gpu) for m in range(M)], _t(V0, gpu)
+    Wts, V0t = [_banded_input(Ws[m], gpu) for m in range(M)], _banded_input(V0, gpu)
     outs = [_banded((B, N, C), gpu) for _ in range(M)]
     lib = _lib.load()
     vp = ctypes.c_void_p
@@ -94,7 +102,7 @@ def test_producer_mlps_stay_inside_their_outputs(gpu, T, E, layers):
     from sparsefactorization_amd.psfnet import MLPBlock
     torch.manual_seed(3)
     blocks = [MLPBlock([h, 'GELU'], E, o).to(gpu) for h, o in layers]
-    x = torch.randn(T, E, device=gpu)
+    x = _banded_input(np.random.default_rng(5).standard_normal((T, E)).astype(np.float32), gpu)
     params = fused_mlp._params_of(blocks)
     K = len(layers)
     As, as_, Bs, bs = params[0::4], params[1::4], params[2::4], params[3::4]
@@ -114,7 +122,7 @@ def test_producer_mlps_stay_inside_their_outputs(gpu, T, E, layers):
             assert _bands_intact(buf, span)
             assert rel_inf(view.cpu().numpy(), blk.double()(x.double()).float().cpu().numpy()) <= TOL
             blk.float()
-    gys = [torch.randn(T, o, device=gpu) for _, o in layers]
+    gys = [_banded_input(np.random.default_rng(6 + i).standard_normal((T, o)).astype(np.float32), gpu) for i, (_, o) in enumerate(layers)]
     grads = [_banded(tuple(p.shape), gpu) for p in params]
     dxb = _banded((T, E), gpu)
     wsb = lib.psf_mlp_bwd_workspace(T, E, K, h, O)
