@@ -5,7 +5,7 @@ throughout; with the MLPs in plain PyTorch f32 (library GEMMs + torch GELU) and 
 plain PyTorch too (out = sum_k W[..., k] * roll(V, -off_k) (+ V0) under torch autograd — the arithmetic of
 torch_sparse.spmm(chord index) written with dense ops). Loss per step side by side.
     python profiles/train_route_compare.py [steps]"""
-import os, sys
+import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparsefactorization_amd import fused_mixer, fused_mlp, psf_training, psfnet  # noqa: E402
@@ -31,7 +31,7 @@ def torch_mix(self, data, V, use_residuals, links=None):
     return V
 
 
-traj = {}
+traj, ms = {}, {}
 for route in ("fused", "pytorch", "pure"):
     fused_mlp.enabled = fused_mlp.train_enabled = fused_mlp.wide_enabled = fused_mixer.enabled = (route == "fused")
     psfnet._ChordMixer.mix = torch_mix if route == "pure" else library_mix
@@ -40,6 +40,8 @@ for route in ("fused", "pytorch", "pure"):
     opt = make_adam(net.parameters(), 1e-3)
     loss = torch.nn.MSELoss()
     out = []
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
     for i in range(steps):
         j = i % 50
         x, y = X[j * batch:(j + 1) * batch], Y[j * batch:(j + 1) * batch]
@@ -47,8 +49,10 @@ for route in ("fused", "pytorch", "pure"):
         l = loss(net(x).squeeze(), y)
         l.backward()
         opt.step()
-        out.append(float(l.detach()))
-    traj[route] = out
+        out.append(l.detach())
+    torch.cuda.synchronize()
+    ms[route] = (time.perf_counter() - t_start) / steps * 1e3
+    traj[route] = [float(v) for v in out]
 fused_mlp.enabled = fused_mlp.train_enabled = fused_mlp.wide_enabled = fused_mixer.enabled = True
 psfnet._ChordMixer.mix = library_mix
 a, b, c = traj["fused"], traj["pytorch"], traj["pure"]
@@ -57,5 +61,7 @@ print(f"first step at which the two losses differ by more than 1e-3 relative: {f
 for i in list(range(0, 20)) + list(range(20, steps, max(1, steps // 40))):
     print(f"step {i:4d}: library {a[i]:.6f}   pytorch MLPs {b[i]:.6f} (rel {abs(a[i] - b[i]) / max(abs(b[i]), 1e-12):.1e})   "
           f"pytorch MLPs and chain {c[i]:.6f} (rel {abs(a[i] - c[i]) / max(abs(c[i]), 1e-12):.1e})")
+print(f"ms per training step (wall, {steps} steps): library {ms['fused']:.2f}, pytorch MLPs + library chain {ms['pytorch']:.2f}, "
+      f"pure pytorch (dense-op chain, library GEMMs) {ms['pure']:.2f}")
 print(f"max loss over the run: library {max(a):.3f} (step {a.index(max(a))}), pytorch MLPs {max(b):.3f} (step {b.index(max(b))}), "
       f"pure pytorch {max(c):.3f} (step {c.index(max(c))})")
