@@ -289,20 +289,32 @@ class _ChordChain(torch.autograd.Function):
         # accumulate kernel per step (14 x 9.5 us per Temporal-Order training step)
         sum_once = ctx.use_residual and need_v0 and g.dtype == torch.float32 and (B * N * C) % 4 == 0 and M + 1 <= 32
         res_terms: List[torch.Tensor] = []
-        for m in range(M - 1, -1, -1):
-            x_in = V0 if m == 0 else steps[m - 1]
-            stride = stride0 if m == 0 else N * C
-            if sum_once:
-                res_terms.append(g)
-            elif ctx.use_residual and need_v0:
-                res_acc = g.clone() if res_acc is None else res_acc.add_(g)
-            want_dx = m > 0 or need_v0
-            dW = torch.empty_like(Ws[m]) if need_w[m] else None
-            dX = torch.empty((B, N, C), dtype=g.dtype, device=g.device) if want_dx else None
-            if dW is not None or dX is not None:
-                _launch_bwd(g, Ws[m], x_in, dW, dX, B, N, L, C, stride, ctx.offsets)
-            dWs[m] = dW
-            g = dX
+        # everything that is the same for the M launches is looked up once: the small LRA models are bound by the host, and
+        # the device guard, the stream object and the symbol look-up of _launch_bwd are most of what a launch costs it
+        dev = _require_hip(g, V0, *Ws)
+        fn = getattr(_lib.load(), "psf_chord_spmm_bwd" + _suffix(g))
+        off = _lib.offsets_array(ctx.offsets)
+        rc = 0
+        with torch.cuda.device(dev):
+            stream = _stream_ptr(dev)
+            for m in range(M - 1, -1, -1):
+                x_in = V0 if m == 0 else steps[m - 1]
+                stride = stride0 if m == 0 else N * C
+                if sum_once:
+                    res_terms.append(g)
+                elif ctx.use_residual and need_v0:
+                    res_acc = g.clone() if res_acc is None else res_acc.add_(g)
+                want_dx = m > 0 or need_v0
+                dW = torch.empty_like(Ws[m]) if need_w[m] else None
+                dX = torch.empty((B, N, C), dtype=g.dtype, device=dev) if want_dx else None
+                if dW is not None or dX is not None:
+                    rc = fn(g.data_ptr(), Ws[m].data_ptr(), x_in.data_ptr(), dW.data_ptr() if dW is not None else None,
+                            dX.data_ptr() if dX is not None else None, B, N, L, C, stride, off, stream)
+                    if rc:
+                        break
+                dWs[m] = dW
+                g = dX
+        _lib.check(rc, "psf_chord_spmm_bwd")
         dV0 = None
         if need_v0:
             dV0 = g

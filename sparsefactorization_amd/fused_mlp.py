@@ -40,7 +40,19 @@ _vp = ctypes.c_void_p
 
 
 def _two_layer(block: nn.Module) -> Optional[tuple]:
-    """(lin1, lin2) if ``block.network`` is exactly Linear, GELU(erf), Linear with biases."""
+    """(lin1, lin2) if ``block.network`` is exactly Linear, GELU(erf), Linear with biases.
+    The answer is remembered on the block and re-validated by identity (six dictionary look-ups): the eligibility checks ask
+    it up to four times per block and step, and indexing an nn.Sequential costs microseconds — 0.17 ms of the 1.5 ms the host
+    needs to issue a CIFAR-10 training step (profiles/lra_host_profile.py)."""
+    seen = block.__dict__.get("_psf_two_layer")
+    if seen is not None:
+        net, l1, act, l2 = seen
+        mods = net._modules
+        if (block._modules.get("network") is net and len(mods) == 3 and mods.get("0") is l1 and mods.get("1") is act
+                and mods.get("2") is l2 and act.approximate == "none" and l1._parameters.get("bias") is not None
+                and l2._parameters.get("bias") is not None):
+            return l1, l2
+        del block.__dict__["_psf_two_layer"]
     net = getattr(block, "network", None)
     if not isinstance(net, nn.Sequential) or len(net) != 3:
         return None
@@ -49,6 +61,8 @@ def _two_layer(block: nn.Module) -> Optional[tuple]:
         return None
     if getattr(act, "approximate", "none") != "none" or l1.bias is None or l2.bias is None:
         return None
+    if type(net) is nn.Sequential and all(k in net._modules for k in ("0", "1", "2")):  # (plain containers with the default keys)
+        block.__dict__["_psf_two_layer"] = (net, l1, act, l2)
     return l1, l2
 
 
