@@ -149,6 +149,23 @@ def last_error() -> str:
     return load().psf_last_error().decode("utf-8", "replace")
 
 
+_torch_stream = None  # (raw getter or False, torch.cuda): filled on first use — this module does not import torch at load
+
+
+def stream_ptr(dev) -> int:
+    """The current HIP stream of ``dev`` as the integer the C ABI takes. torch.cuda.current_stream builds a Stream object on every
+    call (3-5 us; a dozen calls per training step of a model whose step the host bounds); the raw getter returns the handle."""
+    global _torch_stream
+    if _torch_stream is None:
+        import torch
+        _torch_stream = (getattr(torch._C, "_cuda_getCurrentRawStream", False), torch.cuda)
+    raw, cuda = _torch_stream
+    if raw:
+        idx = dev.index
+        return raw(cuda.current_device() if idx is None else idx)
+    return cuda.current_stream(dev).cuda_stream
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         kind = "invalid argument" if rc < 0 else "HIP error"

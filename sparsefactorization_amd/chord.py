@@ -47,7 +47,7 @@ def _require_hip(*tensors: torch.Tensor) -> torch.device:
 
 
 def _stream_ptr(dev: torch.device) -> int:
-    return torch.cuda.current_stream(dev).cuda_stream
+    return _lib.stream_ptr(dev)
 
 
 def _norm_offsets(offsets) -> Optional[Tuple[int, ...]]:

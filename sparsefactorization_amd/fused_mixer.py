@@ -157,7 +157,7 @@ def mixer_forward_in(r: Recipe, g: nn.Module, fs: Sequence[nn.Module], use_resid
     with torch.cuda.device(dev):
         rc = lib.psf_mixer_fwd_in_f32(ctypes.byref(spec), B, N, E, M, _ptrs(params[0::4]), _ptrs(params[1::4]), _ptrs(params[2::4]),
                                       _ptrs(params[3::4]), h, C, L, 1 if use_residual else 0, V0.data_ptr(), o_tab, ws.data_ptr(),
-                                      ws_bytes, torch.cuda.current_stream(dev).cuda_stream)
+                                      ws_bytes, _lib.stream_ptr(dev))
     _lib.check(rc, "psf_mixer_fwd_in_f32")
     return bufs[(M - 1) % len(bufs)]
 

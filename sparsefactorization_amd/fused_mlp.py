@@ -120,7 +120,7 @@ def _forward_raw(x2: torch.Tensor, params: Sequence[torch.Tensor]) -> List[torch
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)  # packed weight images
         with torch.cuda.device(dev):
             rc = lib.psf_mlp_fwd_f32(x2.data_ptr(), T, E, K, _ptrs(As), _ptrs(as_), _ptrs(Bs), _ptrs(bs), h, O, _ptrs(ys),
-                                     ws.data_ptr(), ws_bytes, torch.cuda.current_stream(dev).cuda_stream)
+                                     ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
         _lib.check(rc, "psf_mlp_fwd_f32")
         outs.extend(ys)
     return outs
@@ -144,7 +144,7 @@ def _backward_raw(x2: torch.Tensor, params: Sequence[torch.Tensor], gys: Sequenc
         rc = lib.psf_mlp_bwd_f32(x2.data_ptr(), T, E, K, _ptrs(As), _ptrs(as_), _ptrs(Bs), h, O, _ptrs(gys),
                                  dX.data_ptr() if need_dx else None, _ptrs(grads[0::4]), _ptrs(grads[1::4]),
                                  _ptrs(grads[2::4]), _ptrs(grads[3::4]), ws.data_ptr(), ws_bytes,
-                                 torch.cuda.current_stream(dev).cuda_stream)
+                                 _lib.stream_ptr(dev))
     _lib.check(rc, "psf_mlp_bwd_f32")
     return dX, grads
 
@@ -154,7 +154,7 @@ class _FusedMLPFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x2, *params):
-        params = tuple(p.detach().contiguous() for p in params)
+        params = tuple(p if p.is_contiguous() else p.contiguous() for p in params)  # (no graph is recorded in here: no detach)
         ctx.save_for_backward(x2, *params)
         return tuple(_forward_raw(x2, params))
 
@@ -261,7 +261,7 @@ def _wide_forward_raw(x2: torch.Tensor, params: Sequence[torch.Tensor], keep: bo
     with torch.cuda.device(dev):
         rc = lib.psf_mlp_wide_fwd_f32(x2.data_ptr(), T, E, K, _ptrs(As), _ptrs(as_), _ptrs(Bs), _ptrs(bs), h, O, _ptrs(ys),
                                       saved.data_ptr() if keep else None, saved.numel() if keep else 0, ws.data_ptr(), ws.numel(),
-                                      torch.cuda.current_stream(dev).cuda_stream)
+                                      _lib.stream_ptr(dev))
     _lib.check(rc, "psf_mlp_wide_fwd_f32")
     return ys, saved
 
@@ -283,7 +283,7 @@ def _wide_backward_raw(saved: torch.Tensor, T: int, E: int, params: Sequence[tor
         rc = lib.psf_mlp_wide_bwd_f32(saved.data_ptr(), saved.numel(), T, E, K, _ptrs(As), _ptrs(Bs), h, O, _ptrs(gys),
                                       dX.data_ptr() if need_dx else None, _ptrs(grads[0::4]), _ptrs(grads[1::4]),
                                       _ptrs(grads[2::4]), _ptrs(grads[3::4]), ws.data_ptr(), ws.numel(),
-                                      torch.cuda.current_stream(dev).cuda_stream)
+                                      _lib.stream_ptr(dev))
     _lib.check(rc, "psf_mlp_wide_bwd_f32")
     return dX, grads
 
@@ -293,7 +293,7 @@ class _WideMLPFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x2, *params):
-        params = tuple(p.detach().contiguous() for p in params)
+        params = tuple(p if p.is_contiguous() else p.contiguous() for p in params)  # (inside Function.forward: nothing to detach from)
         ys, saved = _wide_forward_raw(x2, params)
         ctx.save_for_backward(saved, *params)
         ctx.x_shape = tuple(x2.shape)

@@ -88,7 +88,7 @@ class _FlatHeadFn(torch.autograd.Function):
         with torch.cuda.device(flat.device):
             rc = lib.psf_flat_head_f32(flat_c.data_ptr(), w_c.data_ptr(), bias.data_ptr() if bias is not None else None,
                                        out.data_ptr(), B, K, J, ws.data_ptr(), ws_bytes,
-                                       torch.cuda.current_stream(flat.device).cuda_stream)
+                                       _lib.stream_ptr(flat.device))
         _lib.check(rc, "psf_flat_head_f32")
         return out
 
@@ -108,7 +108,7 @@ class _FlatHeadFn(torch.autograd.Function):
             with torch.cuda.device(flat.device):
                 rc = _lib.load().psf_flat_head_bwd_f32(dy_c.data_ptr(), flat.data_ptr(), weight.data_ptr(),
                                                        d_flat.data_ptr() if need_x else None, d_w.data_ptr() if need_w else None,
-                                                       B, K, J, torch.cuda.current_stream(flat.device).cuda_stream)
+                                                       B, K, J, _lib.stream_ptr(flat.device))
             _lib.check(rc, "psf_flat_head_bwd_f32")
         else:
             d_flat = dy.mm(weight) if need_x else None

@@ -43,7 +43,7 @@ def linear_wgrad(x2d: torch.Tensor, dy2d: torch.Tensor, need_bias: bool = True):
     with torch.cuda.device(x2d.device):
         rc = lib.psf_linear_wgrad_strided_f32(x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), T, m, n,
                                               dW.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(),
-                                              ws_bytes, torch.cuda.current_stream(x2d.device).cuda_stream)
+                                              ws_bytes, _lib.stream_ptr(x2d.device))
     _lib.check(rc, "psf_linear_wgrad_strided_f32")
     return dW, db
 
@@ -67,7 +67,7 @@ def affine_rows(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
     out = torch.empty((x2.shape[0], E), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         rc = _lib.load().psf_affine_rows_f32(x2.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None, out.data_ptr(),
-                                             x2.shape[0], K, E, torch.cuda.current_stream(x.device).cuda_stream)
+                                             x2.shape[0], K, E, _lib.stream_ptr(x.device))
     _lib.check(rc, "psf_affine_rows_f32")
     return out.reshape(*x.shape[:-1], E)
 
@@ -122,7 +122,7 @@ def embedding_wgrad(idx: torch.Tensor, dout: torch.Tensor, vocab: int, padding_i
     dW = torch.empty((vocab, E), dtype=torch.float32, device=d2.device)
     with torch.cuda.device(d2.device):
         rc = lib.psf_embed_tokens_bwd_f32(idx_c.data_ptr(), d2.data_ptr(), T, vocab, E, dW.data_ptr(), ws.data_ptr(),
-                                          ws_bytes, torch.cuda.current_stream(d2.device).cuda_stream)
+                                          ws_bytes, _lib.stream_ptr(d2.device))
     _lib.check(rc, "psf_embed_tokens_bwd_f32")
     if padding_idx is not None and padding_idx >= 0:
         dW[padding_idx].zero_()
@@ -160,7 +160,7 @@ class _EmbedTokensFn(torch.autograd.Function):
         w, p = weight.detach().contiguous(), (pos.detach().contiguous() if pos is not None else None)
         with torch.cuda.device(idx.device):
             rc = lib.psf_embed_tokens_f32(idx_c.data_ptr(), w.data_ptr(), p.data_ptr() if p is not None else None,
-                                          out.data_ptr(), T, N, V, E, torch.cuda.current_stream(idx.device).cuda_stream)
+                                          out.data_ptr(), T, N, V, E, _lib.stream_ptr(idx.device))
         _lib.check(rc, "psf_embed_tokens_f32")
         ctx.save_for_backward(idx_c)
         ctx.vocab, ctx.padding_idx, ctx.has_pos, ctx.n_pos = V, padding_idx, pos is not None, N

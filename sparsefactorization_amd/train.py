@@ -193,7 +193,7 @@ class ChunkedAdam(torch.optim.Optimizer):
             n = len(live)
             gtab = (ctypes.c_void_p * n)(*[(p.grad if p.grad.is_contiguous() else p.grad.contiguous()).data_ptr() for p in live])
             b1, b2 = group["betas"]
-            stream = torch.cuda.current_stream(dev).cuda_stream
+            stream = _lib.stream_ptr(dev)
             with torch.cuda.device(dev):
                 if cap:
                     self._step_devs[gi].add_(1.0)
