@@ -102,7 +102,8 @@ struct BwdArgs {
   float* dX;        // [T, E] or nullptr
   float* images;    // U images of kImg floats
   float* partials;  // [G][U][kPart], one slot per workgroup
-  float* stage1;    // [kSlices][U * kPart]
+  float* stage1;    // [slices][U * kPart] (room for kSlices)
+  int32_t slices;   // stage-1 slices in use (<= kSlices)
   int64_t T;
   int64_t G;        // workgroups = partial slots
   int32_t E, K, U;
@@ -558,7 +559,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_reduce1_k(const BwdArgs a) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const int s = blockIdx.y;
-  const int64_t per = (a.G + kSlices - 1) / kSlices;
+  const int64_t per = (a.G + a.slices - 1) / a.slices;
   const int64_t g0 = s * per, g1 = g0 + per < a.G ? g0 + per : a.G;
   const float4* __restrict__ P = reinterpret_cast<const float4*>(a.partials);
   float4 acc[4];
@@ -602,7 +603,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_reduce2_k(const BwdArgs a) {
   const int ht = 32 * (int)(a.unit[u] >> 8), E = a.E;
   auto total = [&](int64_t at) {
     float acc = 0.f;
-    for (int s = 0; s < kSlices; ++s) acc += a.stage1[s * n + at];
+    for (int s = 0; s < a.slices; ++s) acc += a.stage1[s * n + at];
     return acc;
   };
   if (i < 1024) {
@@ -699,6 +700,10 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   args.stage1 = args.partials + p.G8 * p.U * kPart;
   args.T = T;
   args.G = p.G8;
+  // stage-1 slices: about sixteen partial slots each, at most kSlices. With 64 slices for the 128 slots of a 32 k-token input
+  // (CIFAR-10) stage 1 was 1 536 workgroups adding two numbers each and stage 2 read 64 slices per element: 19 + 7.6 us
+  // beside a 65 us kernel. The Order / Adding shapes (1 280 slots) keep 64 slices and their bits.
+  args.slices = (int32_t)((p.G8 + 15) / 16 < 1 ? 1 : ((p.G8 + 15) / 16 > kSlices ? kSlices : (p.G8 + 15) / 16));
   args.E = E;
   args.K = K;
   args.U = p.U;
@@ -722,7 +727,7 @@ int psf_mlp_bwd_f32(const float* X, int64_t T, int32_t E, int32_t K, const float
   e = hipGetLastError();
   if (e != hipSuccess) return psf_internal_fail((int)e, hipGetErrorString(e));
   const int64_t n = (int64_t)p.U * kPart;
-  hipLaunchKernelGGL(mlp_bwd_reduce1_k, dim3((unsigned)((n / 4 + 255) / 256), kSlices), dim3(256), 0, s, args);
+  hipLaunchKernelGGL(mlp_bwd_reduce1_k, dim3((unsigned)((n / 4 + 255) / 256), (unsigned)args.slices), dim3(256), 0, s, args);
   hipLaunchKernelGGL(mlp_bwd_reduce2_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, args);
   e = hipGetLastError();
   return e == hipSuccess ? PSF_OK : psf_internal_fail((int)e, hipGetErrorString(e));
