@@ -106,14 +106,25 @@ def _block_sizes(E: int, g: nn.Module, fs: Sequence[nn.Module]):
     return len(fs), h, pairs[0][1].out_features, L
 
 
-def _route_ok(N: int, E: int, M: int, C: int, L: int, h) -> bool:
+def _route_ok(N: int, E: int, M: int, C: int, L: int, h, tokens: int = 1 << 62) -> bool:
     if route != "auto":
         return route == "always"
     if N >= 8192 and C <= 32 and max(h) <= 32:  # (32-channel rows since the step kernel's diet: genome shape 488 -> 451 us)
         return True
     # short sequences: ONE launch with V resident in LDS (csrc/mixer_lds.h) against producer + chain
     # (profiles/r04n_mixer_bench_short.log: cfg1 115 -> 89 us per forward, N = 512: 134 -> 106)
-    return _lib.load().psf_mixer_fwd_plan(N, E, M, h, C, L) == 2
+    plan = _lib.load().psf_mixer_fwd_plan(N, E, M, h, C, L)
+    if plan == 2:
+        return True
+    # An EAGER forward of a small network is bound by the host, and the fused route is one library call for all its M + 2
+    # launches: in the no-grad forward of the LRA networks (profiles/infer_route_sweep.py, ms per forward, fused / through
+    # memory) CIFAR-10's widths (hidden 16) win at every batch size — 0.227 / 0.270 at 32 k tokens, 0.319 / 0.339 at 524 k —
+    # and hidden 128 wins while the GPU time of the heavier step kernels stays under the host's: Pathfinder 0.173 / 0.222 at
+    # 16 k tokens, IMDb 0.247 / 0.291 at 32 k, but 0.377 / 0.280 at 65 k. Under stream capture there is no host in the replay
+    # and the GPU-time rule above stands.
+    if plan == 1 and not torch.cuda.is_current_stream_capturing():
+        return (max(h) <= 32 and C <= 32) or tokens <= 40000
+    return False
 
 
 def eligible_recipe(r: Recipe, g: nn.Module, fs: Sequence[nn.Module]) -> bool:
@@ -126,7 +137,7 @@ def eligible_recipe(r: Recipe, g: nn.Module, fs: Sequence[nn.Module]) -> bool:
     if sz is None:
         return False
     M, h, C, L = sz
-    return _route_ok(r.N, r.E, M, C, L, h) and _lib.load().psf_mixer_fwd_workspace(r.N, r.E, M, h, C, L) >= 0
+    return _route_ok(r.N, r.E, M, C, L, h, r.B * r.N) and _lib.load().psf_mixer_fwd_workspace(r.N, r.E, M, h, C, L) >= 0
 
 
 def mixer_forward_in(r: Recipe, g: nn.Module, fs: Sequence[nn.Module], use_residual: bool) -> torch.Tensor:

@@ -300,3 +300,42 @@ def test_nets_take_the_fused_mixer_in_inference_and_agree_with_the_unfused_route
         net.train()  # dropout active / gradients wanted: the fused inference path must step aside
         out = net(x)
         assert out.requires_grad
+
+
+def test_automatic_route_follows_the_measured_rule(gpu):
+    """fused_mixer's automatic route (profiles/infer_route_sweep.py): long sequences with hidden <= 32 and every shape of the
+    single-launch kernel always; per-step kernels for short sequences when the forward is eager and either the widths are
+    CIFAR-10's (hidden <= 32) or the batch is small enough for the host to be the bound (B N <= 40 000 tokens at hidden 128);
+    never under stream capture, where the GPU-time rule stands."""
+    from sparsefactorization_amd import fused_mixer
+
+    def auto(B, N, E, h, C, L, M):
+        g, fs = _blocks(E, h, C, L, M, seed=1)
+        g.to(gpu)
+        for f in fs:
+            f.to(gpu)
+        with torch.no_grad():
+            return fused_mixer.eligible(torch.randn(B, N, E, device=gpu), g, fs)
+
+    assert fused_mixer.route == "auto"
+    assert auto(64, 16384, 32, 32, 8, 15, 14)      # Adding / Order
+    assert auto(40, 128, 32, 32, 8, 8, 7)          # cfg1: the single launch
+    assert auto(32, 1024, 16, 16, 16, 11, 10)      # CIFAR-10, the reference's batch
+    assert auto(512, 1024, 16, 16, 16, 11, 10)     # ... and a large one
+    assert auto(16, 1024, 32, 128, 32, 12, 11)     # Pathfinder widths, 16 k tokens
+    assert not auto(64, 1024, 32, 128, 32, 12, 11)  # ... at the reference's batch (65 k tokens): W through memory
+    assert auto(8, 4097, 32, 128, 32, 13, 12)      # IMDb widths, 32 k tokens
+    assert not auto(32, 4097, 32, 128, 32, 13, 12)  # ... at the reference's batch
+    side = torch.cuda.Stream(gpu)
+    graph = torch.cuda.CUDAGraph()
+    seen = {}
+    g, fs = _blocks(16, 16, 16, 11, 10, seed=1)
+    g.to(gpu)
+    for f in fs:
+        f.to(gpu)
+    x = torch.randn(32, 1024, 16, device=gpu)
+    with torch.cuda.stream(side):
+        with torch.no_grad(), torch.cuda.graph(graph, stream=side):
+            seen["capturing"] = fused_mixer.eligible(x, g, fs)
+    torch.cuda.synchronize()
+    assert seen["capturing"] is False
