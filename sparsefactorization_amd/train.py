@@ -148,7 +148,12 @@ class ChunkedAdam(torch.optim.Optimizer):
                 loss = closure()
         lib = _lib.load()
         for gi, group in enumerate(self.param_groups):
-            live = [p for p in group["params"] if p.grad is not None]
+            live, grads = [], []
+            for p in group["params"]:  # (one look at .grad per parameter: it is a property that goes through the dispatcher)
+                g = p.grad
+                if g is not None:
+                    live.append(p)
+                    grads.append(g)
             if not live:
                 continue
             dev = live[0].device
@@ -181,17 +186,18 @@ class ChunkedAdam(torch.optim.Optimizer):
                 self._live_states[gi] = (live_ids, states)
             # host-side plan (pointer tables of the parameters and their moments), rebuilt only when a tensor of it
             # moved: the small LRA models are launch-bound, every microsecond here counts
-            key = tuple((p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) for p, st in zip(live, states))
+            key = tuple([(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) for p, st in zip(live, states)])
             plan = self._plans.get(gi)
             if plan is None or plan[0] != key:
                 n = len(live)
                 tab = lambda ts: (ctypes.c_void_p * n)(*[x.data_ptr() for x in ts])  # noqa: E731
                 plan = (key, tab(live), tab([st["exp_avg"] for st in states]), tab([st["exp_avg_sq"] for st in states]),
-                        (ctypes.c_int64 * n)(*[p.numel() for p in live]))
+                        (ctypes.c_int64 * n)(*[p.numel() for p in live]), states)
                 self._plans[gi] = plan
-            _, ptab, mtab, vtab, sizes = plan
+            _, ptab, mtab, vtab, sizes, _ = plan
             n = len(live)
-            gtab = (ctypes.c_void_p * n)(*[(p.grad if p.grad.is_contiguous() else p.grad.contiguous()).data_ptr() for p in live])
+            grads = [g if g.is_contiguous() else g.contiguous() for g in grads]  # (copies stay alive until the launch is queued)
+            gtab = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
             b1, b2 = group["betas"]
             stream = _lib.stream_ptr(dev)
             with torch.cuda.device(dev):
