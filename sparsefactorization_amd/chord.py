@@ -238,38 +238,45 @@ def _sum_tensors(terms: Sequence[torch.Tensor]) -> torch.Tensor:
     return out
 
 
+def _chain_forward_raw(V0, use_residual, offsets, Ws, keep_all):
+    """The M launches of the chain (one library call). keep_all: every step's result in its own buffer (they are the saved
+    inputs of the backward steps); otherwise two buffers take turns. Returns (V0 contiguous, [W_m contiguous], outs, geometry)."""
+    M = len(Ws)
+    Ws = [w if w.is_contiguous() else w.contiguous() for w in Ws]
+    V0c = V0 if V0.is_contiguous() else V0.contiguous()
+    B, N, L, C, stride0 = _shapes(Ws[0], V0c)
+    for w in Ws:
+        if w.shape != Ws[0].shape or w.dtype != V0c.dtype:
+            raise ValueError("every W_m must be [B, N, L] with V0's dtype")
+    if use_residual and stride0 == 0 and B != 1:
+        raise ValueError("a broadcast V0 cannot be the residual")
+    dev = _require_hip(V0c, *Ws)
+    nbuf = M if keep_all else min(M, 2)
+    bufs = [torch.empty((B, N, C), dtype=V0c.dtype, device=dev) for _ in range(nbuf)]
+    outs = [bufs[m % nbuf] for m in range(M)]
+    lib = _lib.load()
+    w_tab = (ctypes.c_void_p * M)(*[w.data_ptr() for w in Ws])
+    o_tab = (ctypes.c_void_p * M)(*[o.data_ptr() for o in outs])
+    with torch.cuda.device(dev):
+        fn = getattr(lib, "psf_chord_chain_fwd" + _suffix(V0c))
+        rc = fn(w_tab, V0c.data_ptr(), o_tab, M, 1 if use_residual else 0, B, N, L, C, stride0,
+                _lib.offsets_array(offsets), _stream_ptr(dev))
+    _lib.check(rc, "psf_chord_chain_fwd")
+    return V0c, Ws, outs, (B, N, L, C, stride0)
+
+
 class _ChordChain(torch.autograd.Function):
     """X_0 = V0; X_{m+1} = W_m (.) X_m (+ V0) — SyntheticExperiments/psf.py:167-188 as one autograd node."""
 
     @staticmethod
     def forward(ctx, V0, use_residual, offsets, *Ws):
-        M = len(Ws)
-        if M == 0:
+        if not Ws:
             return V0
-        Ws = [w.contiguous() for w in Ws]
-        V0c = V0.contiguous()
-        B, N, L, C, stride0 = _shapes(Ws[0], V0c)
-        for w in Ws:
-            if w.shape != Ws[0].shape or w.dtype != V0c.dtype:
-                raise ValueError("every W_m must be [B, N, L] with V0's dtype")
-        if use_residual and stride0 == 0 and B != 1:
-            raise ValueError("a broadcast V0 cannot be the residual")
-        dev = _require_hip(V0c, *Ws)
         keep_all = any(ctx.needs_input_grad)
-        nbuf = M if keep_all else min(M, 2)
-        bufs = [torch.empty((B, N, C), dtype=V0c.dtype, device=dev) for _ in range(nbuf)]
-        outs = [bufs[m % nbuf] for m in range(M)]
-        lib = _lib.load()
-        w_tab = (ctypes.c_void_p * M)(*[w.data_ptr() for w in Ws])
-        o_tab = (ctypes.c_void_p * M)(*[o.data_ptr() for o in outs])
-        with torch.cuda.device(dev):
-            fn = getattr(lib, "psf_chord_chain_fwd" + _suffix(V0c))
-            rc = fn(w_tab, V0c.data_ptr(), o_tab, M, 1 if use_residual else 0, B, N, L, C, stride0,
-                    _lib.offsets_array(offsets), _stream_ptr(dev))
-        _lib.check(rc, "psf_chord_chain_fwd")
+        V0c, Ws, outs, geom = _chain_forward_raw(V0, use_residual, offsets, Ws, keep_all)
         if keep_all:
             ctx.save_for_backward(V0c, *Ws, *outs[:-1])
-        ctx.M, ctx.geom, ctx.offsets, ctx.use_residual, ctx.v_shape = M, (B, N, L, C, stride0), offsets, use_residual, V0.shape
+        ctx.M, ctx.geom, ctx.offsets, ctx.use_residual, ctx.v_shape = len(Ws), geom, offsets, use_residual, V0.shape
         return outs[-1]
 
     @staticmethod
@@ -332,6 +339,11 @@ def chord_chain(W_list: Sequence[torch.Tensor], V0: torch.Tensor, use_residual: 
                 offsets: Optional[Sequence[int]] = None) -> torch.Tensor:
     """Run ``for m: V = W_m (.) V (+ V0)`` for all factors in one call (M dependent HIP launches on the
     current stream, no Python or allocator work between them). Returns the final V [B, N, C]."""
+    if not len(W_list):
+        return V0
+    if not torch.is_grad_enabled() or not (V0.requires_grad or any(w.requires_grad for w in W_list)):
+        # nothing to differentiate: no autograd node (its bookkeeping is most of the host time of a short chain)
+        return _chain_forward_raw(V0.detach(), bool(use_residual), _norm_offsets(offsets), [w.detach() for w in W_list], False)[2][-1]
     return _ChordChain.apply(V0, bool(use_residual), _norm_offsets(offsets), *W_list)
 
 
