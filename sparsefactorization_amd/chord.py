@@ -343,7 +343,7 @@ def chord_chain(W_list: Sequence[torch.Tensor], V0: torch.Tensor, use_residual: 
         return V0
     if not torch.is_grad_enabled() or not (V0.requires_grad or any(w.requires_grad for w in W_list)):
         # nothing to differentiate: no autograd node (its bookkeeping is most of the host time of a short chain)
-        return _chain_forward_raw(V0.detach(), bool(use_residual), _norm_offsets(offsets), [w.detach() for w in W_list], False)[2][-1]
+        return _chain_forward_raw(V0, bool(use_residual), _norm_offsets(offsets), W_list, False)[2][-1]
     return _ChordChain.apply(V0, bool(use_residual), _norm_offsets(offsets), *W_list)
 
 
