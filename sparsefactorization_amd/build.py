@@ -15,6 +15,7 @@ import os
 import shutil
 import subprocess
 import sys
+import threading
 from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -71,8 +72,8 @@ def _units():
 
 def _unit_table():
     """The units without the hash define (csrc_hash() folds their flags in). `lint`: the unit's gfx950 assembly is kept and
-    checked by isa_lint.py — every unit with a hand-placed s_waitcnt, and every one that mixes MFMA phases with LDS-fed
-    packed arithmetic."""
+    checked by isa_lint.py — since round 6 EVERY unit (R0-R2 hold everywhere; R3-pattern sites are counted everywhere and
+    are an error only in kernels that issue MFMAs themselves, isa_lint.py's docstring)."""
     units = [(os.path.join(OBJ_DIR, "psf_chord.o"), os.path.join(CSRC, "psf_chord.hip"), []),
              (os.path.join(OBJ_DIR, "linear_wgrad.o"), os.path.join(CSRC, "linear_wgrad.hip"), []),
              # -fno-slp-vectorize: the LDS-resident chain's multiply-add loop is faster on scalar f32 instructions than on the
@@ -108,12 +109,12 @@ def _unit_table():
     wide = ["-DPSF_TGS=3", "-DPSF_NT=1024"]
     units.append((os.path.join(OBJ_DIR, "fwd_window_wide.o"), os.path.join(CSRC, "fwd_window_inst.hip"), wide))
     units.append((os.path.join(OBJ_DIR, "bwd_window_wide.o"), os.path.join(CSRC, "bwd_window_inst.hip"), wide))
-    return [(o, s, e, os.path.basename(o).startswith(LINT_UNITS)) for o, s, e in units]
+    return [(o, s, e, True) for o, s, e in units]
 
 
-# hand-placed waits: fwd_window.h (counted vmcnt before the barrier), x3_gemm.h in mlp_wide (counted vmcnt per chunk),
-# fwd_mlp_step.h / mixer_lds.h (full LDS wait in front of packed arithmetic beside MFMA phases)
-LINT_UNITS = ("fwd_window", "fwd_mlp_step", "mixer_lds", "mlp_wide", "mlp_fwd", "mlp_bwd")  # (+ the other MFMA units: R0, R2, R3)
+# the kernels the round-4 wrong result was seen in (and their single-launch sibling): failing-form R3 sites are errors here
+R3_STRICT_UNITS = ("fwd_mlp_step", "mixer_lds")
+LINT_LOG = os.path.join(OBJ_DIR, "isa_lint.log")  # one line per unit: functions, errors, notes, R3-pattern sites
 
 
 def _unit_weight(unit) -> int:
@@ -143,6 +144,9 @@ def needs_build() -> bool:
     return not os.path.exists(LIB_PATH) or built_hash() != csrc_hash()
 
 
+_LOG_LOCK = threading.Lock()
+
+
 def _compile(unit, cc, verbose):
     obj, src, extra, lint = unit
     if lint:  # keep the unit's assembly (in a directory of its own: the temporaries are named after the source file)
@@ -162,9 +166,18 @@ def _compile(unit, cc, verbose):
         asm = [os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith(f"{ARCH}.s")]
         if len(asm) != 1:
             raise RuntimeError(f"isa_lint: expected one {ARCH} assembly file for {os.path.basename(real_obj)}, found {asm}")
-        errs, notes, nfun = isa_lint.lint_file(asm[0])
+        sites: dict = {}
+        unit_name = os.path.basename(real_obj)[:-2]
+        errs, notes, nfun = isa_lint.lint_file(asm[0], sites, unit_name.startswith(R3_STRICT_UNITS))
+        warn = [w for w in notes if w.startswith("WARNING")]
+        report = (f"isa_lint {unit_name}: {nfun} functions, {len(errs)} errors, {len(notes)} notes"
+                  + (f" ({len(warn)} of them R3 warnings: failing-form sites)" if warn else "") + "\n"
+                  + isa_lint.r3_summary(unit_name, sites) + "\n" + "".join(f"  note {w}\n" for w in notes[:4]))
+        with _LOG_LOCK:
+            with open(LINT_LOG, "a") as fh:
+                fh.write(report)
         if verbose:
-            print(f"isa_lint {os.path.basename(real_obj)}: {nfun} functions, {len(errs)} errors, {len(notes)} notes", file=sys.stderr)
+            print(report, end="", file=sys.stderr)
         if errs:
             raise RuntimeError(f"isa_lint rejects {os.path.basename(real_obj)} (kept: {asm[0]}):\n" + "\n".join(errs[:20]))
         os.replace(obj, real_obj)
@@ -179,6 +192,7 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
         return LIB_PATH
     cc = hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
+    open(LINT_LOG, "w").close()
     units = _units()
     jobs = jobs or min(len(units), max(1, (os.cpu_count() or 2)))
     # longest units first (the pool takes them in order: a 25 s unit started last would be the build's tail)

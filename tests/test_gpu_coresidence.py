@@ -1,0 +1,149 @@
+"""GPU: the chord kernels beside an MFMA kernel on a second stream of the same device.
+
+Why this test exists (profiles/r04b_mixer_lds_wait.md, isa_lint.py R3): the one sporadically wrong result this library ever
+produced (round 4, chord_fwd_mlp_k) was attributed — by inference, never by observation — to a packed-f32 instruction
+consuming a just-released ds_read result "under a co-resident wave's MFMA phase". The chord window kernels carry that ISA
+pattern thousands of times (21 sites in the headline instance chord_fwd_win_k<float,15,1,2,256,true,true,2>) and issue no
+MFMA themselves, so whether they are safe hinged on an untested premise: that they never share a CU with an MFMA kernel.
+Nothing in the boundary says so, and a PSFNet forward on two streams (producers on one, chain on the other) does exactly that.
+
+So: the chain of SURVEY.md §8(a2) at BASELINE configs[1]'s full size (SyntheticExperiments/psf.py:172-188 semantics) runs on
+stream A while the producer MLP kernel (x3_fwd_k: split-bf16 MFMA phases, psf_mlp_fwd_f32) runs on stream B, a fixed small
+number of rounds, and every result must be bit-equal to the solo run — and the chain bit-equal to the CPU oracle on batch
+elements 0 / 37 / 63, as tests/test_gpu_parity.py::test_full_size_properties checks the solo chain. The backward step
+(chord_bwd_fused_k, 36 sites) gets the same treatment beside the MLP backward (mlp_bwd_x3p_k).
+
+This is new coverage of a configuration, not a re-run of a known failure: a fixed launch count, one pass.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import chord_oracle as oc
+
+pytestmark = pytest.mark.gpu
+
+ROUNDS = 6
+
+
+def _cfg2(gpu, B=64):
+    N, M, L, C = 16384, 14, 15, 8
+    g = torch.Generator(device=gpu)
+    Ws = []
+    for i in range(M):
+        g.manual_seed(1234 + i + 1)
+        Ws.append(0.1 * torch.randn(B, N, L, device=gpu, generator=g))
+    g.manual_seed(1234)
+    V0 = torch.randn(B, N, C, device=gpu, generator=g)
+    return Ws, V0
+
+
+def _producer(gpu, T, E=32, M=14, C=8):
+    """The 15 MLPs of the synthetic PSFNet at cfg2 (SyntheticExperiments/psf.py:35-60,165,175): parameters and input rows."""
+    g = torch.Generator(device=gpu).manual_seed(99)
+    x2 = torch.randn(T, E, device=gpu, generator=g)
+    params = []
+    for out in [C] + [M + 1] * M:
+        params += [torch.randn(32, E, device=gpu, generator=g) / E ** 0.5, 0.1 * torch.randn(32, device=gpu, generator=g),
+                   torch.randn(out, 32, device=gpu, generator=g) / 32 ** 0.5, 0.1 * torch.randn(out, device=gpu, generator=g)]
+    return x2, params
+
+
+def _overlap_ms(e0, a0, a1, b0, b1):
+    """Length of the intersection of the two streams' busy intervals, from events timed against a common origin."""
+    sa, ea, sb, eb = e0.elapsed_time(a0), e0.elapsed_time(a1), e0.elapsed_time(b0), e0.elapsed_time(b1)
+    return min(ea, eb) - max(sa, sb), (sa, ea, sb, eb)
+
+
+def test_chain_beside_the_mfma_producer_on_a_second_stream(gpu):
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import fused_mlp
+    Ws, V0 = _cfg2(gpu)
+    x2, params = _producer(gpu, T=64 * 16384)
+    solo = sfa.chord_chain(Ws, V0, True)
+    ys_solo = fused_mlp._forward_raw(x2, params)
+    torch.cuda.synchronize()
+
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    outs, yss, spans = [], [], []
+    for r in range(ROUNDS):
+        e0, a0, a1, b0, b1 = ev(), ev(), ev(), ev(), ev()
+        e0.record()
+        sA.wait_event(e0)
+        sB.wait_event(e0)
+        # alternate who goes first: the chain's workgroups move into CUs the producer is draining from, and the other way round
+        order = (sB, sA) if r % 2 == 0 else (sA, sB)
+        for s in order:
+            with torch.cuda.stream(s):
+                if s is sB:
+                    b0.record()
+                    yss.append(fused_mlp._forward_raw(x2, params))
+                    b1.record()
+                else:
+                    a0.record()
+                    outs.append(sfa.chord_chain(Ws, V0, True))
+                    outs.append(sfa.chord_chain(Ws, V0, True))  # two chains ~ one producer launch in time
+                    a1.record()
+        spans.append((e0, a0, a1, b0, b1))
+    torch.cuda.synchronize()
+
+    overlaps = [_overlap_ms(*s)[0] for s in spans]
+    print("coresidence: busy-interval overlap per round, ms:", [round(o, 3) for o in overlaps])
+    assert max(overlaps) > 0.05, f"the two streams never ran at the same time ({overlaps}): the test did not test co-residence"
+    for o in outs:
+        assert torch.equal(o, solo)
+    for ys in yss:
+        for y, y0 in zip(ys, ys_solo):
+            assert torch.equal(y, y0)
+    sel = [0, 37, 63]
+    W_np = np.stack([w[sel].cpu().numpy() for w in Ws])
+    rows, cols = oc.chord_indices(16384, 15)
+    want = oc.chain(np.stack([rows, cols]), W_np, V0[sel].cpu().numpy(), True)[-1]
+    assert np.array_equal(solo[sel].cpu().numpy(), want)
+    assert np.array_equal(outs[-1][sel].cpu().numpy(), want)
+
+
+def test_backward_step_beside_the_mfma_mlp_backward_on_a_second_stream(gpu):
+    """chord_bwd_fused_k (dV bit-exact vs the oracle, dW <= 1e-5: spmul_cuda.cu:75-84,102-111) while mlp_bwd_x3p_k runs."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import fused_mlp
+    B, N, L, C = 40, 16384, 15, 8  # the Temporal-Order training shape (BASELINE configs[4])
+    g = torch.Generator(device=gpu).manual_seed(7)
+    W = 0.1 * torch.randn(B, N, L, device=gpu, generator=g)
+    V = torch.randn(B, N, C, device=gpu, generator=g)
+    dZ = torch.randn(B, N, C, device=gpu, generator=g)
+    x2, params = _producer(gpu, T=B * N)
+    gys = [torch.randn(x2.shape[0], p.shape[0], device=gpu, generator=g) for p in params[2::4]]
+
+    def step():
+        Wr, Vr = W.clone().requires_grad_(True), V.clone().requires_grad_(True)
+        sfa.chord_spmm(Wr, Vr).backward(dZ)
+        return Wr.grad, Vr.grad
+
+    dW0, dV0 = step()
+    dX0, grads0 = fused_mlp._backward_raw(x2, params, gys, True)
+    torch.cuda.synchronize()
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    sA.wait_stream(torch.cuda.current_stream())
+    sB.wait_stream(torch.cuda.current_stream())
+    got, got_mlp = [], []
+    for r in range(ROUNDS):
+        for s in ((sB, sA) if r % 2 == 0 else (sA, sB)):
+            with torch.cuda.stream(s):
+                if s is sB:
+                    got_mlp.append(fused_mlp._backward_raw(x2, params, gys, True))
+                else:
+                    for _ in range(8):  # ~ 8 x 45 us beside a ~ 0.75 ms MLP backward
+                        got.append(step())
+    torch.cuda.synchronize()
+    for dW, dV in got:
+        assert torch.equal(dV, dV0) and torch.equal(dW, dW0)
+    for dX, grads in got_mlp:
+        assert torch.equal(dX, dX0)
+        for a, b in zip(grads, grads0):
+            assert torch.equal(a, b)
+    sel = [0, 21, 39]
+    want_dW, want_dV = oc.spmul_bwd(dZ[sel].cpu().numpy(), W[sel].cpu().numpy(), V[sel].cpu().numpy())
+    assert np.array_equal(dV0[sel].cpu().numpy(), want_dV)
+    assert float(np.abs(dW0[sel].cpu().numpy() - want_dW).max() / np.abs(want_dW).max()) <= 1e-5

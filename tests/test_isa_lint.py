@@ -72,7 +72,10 @@ def test_r0_and_r2(tmp_path):
     assert any("scalar-memory" in e for e in errs)  # SMEM returns out of order: the count proves nothing
 
 
-def test_r3_packed_first_consumer_only_in_mfma_kernels(tmp_path):
+def test_r3_is_graded(tmp_path, monkeypatch):
+    """R3 (isa_lint.py's docstring): counted everywhere; an error only in a kernel that issues MFMAs, behind a counted wait
+    with other reads still in flight; a note-free count behind a full wait; PSF_ISA_LINT_R3=warn downgrades the error."""
+    monkeypatch.delenv("PSF_ISA_LINT_R3", raising=False)
     pattern = """
         ds_read_b128 v[14:17], v113
         ds_read_b128 v[18:21], v113 offset:128
@@ -80,20 +83,64 @@ def test_r3_packed_first_consumer_only_in_mfma_kernels(tmp_path):
         v_pk_mul_f32 v[14:15], v[2:3], v[14:15] op_sel_hi:[0,1]
     """
     mfma = "        v_mfma_f32_32x32x16_bf16 v[30:45], v[22:25], v[26:29], v[30:45]\n"
-    errs, _ = _lint(tmp_path, mfma + pattern)
-    assert len(errs) == 1 and "(R3)" in errs[0]
-    assert _lint(tmp_path, pattern) == ([], [])  # no MFMA in the kernel: the forward window kernel's normal form
+
+    def sites(body):
+        p = tmp_path / "k.s"
+        p.write_text(HEAD + textwrap.dedent(body) + TAIL)
+        found = {}
+        errs, notes, _ = isa_lint.lint_file(str(p), found, strict)
+        return errs, notes, sum(found.values())
+
+    strict = True  # (the units of the kernels the failure was seen in: fwd_mlp_step_*, mixer_lds)
+    errs, _, n = sites(mfma + pattern)
+    assert len(errs) == 1 and "(R3)" in errs[0] and n == 1
+    strict = False  # every other unit: the same site is a loud note (589 of them in linear_wgrad.hip, results pinned since round 2)
+    errs, notes, n = sites(mfma + pattern)
+    assert errs == [] and len(notes) == 1 and notes[0].startswith("WARNING") and n == 1
+    monkeypatch.setenv("PSF_ISA_LINT_R3", "error")
+    assert len(sites(mfma + pattern)[0]) == 1
+    monkeypatch.delenv("PSF_ISA_LINT_R3")
+    strict = True
+    assert sites(pattern) == ([], [], 1)  # no MFMA in the kernel: the forward window kernels' normal form — counted, not an error
+    monkeypatch.setenv("PSF_ISA_LINT_R3", "warn")
+    errs, notes, n = sites(mfma + pattern)
+    assert errs == [] and len(notes) == 1 and notes[0].startswith("WARNING") and n == 1
+    monkeypatch.delenv("PSF_ISA_LINT_R3")
+    # the shipped form: a full wait, the empty behind_wait statements, hipcc's own (now redundant) counted waits in between.
+    # The packed multiply is still the first vector instruction behind the wait that released its operand: the site is
+    # COUNTED (the round-5 rule let the redundant wait hide it) but nothing was in flight, so it is not an error
     shipped = """
         ds_read_b128 v[14:17], v113
         ds_read_b128 v[18:21], v113 offset:128
         ;;#ASMSTART
         s_waitcnt lgkmcnt(0)
         ;;#ASMEND
-        v_mov_b32_e32 v40, v1
-        v_mov_b32_e32 v41, v1
+        s_waitcnt lgkmcnt(1)
+        ;;#ASMSTART
+        ;;#ASMEND
+        s_nop 0
         v_pk_mul_f32 v[14:15], v[2:3], v[14:15] op_sel_hi:[0,1]
     """
-    assert _lint(tmp_path, mfma + shipped) == ([], [])
+    assert sites(mfma + shipped) == ([], [], 1)
+    # two vector instructions between the wait and the packed consumer: not a site at all
+    distant = shipped.replace("        s_nop 0\n", "        v_mov_b32_e32 v40, v1\n        v_mov_b32_e32 v41, v1\n")
+    assert sites(mfma + distant) == ([], [], 0)
+    # a counted wait that releases one read, then a later wait that releases nothing: the watch survives it
+    leaky = """
+        ds_read_b128 v[14:17], v113
+        ds_read_b128 v[18:21], v113 offset:128
+        s_waitcnt lgkmcnt(1)
+        s_waitcnt lgkmcnt(1)
+        v_pk_mul_f32 v[14:15], v[2:3], v[14:15] op_sel_hi:[0,1]
+    """
+    errs, _, n = sites(mfma + leaky)
+    assert len(errs) == 1 and n == 1
+
+
+def test_r3_summary_line():
+    assert "0 sites" in isa_lint.r3_summary("u", {})
+    line = isa_lint.r3_summary("fwd_window_tgs1", {"a": 21, "b": 3})
+    assert "24 sites in 2 kernels" in line and "21 in a" in line
 
 
 def test_csrc_hash_covers_the_effective_flags(monkeypatch):
@@ -114,6 +161,7 @@ def test_every_unit_with_a_hand_placed_wait_is_linted():
             if re.search(r'asm volatile\("s_waitcnt|__builtin_amdgcn_s_waitcnt\(', fh.read()):  # (comments mention it too)
                 hand.add(f)
     assert {"fwd_window.h", "psf_common.h", "x3_gemm.h", "mlp_bwd.hip"} <= hand
+    assert all(lint for *_, lint in build._unit_table())  # round 6: every unit is linted (R3 sites counted everywhere)
     linted_sources = {os.path.basename(src) for _, src, _, lint in build._unit_table() if lint}
     includes = {"fwd_window.h": "fwd_window_inst.hip", "fwd_mlp_step.h": "fwd_mlp_step_inst.hip", "mixer_lds.h": "mixer_lds_inst.hip",
                 "x3_gemm.h": "mlp_wide.hip", "psf_common.h": "fwd_mlp_step_inst.hip"}
