@@ -30,10 +30,15 @@ roofline.peak_measured / frac_of_measured = the same achieved rate against what 
 e2e_forward = SURVEY.md §8(d)'s end-to-end variant (one GPU): the real PSFNet (seed 42) on generated Adding / Temporal-Order
   batches at N = 16384, B = 64, both routes of the mixer (W through memory; W computed inside each chain step).
 shapes = the other timed shapes of SURVEY.md §8(d) (cfg1, cfg3 reference and BASELINE wording, cfg4 chain and attention map,
-  genome-like): us per step and algorithmic-bytes fraction, forward and fused backward (one GPU), twice: `*_cache_resident`
-  (one operand set re-used: it sits in the 256 MB Infinity Cache — NOT an HBM rate) and `*_rotating` (operand sets spanning
-  2.5 x the Infinity Cache: the fraction of the HBM roofline); `*_counters`: memory-side bytes per launch of the same kernels
-  from the committed per-shape counter summary, when it was collected on these kernel sources.
+  genome-like): us per step and algorithmic-bytes fraction (one GPU), twice: `*_cache_resident` (one operand set re-used: it
+  sits in the 256 MB Infinity Cache — NOT an HBM rate) and `*_rotating` (operand sets spanning 2.5 x the Infinity Cache: the
+  fraction of the HBM roofline). One entry PER KERNEL, each with the time of that kernel and the counters of that kernel:
+  `fwd_step_kernel` (the per-step chord_fwd_win_k: what training runs, every step kept), `fwd_chain_kernel` (what a no-grad
+  chord_chain call runs: chord_chain_lds_k, one launch for all steps, where it applies — else "same_as"), `bwd_step_kernel`
+  (the fused backward step). `counters`: memory-side bytes and L2 requests per launch of THAT kernel from the committed
+  per-shape counter summary, only when it was collected on these kernel sources. `bound`: "hbm", or "l2" when the counters say
+  traffic / algorithmic <= 1.1 and the kernel is under 0.6 of HBM — then `l2_to_cu_GBps` (L2 requests x 128 B / rocprof time)
+  and `frac_of_l2_roof` (of the guide's 16.8-18.8 TB/s for rows served out of the XCDs' L2) say where it sits.
 devices = every rank's HIP device as the library sees it (PCI bus id, XCDs, CUs); distinct_pci_devices must equal n_gpus in a
   real multi-GPU run.
 train = the data-parallel leg (BASELINE.json configs[4]): Temporal Order N = 16384, B = 40 per
@@ -59,6 +64,11 @@ if ROOT not in sys.path:
 N_SEQ, M_FACTORS, C_CH, B_PER_GPU = 16384, 14, 8, 64
 L_LINKS = M_FACTORS + 1
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the rate this box sustains is measured below
+# rows served out of an XCD's L2 to its CUs, chip-wide (MI355X_MICROARCH.md, "L2 (per XCD)": 2 048 rows shared by every
+# workgroup: 16.8-18.8 TB/s): the roof of a chord kernel whose memory-side traffic is its algorithmic bytes and which still
+# sits under 0.6 of HBM — every link of a row is an L2 -> CU request
+L2_ROOF_GBS = (16800.0, 18800.0)
+L2_REQUEST_BYTES = 128
 # several ranks: the data-parallel training leg is abandoned after this long (see main); the variable exists for the test of it
 TRAIN_DEADLINE_S = float(os.environ.get("PSF_BENCH_TRAIN_DEADLINE_S", "300"))
 TRAIN_ABANDONED_RC = 4  # exit code of every rank when that deadline passes (the headline line is still printed by rank 0)
@@ -706,8 +716,9 @@ def pmc_shapes():
         return None, f"unavailable: {exc!r}"
 
 
-def _counter_traffic(pmc, shape_key, kernel_prefix):
-    """{traffic_bytes, traffic_over_alg, l2_requests_per_row} of the shape's main launch of a kernel family, or None."""
+def _counter_traffic(pmc, shape_key, kernel_prefix, alg_bytes_per_launch=None):
+    """Counters of the shape's main launch of ONE kernel family from the per-shape summary, or None: memory-side bytes and L2
+    requests per launch, the rocprofv3 duration they were collected beside, and the L2 -> CU rate they amount to."""
     if not pmc or shape_key not in pmc:
         return None
     best = None
@@ -718,9 +729,30 @@ def _counter_traffic(pmc, shape_key, kernel_prefix):
     if best is None:
         return None
     name, k = best
-    return {"kernel": name, "rocprof_avg_us": k.get("avg_us"), "traffic_bytes": k["traffic_bytes"],
-            "traffic_over_algorithmic": k.get("traffic_over_alg"), "l2_requests_per_row": k.get("tcc_req_per_row"),
-            "l2_hit_rate": k.get("l2_hit_rate")}
+    rows = pmc[shape_key]["B"] * pmc[shape_key]["N"]
+    out = {"kernel": name, "rocprof_avg_us": k.get("avg_us"), "traffic_bytes": k["traffic_bytes"],
+           "traffic_over_algorithmic": (k["traffic_bytes"] / alg_bytes_per_launch if alg_bytes_per_launch else k.get("traffic_over_alg")),
+           "l2_requests_per_row": k.get("tcc_req_per_row"), "l2_hit_rate": k.get("l2_hit_rate")}
+    if k.get("tcc_req_per_row") and k.get("avg_us"):
+        out["l2_to_cu_GBps"] = k["tcc_req_per_row"] * rows * L2_REQUEST_BYTES / k["avg_us"] / 1e3
+    return out
+
+
+def _with_roof(entry, counters):
+    """Attach a kernel's own counters and state the roof that applies (module docstring, `bound`)."""
+    entry["bound"] = "hbm"
+    if counters is None:
+        return entry
+    entry["counters"] = counters
+    toa, frac = counters.get("traffic_over_algorithmic"), entry.get("frac_of_hbm_peak_rotating", 1.0)
+    if toa is not None and toa <= 1.1 and frac < 0.6 and "l2_to_cu_GBps" in counters:
+        entry["bound"] = "l2"
+        entry["l2_to_cu_GBps"] = counters["l2_to_cu_GBps"]
+        entry["l2_roof_GBps"] = list(L2_ROOF_GBS)
+        entry["frac_of_l2_roof"] = [counters["l2_to_cu_GBps"] / L2_ROOF_GBS[1], counters["l2_to_cu_GBps"] / L2_ROOF_GBS[0]]
+    elif toa is not None and toa > 1.1:
+        entry["bound"] = "hbm (re-reads: traffic over algorithmic %.2f)" % toa
+    return entry
 
 
 ROTATE_FOOTPRINT = 640 * 1000 * 1000  # bytes an operand rotation has to span: 2.5 x the 256 MB Infinity Cache
@@ -783,19 +815,39 @@ def shapes_leg(device):
                 sfa.chord_chain(Wsets[s_], V0s[s_ % len(V0s)], res)
 
             with torch.no_grad():
-                t_chain = timed(lambda: sfa.chord_chain(Wsets[0], V0, res), 20)
-                t_rot = timed(chain_rot, max(20, 2 * sets))
                 fwd_bytes = 4 * B * N * (L + 2 * C + (C if res else 0))
+
+                def fwd_entry(kernel, what, launches_per_chain):
+                    t_res = timed(lambda: sfa.chord_chain(Wsets[0], V0, res), 20)
+                    t_rot = timed(chain_rot, max(20, 2 * sets))
+                    return {"kernel": kernel, "what": what, "launches_per_chain": launches_per_chain,
+                            "us_per_step_cache_resident": t_res / M,
+                            "frac_of_hbm_peak_cache_resident": fwd_bytes / (t_res / M * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                            "us_per_step_rotating": t_rot / M,
+                            "frac_of_hbm_peak_rotating": fwd_bytes / (t_rot / M * 1e-6) / 1e9 / HBM_PEAK_GBS}
+
                 entry = {"B": B, "N": N, "L": L, "C": C, "M": M, "residual": res, "fwd_bytes_per_step": fwd_bytes,
-                         "fwd_us_per_step_cache_resident": t_chain / M,
-                         "fwd_frac_of_hbm_peak_cache_resident": fwd_bytes / (t_chain / M * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "fwd_us_per_step_rotating": t_rot / M,
-                         "fwd_frac_of_hbm_peak_rotating": fwd_bytes / (t_rot / M * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "rotation": {"operand_sets": sets, "footprint_MB": sets * chain_bytes / 1e6},
-                         "fwd_kernel": _lib.describe_chain_fwd(B, N, L, C, M)}
-                fc = _counter_traffic(pmc, pkey, "chord_fwd_")
-                if fc is not None:
-                    entry["fwd_counters"] = fc
+                         "rotation": {"operand_sets": sets, "footprint_MB": sets * chain_bytes / 1e6}}
+                # (a) the per-step kernel — what training runs (every step's result kept): M launches per chain, forced here
+                _lib.set_tuning("chain_fused", 0)
+                try:
+                    step = fwd_entry(_lib.describe_fwd(B, N, L, N if amap else C), "M per-step launches (knob chain_fused = 0): "
+                                     "what a training forward runs", M)
+                finally:
+                    _lib.set_tuning("chain_fused", 1)
+                # counters of the per-step kernel: one launch = one step without residual (profiles/bwd_pmc_run.py)
+                entry["fwd_step_kernel"] = _with_roof(step, _counter_traffic(pmc, pkey, "chord_fwd_", 4 * B * N * (L + 2 * C)))
+                # (b) what a no-grad chord_chain call runs by itself: the single LDS-resident launch where the library takes it
+                chain_desc = _lib.describe_chain_fwd(B, N, L, N if amap else C, M)
+                if "chord_chain_lds_k" in chain_desc:
+                    chain = fwd_entry(chain_desc, "ONE launch for all M steps, only the last result kept: what a no-grad "
+                                      "chord_chain (inference) runs", 1)
+                    cc = _counter_traffic(pmc, pkey, "chord_chain_lds", M * 4 * B * N * (L + 2 * C))
+                    if cc is not None and cc.get("l2_requests_per_row"):
+                        cc["l2_requests_per_row_per_step"] = cc["l2_requests_per_row"] / M
+                    entry["fwd_chain_kernel"] = _with_roof(chain, cc)
+                else:
+                    entry["fwd_chain_kernel"] = {"same_as": "fwd_step_kernel", "kernel": chain_desc}
                 if not amap:
                     step_bytes_in = 4 * B * N * (L + 2 * C)
                     bsets = max(2, min(ROTATE_MAX_SETS, -(-ROTATE_FOOTPRINT // (2 * step_bytes_in))))
@@ -814,22 +866,28 @@ def shapes_leg(device):
                     t_bwd = timed(lambda: _launch_bwd(zz[0], flatW[0], Vs[0], dWs[0], zz[1], B, N, L, C, N * C, None), 40)
                     t_brot = timed(bwd_rot, max(40, 2 * bsets))
                     bwd_bytes = 4 * B * N * (2 * L + 3 * C)
-                    entry.update({"bwd_bytes_per_step": bwd_bytes, "bwd_us_per_step_cache_resident": t_bwd,
-                                  "bwd_frac_of_hbm_peak_cache_resident": bwd_bytes / (t_bwd * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                  "bwd_us_per_step_rotating": t_brot,
-                                  "bwd_frac_of_hbm_peak_rotating": bwd_bytes / (t_brot * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                  "bwd_rotation_operand_sets": bsets})
-                    bc = _counter_traffic(pmc, pkey, "chord_bwd_fused") or _counter_traffic(pmc, pkey, "chord_dv_")
-                    if bc is not None:
-                        entry["bwd_counters"] = bc
+                    entry["bwd_bytes_per_step"] = bwd_bytes
+                    bwd = {"kernel": "chord_bwd_fused_k" if C <= 32 else "chord_dv_win_k + chord_dw_chunk_k (two launches per step)",
+                           "what": "one backward step, both gradients; rotating: W, V, dW new every launch, dZ = the dV of the launch before",
+                           "us_per_step_cache_resident": t_bwd,
+                           "frac_of_hbm_peak_cache_resident": bwd_bytes / (t_bwd * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                           "us_per_step_rotating": t_brot,
+                           "frac_of_hbm_peak_rotating": bwd_bytes / (t_brot * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                           "rotation_operand_sets": bsets}
+                    bc = _counter_traffic(pmc, pkey, "chord_bwd_fused", bwd_bytes)
+                    if bc is None:  # wide rows: two kernels per step — the dV kernel's counters, against its own bytes
+                        bc = _counter_traffic(pmc, pkey, "chord_dv_", 4 * B * N * (L + 2 * C))
+                    if bc is not None and C <= 32:
+                        bwd["kernel"] = bc["kernel"]
+                    entry["bwd_step_kernel"] = _with_roof(bwd, bc)
                     del Vs, dWs, zz, flatW
             out[name] = entry
             del Wsets, V0, V0s
             torch.cuda.empty_cache()
         bvs = backward_vs_stream(device, timed)
-        bc = _counter_traffic(pmc, "order_train", "chord_bwd_fused")
-        if bc is not None:
-            bvs["counters"] = bc  # (cache-resident operands under the profiler: its traffic is the memory side of L2, not HBM alone)
+        bc = _counter_traffic(pmc, "order_train", "chord_bwd_fused", bvs["step_bytes"])
+        bvs["frac_of_hbm_peak_rotating"] = bvs["step_frac_of_hbm_peak"]
+        _with_roof(bvs, bc)  # (cache-resident operands under the profiler: its traffic is the memory side of L2, not HBM alone)
         out["backward_step_vs_stream"] = bvs
     except Exception as exc:
         out["error"] = repr(exc)

@@ -41,6 +41,15 @@
  * worker threads). The first launch of a kernel instance that needs more than 48 KB of LDS raises that function's limit
  * (hipFuncSetAttribute, idempotent; two threads racing there both succeed).
  *
+ * Streams.  Calls on different streams of one device may run at the same time and share compute units; no entry point
+ * needs the device, a CU or a cache to itself, and no kernel's result depends on what runs beside it. This is tested, not
+ * assumed: the forward chain at BASELINE configs[1]'s full size and the fused backward step are bit-identical to their solo
+ * runs (and the chain to the CPU oracle) while the producer MLP kernels — MFMA phases, the one kind of neighbour the round-4
+ * investigation ever suspected (profiles/r04b_mixer_lds_wait.md) — run on a second stream over the same CUs, and the other way
+ * round (tests/test_gpu_coresidence.py). Two streams buy no time here (both kernel families are bound by the CUs' issue
+ * slots and L2 ports: the two take the sum of their times, profiles/r05y_concurrent_streams_lab.log); the point is that
+ * a caller who does it gets the same bits.
+ *
  * Reference binding this replaces: pybind11 module `spmul_cuda` {forward_host, backward_host}
  * (spmul/spmul_cuda.cu:163-166) and the Python call torch_sparse.spmm (SyntheticExperiments/psf.py:5,178).
  * See INTEGRATION.md for the ctypes stub a maintainer of the reference would add.
@@ -305,8 +314,9 @@ int psf_mixer_fwd_f32(const float* X, int64_t B, int64_t N, int32_t E, int32_t M
  *                        SyntheticExperiments/psf.py:136-141,153-154; the K products are summed first, then the bias
  *   PSF_MIXER_IN_TOKENS  src = int64 tokens [B,N] in [0, K);  X = weight[token] (+ pos[p])
  *                        weight = the embedding table [K,E], pos [N,E] or NULL — psf.py:151-152,157-162, LRA/psf.py:204-209,
- *                        attention_block.py:150-152; one rounded add, as psf_embed_tokens_f32. Tokens are not range-checked
- *                        (device data): an index outside [0, K) reads outside the table, as it would in nn.Embedding.
+ *                        attention_block.py:150-152; one rounded add, as psf_embed_tokens_f32. Tokens are device data and
+ *                        cannot be range-checked by the host: an index outside [0, K) is CLAMPED into the table (row 0
+ *                        or row K-1, as psf_embed_tokens_f32 does) — never a read outside it; nn.Embedding would raise.
  *   weight and pos 16-byte aligned, src aligned to its element type. Everything else as psf_mixer_fwd_f32.
  */
 enum { PSF_MIXER_IN_DATA = 0, PSF_MIXER_IN_AFFINE = 1, PSF_MIXER_IN_TOKENS = 2 };

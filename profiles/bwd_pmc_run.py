@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Workload for the per-shape counter passes: `iters` launches of dV alone, then of dW alone, then of the step that wants both
-(the fused kernel, csrc/bwd_fused.h, where it applies), then of the forward step, at one shape.
+(the fused kernel, csrc/bwd_fused.h, where it applies), then of the forward step, then (round 6) `iters` no-grad chains of
+M = L - 1 steps where the library runs those as ONE launch (chord_chain_lds_k: what inference runs at the LRA lengths), at one shape.
 
     python3 profiles/bwd_pmc_run.py B N L C [iters]
 
@@ -37,6 +38,14 @@ def main():
     for _ in range(iters):  # (round 5) the forward step of the shape too, no residual: counters for every forward instance
         chord._launch_fwd(W, V, None, out, B, N, L, C, N * C, None)
     torch.cuda.synchronize()
+    from sparsefactorization_amd import _lib
+    M = L - 1
+    if "chord_chain_lds_k" in _lib.describe_chain_fwd(B, N, L, C, M):  # the one-launch chain: bench.py's `fwd_chain_kernel`
+        Ws = [0.1 * torch.randn(B, N, L, device=dev, generator=g) for _ in range(M)]
+        with torch.no_grad():
+            for _ in range(iters):
+                chord.chord_chain(Ws, V, False)
+        torch.cuda.synchronize()
     print(f"done B={B} N={N} L={L} C={C} iters={iters} alg_bytes={4 * B * N * (L + 2 * C)}")
 
 

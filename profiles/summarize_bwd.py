@@ -67,9 +67,12 @@ def main():
             row = [f"`{name}`", str(k.get("calls", "")), f"{k.get('avg_us', float('nan')):.2f}"]
             fused = "fused" in name
             fwd = "chord_fwd_" in name
-            full = k.get("calls", 0) >= 50 and ("false>" in name or fused or fwd)  # the main (full-tile) launch of the shape
+            chain = "chord_chain_lds" in name  # ONE launch for all L - 1 steps of a chain (round 6)
+            full = k.get("calls", 0) >= 50 and ("false>" in name or fused or fwd or chain)  # the main (full-tile) launch of the shape
+            alg_k = 4 * B * N * (2 * L + 3 * C) if fused else ((L - 1) * alg if chain else alg)  # the fused step: 4BN(2L+3C)
+            k["alg_bytes_per_launch"] = alg_k
             if "avg_us" in k and full:
-                tbs = (4 * B * N * (2 * L + 3 * C) if fused else alg) / k["avg_us"] / 1e6  # the fused step: 4BN(2L+3C)
+                tbs = alg_k / k["avg_us"] / 1e6
                 k["alg_tbs"], k["frac"] = tbs, tbs / 8.0
                 row += [f"{tbs:.2f}", f"{tbs / 8.0:.3f}"]
             else:
@@ -77,7 +80,6 @@ def main():
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 rd, wr = 2.0 * c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
                 k["traffic_bytes"], k["traffic_read"], k["traffic_write"] = rd + wr, rd, wr
-                alg_k = 4 * B * N * (2 * L + 3 * C) if fused else alg
                 k["traffic_over_alg"] = (rd + wr) / alg_k
                 row += [f"{(rd + wr) / 1e6:.1f} ({rd / 1e6:.1f}+{wr / 1e6:.1f})", f"{(rd + wr) / alg_k:.3f}" if full else ""]
             else:

@@ -9,8 +9,8 @@
 //   the dZ window [q0 - TR, q0 + TR)  — dV's backward window; its upper half IS dW's tile of dZ rows,
 //   the V window  [q0, q0 + 2 TR)     — dW's forward window,
 //   the two W tiles under the dZ window (flat 16-byte-chunk images),
-// loads the far-link operands into registers (dZ rows and W column elements for dV — the latter from the link-major side
-// copy when the producer left one, see psf_chord.h; V rows for dW), then computes dV (links ascending, uncontracted:
+// loads the far-link operands into registers (dZ rows and W column elements for dV, V rows for dW), then computes dV
+// (links ascending, uncontracted:
 // bit-identical to chord_dv_win_k and the oracle), the row dots of dW (same order as chord_dw_win_k) and writes the dW
 // tile flat through LDS (the image reuses the first W tile's bytes).
 // Full tiles only: N a multiple of TR, C / 4 = TG exactly, chunk-clean W / dW buffers; the host sends anything else to

@@ -239,9 +239,7 @@ chord_dv_win_k(const T* __restrict__ dZ, const T* __restrict__ W, T* __restrict_
     if (!EDGE || cgi < gm.CG) stage16<T, VEC, true>(Zb + (int64_t)src * C + (int64_t)cgi * VEC, sWin + n * NT + wave64, lane);
   }
 
-  // (3) far links: dZ rows (coalesced) and one W column element per row, strided out of W's rows (a link-major side copy
-  //     of those columns, written by the forward step, was built in round 2 and removed in round 5: a wash end to end —
-  //     profiles/r02n_far_copy.log, r03aj_farcopy_in_step_ab.log)
+  // (3) far links: dZ rows (coalesced) and one W column element per row, strided out of W's rows
   V4 farZ[R][NF > 0 ? NF : 1];
   T farW[R][NF > 0 ? NF : 1];
 #pragma unroll

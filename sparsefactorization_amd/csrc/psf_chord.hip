@@ -666,7 +666,6 @@ int chain_impl(Tuning tn, const T* const* W_steps, const T* V0, T* const* out_st
   if constexpr (sizeof(T) == 4) {
     // Short sequences: the whole chain in ONE launch with the sequence's X slice resident in LDS.
     ChainLdsPlan plan;
-    // (the single-launch LDS chain reads W rows straight into registers: it cannot emit the far-column side copy)
     // Every workgroup of a sequence streams the sequence's whole W: with `chunks` workgroups per sequence W crosses
     // L2 -> CU `chunks` times and every output row is stored in `chunks` pieces. Past ~8 the per-step kernels win
     // (profiles/r03n_chain_train_sweep.log, us per chain one launch / per step: ListOps N = 2000, C = 128, 32 chunks:

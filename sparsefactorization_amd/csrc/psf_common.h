@@ -127,6 +127,9 @@ __device__ __forceinline__ uint32_t lane_off(uint32_t v) {
 }
 
 // ---- LDS results in kernels that also issue MFMAs: the rule (profiles/r04b_mixer_lds_wait.md, isa_lint.py R3) ----
+// (The MECHANISM below is unproven — an inference from the failure's signature. Round 6 found the bare pattern in every
+// chord kernel, bit-exact beside a co-resident MFMA kernel, and in this rule's own emitted code: what the rule removes is the
+// failing build's remaining difference, OTHER LDS READS OF THE ROW STILL IN FLIGHT when a packed pair is consumed.)
 // A packed-f32 instruction (v_pk_*_f32: 64-bit register-pair operands) must not be the first consumer of a ds_read result
 // right behind the counted `s_waitcnt lgkmcnt(n)` that released it. That is the only thing the ISA of the one sporadically
 // wrong build of this library (chord_fwd_mlp_k, round 4) has which its two clean builds have not; the counts themselves were

@@ -8,6 +8,7 @@ produces the W_m (fused_mlp.py) and runs the chain (chord.chord_chain).
 from __future__ import annotations
 
 import ctypes
+import threading
 from typing import Sequence
 
 import torch
@@ -90,8 +91,9 @@ class Recipe:
         return s.dim() == 2 and s.dtype == torch.int64 and self.weight.dtype == torch.float32 and self.weight.dim() == 2
 
 
-def _block_sizes(E: int, g: nn.Module, fs: Sequence[nn.Module]):
-    """(M, h table, C, L) when every block is Linear, GELU(erf), Linear of input width E and the link MLPs agree on L."""
+def _block_pairs(E: int, g: nn.Module, fs: Sequence[nn.Module]):
+    """((M, h table, C, L), [(lin1, lin2), ...]) when every block is Linear, GELU(erf), Linear of input width E and the link
+    MLPs agree on L; None otherwise."""
     if not len(fs):
         return None
     pairs = [_two_layer(b) for b in [g, *fs]]
@@ -103,13 +105,24 @@ def _block_sizes(E: int, g: nn.Module, fs: Sequence[nn.Module]):
     if any(l2.out_features != L for _, l2 in pairs[1:]):
         return None
     h = (ctypes.c_int32 * len(pairs))(*[l1.out_features for l1, _ in pairs])
-    sz = (len(fs), h, pairs[0][1].out_features, L)
-    global _pending
-    _pending = ((E, id(g), tuple(map(id, fs))), pairs, sz)  # for the mixer_forward_in that follows an eligibility check at once
-    return sz
+    return (len(fs), h, pairs[0][1].out_features, L), pairs
 
 
-_pending = None  # (key, [(lin1, lin2), ...], sizes) left by the last _block_sizes: consumed (and cleared) by the next mixer_forward_in
+def _block_sizes(E: int, g: nn.Module, fs: Sequence[nn.Module]):
+    """(M, h table, C, L), or None (see _block_pairs)."""
+    found = _block_pairs(E, g, fs)
+    return None if found is None else found[0]
+
+
+def _key(E: int, g: nn.Module, fs: Sequence[nn.Module]):
+    return (E, id(g), tuple(map(id, fs)))
+
+
+# What a successful eligibility check found, for the mixer_forward_in that follows it at once ON THE SAME THREAD (a third
+# fewer Python calls per no-grad forward of an LRA network): (key, sizes, pairs). Thread-local — two threads serving two models
+# never see each other's layer pairs — set only when the check says yes, consumed (and cleared) by the next forward, so it
+# keeps no module alive beyond that.
+_handoff = threading.local()
 
 
 def _route_ok(N: int, E: int, M: int, C: int, L: int, h, tokens: int = 1 << 62) -> bool:
@@ -139,21 +152,29 @@ def eligible_recipe(r: Recipe, g: nn.Module, fs: Sequence[nn.Module]) -> bool:
         return False
     if _needs_grad(torch.empty(0), [g, *fs]):
         return False
-    sz = _block_sizes(r.E, g, fs)
-    if sz is None:
+    _handoff.pending = None
+    found = _block_pairs(r.E, g, fs)
+    if found is None:
         return False
-    M, h, C, L = sz
-    return _route_ok(r.N, r.E, M, C, L, h, r.B * r.N) and _lib.load().psf_mixer_fwd_workspace(r.N, r.E, M, h, C, L) >= 0
+    (M, h, C, L), pairs = found
+    ok = _route_ok(r.N, r.E, M, C, L, h, r.B * r.N) and _lib.load().psf_mixer_fwd_workspace(r.N, r.E, M, h, C, L) >= 0
+    if ok:
+        _handoff.pending = (_key(r.E, g, fs), found[0], pairs)
+    return ok
 
 
 def mixer_forward_in(r: Recipe, g: nn.Module, fs: Sequence[nn.Module], use_residual: bool) -> torch.Tensor:
     """V_M [B, N, C] from the recipe of ``data``. Caller checks ``eligible_recipe`` (or ``covered``) first."""
-    global _pending
-    pend, _pending = _pending, None
-    if pend is None or pend[0] != (r.E, id(g), tuple(map(id, fs))):  # (not straight after an eligibility check of the same blocks)
-        _block_sizes(r.E, g, fs)
-        pend, _pending = _pending, None
-    pairs, (M, h, C, L) = pend[1], pend[2]
+    pend = getattr(_handoff, "pending", None)
+    _handoff.pending = None
+    if pend is not None and pend[0] == _key(r.E, g, fs):  # straight after this thread's eligibility check of the same blocks
+        (M, h, C, L), pairs = pend[1], pend[2]
+    else:
+        found = _block_pairs(r.E, g, fs)
+        if found is None:
+            raise ValueError("psf_mixer_fwd does not cover these blocks: every block must be Linear(E, h) -> GELU(erf) -> "
+                             "Linear(h, out) in f32 on input width E, the link MLPs agreeing on L (check eligible() / covered())")
+        (M, h, C, L), pairs = found
     B, N, E = r.B, r.N, r.E
     dev = r.src.device
     lib = _lib.load()

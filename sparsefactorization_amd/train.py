@@ -173,7 +173,11 @@ class ChunkedAdam(torch.optim.Optimizer):
             # parameters are remembered per group)
             live_ids = tuple(map(id, live))
             seen = self._live_states.get(gi)
-            if seen is not None and seen[0] == live_ids and self.state.get(live[0]) is seen[1][0]:  # (state not reset meanwhile)
+            # (every entry re-validated by identity — 8 us for 60 parameters: a user who clears, deletes or replaces ONE
+            # parameter's state between steps, `opt.state[p].clear()` / `del opt.state[p]`, gets fresh moments for it, and
+            # no update ever lands in a dict that self.state no longer holds)
+            if (seen is not None and seen[0] == live_ids
+                    and all(st and self.state.get(p) is st for p, st in zip(live, seen[1]))):
                 states = seen[1]
             else:
                 for p in live:

@@ -93,6 +93,53 @@ def test_argument_validation_returns_codes_not_crashes(lib):
     assert c(None, None, None, 0, 0, 1, 8, 4, 4, 32, None, None) == 0          # M == 0
 
 
+C99_CONSUMER = r"""
+/* A consumer of include/psf_chord.h that is not Python: what a maintainer of the reference would link where
+   spmul/spmul_cuda.cu:163-166 binds forward_host / backward_host with pybind11. Host-only calls: no GPU needed. */
+#include <stdio.h>
+#include <string.h>
+#include "psf_chord.h"
+
+int main(void) {
+  int64_t off[12];
+  float w[4] = {0}, v[4] = {0};
+  if (psf_version() != PSF_ABI_VERSION) return 1;
+  if (psf_chord_offsets(1024, 12, off) != PSF_OK) return 2;
+  if (off[0] != 0 || off[1] != 1 || off[11] != 0) return 3;          /* 2^10 mod 1024: the duplicate self link */
+  if (psf_chord_spmm_fwd_f32(NULL, v, NULL, w, 1, 8, 4, 4, 32, NULL, NULL) != PSF_E_NULL) return 4;
+  if (strstr(psf_last_error(), "NULL") == NULL) return 5;
+  if (psf_chord_spmm_fwd_f32(w, v, NULL, v, 1, 8, 4, 4, 32, NULL, NULL) != PSF_E_ALIAS) return 6;
+  if (psf_chord_spmm_fwd_f32(w, v, NULL, w + 1, 1, 0, 4, 4, 0, NULL, NULL) != PSF_E_SHAPE) return 7;
+  printf("psf_version=%d offsets[11]=%lld\n", psf_version(), (long long)off[11]);
+  return 0;
+}
+"""
+
+
+def test_header_is_c99_and_a_plain_c_program_links_the_library(lib, tmp_path):
+    """include/psf_chord.h is the boundary, and its consumer need not be Python: the header compiles as strict C99
+    (-std=c99 -pedantic -Wall -Werror), a C program links libpsf_chord.so and gets the ABI version, the chord offsets of
+    Pathfinder's shape (N = 1024, L = 12: offset 2^10 = 0 mod N, the duplicate self link the reference keeps —
+    SyntheticExperiments/psf.py:7-32) and the argument-error codes, all before any HIP call."""
+    import shutil
+    import subprocess
+    from sparsefactorization_amd import build
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "consumer.c"
+    src.write_text(C99_CONSUMER)
+    exe = tmp_path / "consumer"
+    libdir = os.path.dirname(build.LIB_PATH)
+    cmd = [gcc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+           "-L", libdir, "-l:libpsf_chord.so", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, f"consumer exited {run.returncode}: {run.stdout} {run.stderr}"
+    assert run.stdout.strip() == "psf_version=2 offsets[11]=0"
+
+
 def test_entry_points_are_callable_from_two_threads_at_once(lib):
     """include/psf_chord.h, "Threads": host-only entry points and the validation paths of the device entry points hammered
     from two threads while a third flips a knob; every call must return what it returns single-threaded, and each thread
@@ -385,3 +432,27 @@ def test_library_carries_the_hash_of_its_sources_and_a_stale_one_is_reported(mon
     assert build.needs_build()
     with pytest.warns(RuntimeWarning, match="built from other sources"):
         _lib._warn_if_stale(lib)
+
+
+def test_fused_mixer_handoff_is_per_thread_and_uncovered_blocks_raise():
+    """fused_mixer hands what its eligibility check found to the forward that follows (round 5: a third fewer Python calls).
+    That hand-off is per thread and keyed: another thread's check can never give this forward another model's layers, and
+    blocks the path does not cover raise a ValueError naming the requirement instead of a TypeError."""
+    import threading
+    from sparsefactorization_amd import fused_mixer
+    from sparsefactorization_amd.psfnet import MLPBlock
+    g, fs = MLPBlock([32, 'GELU'], 32, 8), [MLPBlock([32, 'GELU'], 32, 12) for _ in range(3)]
+    found = fused_mixer._block_pairs(32, g, fs)
+    assert found is not None and found[0][0] == 3 and found[0][2:] == (8, 12) and len(found[1]) == 4
+    fused_mixer._handoff.pending = (fused_mixer._key(32, g, fs), found[0], found[1])
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(getattr(fused_mixer._handoff, "pending", None)))
+    t.start()
+    t.join()
+    assert seen == [None]  # the other thread sees nothing of this thread's pending hand-off
+    fused_mixer._handoff.pending = None
+    odd = [MLPBlock([32, 'GELU'], 32, 12), MLPBlock([32, 'GELU'], 32, 13)]  # link MLPs that disagree on L
+    assert fused_mixer._block_pairs(32, g, odd) is None
+    with pytest.raises(ValueError, match="does not cover these blocks"):
+        fused_mixer.mixer_forward(torch.zeros(1, 64, 32), g, odd, True)
+    assert getattr(fused_mixer._handoff, "pending", None) is None

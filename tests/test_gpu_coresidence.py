@@ -66,42 +66,56 @@ def test_chain_beside_the_mfma_producer_on_a_second_stream(gpu):
 
     sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    outs, yss, spans = [], [], []
-    for r in range(ROUNDS):
+    bad = {sA: torch.zeros((), dtype=torch.int64, device=gpu), sB: torch.zeros((), dtype=torch.int64, device=gpu)}
+    spans, last = [], None
+    # Results are compared with the solo run ON the stream that made them and dropped at once (a count of differing elements
+    # per stream, read after the last round): nothing synchronises between rounds, and from the second round on each stream's
+    # allocator pool already holds the blocks — round 0 is the warm-up that fills the pools (hipMalloc stalls the host; its
+    # overlap is not counted).
+    for r in range(ROUNDS + 1):
         e0, a0, a1, b0, b1 = ev(), ev(), ev(), ev(), ev()
         e0.record()
         sA.wait_event(e0)
         sB.wait_event(e0)
         # alternate who goes first: the chain's workgroups move into CUs the producer is draining from, and the other way round
-        order = (sB, sA) if r % 2 == 0 else (sA, sB)
-        for s in order:
+        for s in ((sB, sA) if r % 2 == 0 else (sA, sB)):
             with torch.cuda.stream(s):
                 if s is sB:
                     b0.record()
-                    yss.append(fused_mlp._forward_raw(x2, params))
-                    b1.record()
+                    for _ in range(2):
+                        ys = fused_mlp._forward_raw(x2, params)
+                        b1.record()
+                        for y, y0 in zip(ys, ys_solo):
+                            bad[sB] += (y != y0).sum()
+                        del ys, y
                 else:
                     a0.record()
-                    outs.append(sfa.chord_chain(Ws, V0, True))
-                    outs.append(sfa.chord_chain(Ws, V0, True))  # two chains ~ one producer launch in time
-                    a1.record()
-        spans.append((e0, a0, a1, b0, b1))
+                    for _ in range(3):  # three chains ~ two producer launches in time
+                        last = sfa.chord_chain(Ws, V0, True)
+                        a1.record()
+                        bad[sA] += (last != solo).sum()
+        if r:
+            spans.append((e0, a0, a1, b0, b1))
+        # both streams start the next round together (on the device: the host does not wait)
+        da, db = torch.cuda.Event(), torch.cuda.Event()
+        da.record(sA)
+        db.record(sB)
+        sA.wait_event(db)
+        sB.wait_event(da)
     torch.cuda.synchronize()
 
     overlaps = [_overlap_ms(*s)[0] for s in spans]
-    print("coresidence: busy-interval overlap per round, ms:", [round(o, 3) for o in overlaps])
-    assert max(overlaps) > 0.05, f"the two streams never ran at the same time ({overlaps}): the test did not test co-residence"
-    for o in outs:
-        assert torch.equal(o, solo)
-    for ys in yss:
-        for y, y0 in zip(ys, ys_solo):
-            assert torch.equal(y, y0)
+    print("coresidence: overlap of the two streams' kernel intervals per round, ms:", [round(o, 3) for o in overlaps])
+    assert sum(o > 0.1 for o in overlaps) >= ROUNDS // 2, \
+        f"the two streams ran at the same time in too few rounds ({overlaps}): the test did not test co-residence"
+    assert int(bad[sA]) == 0, f"{int(bad[sA])} chain elements differ from the solo run beside the MFMA producer"
+    assert int(bad[sB]) == 0, f"{int(bad[sB])} producer outputs differ from the solo run beside the chord chain"
     sel = [0, 37, 63]
     W_np = np.stack([w[sel].cpu().numpy() for w in Ws])
     rows, cols = oc.chord_indices(16384, 15)
     want = oc.chain(np.stack([rows, cols]), W_np, V0[sel].cpu().numpy(), True)[-1]
     assert np.array_equal(solo[sel].cpu().numpy(), want)
-    assert np.array_equal(outs[-1][sel].cpu().numpy(), want)
+    assert np.array_equal(last[sel].cpu().numpy(), want)
 
 
 def test_backward_step_beside_the_mfma_mlp_backward_on_a_second_stream(gpu):
@@ -127,22 +141,24 @@ def test_backward_step_beside_the_mfma_mlp_backward_on_a_second_stream(gpu):
     sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
     sA.wait_stream(torch.cuda.current_stream())
     sB.wait_stream(torch.cuda.current_stream())
-    got, got_mlp = [], []
-    for r in range(ROUNDS):
+    bad = {sA: torch.zeros((), dtype=torch.int64, device=gpu), sB: torch.zeros((), dtype=torch.int64, device=gpu)}
+    for r in range(ROUNDS + 1):  # (round 0 fills the streams' allocator pools)
         for s in ((sB, sA) if r % 2 == 0 else (sA, sB)):
             with torch.cuda.stream(s):
                 if s is sB:
-                    got_mlp.append(fused_mlp._backward_raw(x2, params, gys, True))
+                    dX, grads = fused_mlp._backward_raw(x2, params, gys, True)
+                    bad[sB] += (dX != dX0).sum()
+                    for a, b in zip(grads, grads0):
+                        bad[sB] += (a != b).sum()
+                    del dX, grads
                 else:
                     for _ in range(8):  # ~ 8 x 45 us beside a ~ 0.75 ms MLP backward
-                        got.append(step())
+                        dW, dV = step()
+                        bad[sA] += (dV != dV0).sum() + (dW != dW0).sum()
+                        del dW, dV
     torch.cuda.synchronize()
-    for dW, dV in got:
-        assert torch.equal(dV, dV0) and torch.equal(dW, dW0)
-    for dX, grads in got_mlp:
-        assert torch.equal(dX, dX0)
-        for a, b in zip(grads, grads0):
-            assert torch.equal(a, b)
+    assert int(bad[sA]) == 0, f"{int(bad[sA])} gradient elements of the chord step differ from the solo run"
+    assert int(bad[sB]) == 0, f"{int(bad[sB])} gradient elements of the MLP backward differ from the solo run"
     sel = [0, 21, 39]
     want_dW, want_dV = oc.spmul_bwd(dZ[sel].cpu().numpy(), W[sel].cpu().numpy(), V[sel].cpu().numpy())
     assert np.array_equal(dV0[sel].cpu().numpy(), want_dV)
