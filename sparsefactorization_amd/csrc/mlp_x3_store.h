@@ -1,5 +1,5 @@
 // mlp_x3_store.h — how a finished Y^T accumulator tile of the split-bf16 producer kernels leaves the registers: shared by
-// x3_fwd_k (mlp_fwd_x3.hip) and x3w_fwd_k (mlp_fwd_x3w.hip). Everything in an unnamed namespace (one copy per unit).
+// x3_fwd_k (mlp_fwd_x3.hip) and the lab kernel x3w_fwd_k (profiles/r06b_x3w_woven_kernel.patch). Everything in an unnamed namespace (one copy per unit).
 #pragma once
 
 #include <hip/hip_runtime.h>
