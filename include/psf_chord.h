@@ -441,6 +441,10 @@ int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float
  *                      tiles, as many as fit below (five of 256 threads at C = 8); n = at most n (by requesting more LDS).
  *                      Round-4 kernel, rotating operands: 42.3 (what fits) / 40.9 (three) us at Order B = 40, 12.6 / 13.5 on
  *                      2048 tiles
+ *   key "bwd_fronts" : fused backward step (full tiles): 0 = automatic (default): from N = 8192 on every XCD walks the tiles of
+ *                      a batch element as TWO interleaved fronts half a sequence apart (the rows the longest link joins are
+ *                      then in flight together: Order shape 41.1 -> 39.2 us per step); 1 = one front; 2, 4, 8 = that many
+ *                      (speed only: results do not depend on the order of workgroups)
  *   key "wide_fuse"  : psf_mlp_wide_fwd_f32: 1 = the second layers of the MLPs with <= 32 outputs run inside the first
  *                      layers' GEMM epilogue when every MLP has 97..128 hidden rows (default), 0 = always the separate kernel
  *   key "mixer_lds"  : psf_mixer_fwd_*: 1 = short sequences take the single-launch LDS-resident mixer (default), 0 = per-step kernels

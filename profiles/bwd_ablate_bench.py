@@ -28,7 +28,11 @@ ARMS = [(0, "everything"), (2, "no far W elements"), (1, "no far dZ / V rows"), 
         (16, "no dV arithmetic"), (32, "no dW gathers"), (48, "no arithmetic on staged operands"),
         (64, "no stores"), (79, "no loads, no stores"), (112, "loads only"), (115, "staged loads only"),
         (124, "far loads only"), (63, "stores only"),
-        (128, "variant: dW stored non-temporally"), (512, "variant: dW dots as FMAs"), (640, "variant: both")]
+        (128, "variant: dW stored non-temporally"), (512, "variant: dW dots as FMAs"), (640, "variant: both"),
+        (256, "variant: far dZ / V rows by LDS-DMA"), (258, "the same, no far W elements"), (320, "the same, no stores")]
+if len(sys.argv) > 5:
+    keep = {int(a) for a in sys.argv[5].split(",")}
+    ARMS = [a for a in ARMS if a[0] in keep]
 
 
 def reading(abl, cold, steps=100):

@@ -23,6 +23,8 @@ KNOBS = {  # knob: values (first = default)
     "chain_fused": (1, 0, 2),
     "fwd_split": (1, 0, 2),
 }
+if os.environ.get("PSF_SWEEP_KNOBS"):  # e.g. PSF_SWEEP_KNOBS="bwd_ablate=0,1024,2048" (lab knobs; first value = the default)
+    KNOBS = {kv.split("=")[0]: tuple(int(v) for v in kv.split("=")[1].split(",")) for kv in os.environ["PSF_SWEEP_KNOBS"].split(";")}
 for task in (sys.argv[1:] or ["order", "genome", "imdb", "pathfinder", "listops", "cifar10"]):
     torch.manual_seed(42)
     loss = torch.nn.CrossEntropyLoss()

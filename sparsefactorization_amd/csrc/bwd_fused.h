@@ -47,7 +47,8 @@ struct BwdFusedCfg {
 // ABL (diagnostic builds only, -DPSF_BWD_ABLATE_LAB, tuning knob "bwd_ablate"; 0 in the product): leave parts out to see what
 // the step's time is made of — 1 far dZ / V rows, 2 far W elements, 4 the dZ and V windows, 8 the W tiles, 16 dV's
 // arithmetic, 32 dW's arithmetic, 64 the stores (results are then wrong by construction); variants that stay correct: 128 dW
-// stored non-temporally, 512 dW's dots contracted to FMAs.
+// stored non-temporally, 512 dW's dots contracted to FMAs, 256 (round 6) the far dZ / V rows by LDS-DMA into LDS (2 NF NT 16
+// more bytes of LDS: 48 KB at C = 8) instead of 2 NF 16-byte register loads per thread.
 template <int L, int TGS, int NT, int ABL = 0>
 __global__ void __launch_bounds__(NT, (NT == 256 && TGS <= 1) ? 5 : 2)
 chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, const float* __restrict__ V,
@@ -63,9 +64,12 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
   V4* __restrict__ sWV = reinterpret_cast<V4*>(smem + 2 * Cfg::win_bytes);
   const T* __restrict__ sWF = reinterpret_cast<const T*>(sWV);
   T* __restrict__ sOutF = reinterpret_cast<T*>(sWV);  // the dW tile image: written after the last read of the W tiles
+  V4* __restrict__ sFarZ = reinterpret_cast<V4*>(smem + FC::lds_bytes);  // ABL & 256 only: [NF][NT] far dZ rows, then far V rows
+  V4* __restrict__ sFarV = sFarZ + (NF > 0 ? NF : 1) * NT;
 
   int b, tile, chunk;
   decode_block(gm, b, tile, chunk);  // chunks_c == 1
+  if (gm.ileave) tile = (tile & ((1 << gm.ileave) - 1)) * (gm.tiles_n >> gm.ileave) + (tile >> gm.ileave);
   const int tid = threadIdx.x, wave64 = tid & ~63;
   const int g = tid & (TG - 1), pl = tid >> TGS;  // one row per thread: row slot = local row
   const int q0 = tile * TR, N = gm.N, C = gm.C;
@@ -106,7 +110,10 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
     if (src0[f] < 0) src0[f] += N;
     int dst0 = q0 + offs.v[KN + f];
     if (dst0 >= N) dst0 -= N;
-    if constexpr (!(ABL & 1)) {
+    if constexpr ((ABL & 256) != 0) {
+      stage16g<0>(sbase(Zbb + (uint32_t)src0[f] * rowB) + voff, sFarZ + f * NT + wave64);
+      stage16g<0>(sbase(Vbb + (uint32_t)dst0 * rowB) + voff, sFarV + f * NT + wave64);
+    } else if constexpr (!(ABL & 1)) {
       farZ[f] = ldg<T, VEC>(sbase(Zbb + (uint32_t)src0[f] * rowB) + voff);
       farV[f] = ldg<T, VEC>(sbase(Vbb + (uint32_t)dst0 * rowB) + voff);
     } else {
@@ -165,7 +172,7 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
       }
     }
 #pragma unroll
-    for (int f = 0; f < NF; ++f) axpy_rn<T, VEC>(acc, farW[f], farZ[f]);
+    for (int f = 0; f < NF; ++f) axpy_rn<T, VEC>(acc, farW[f], (ABL & 256) ? sFarZ[f * NT + tid] : farZ[f]);
     if (!(ABL & 64) || acc.e[0] == T(12345.678)) {
       // (Non-temporal dV / dW stores for rows of >= 16 channels were in for a while in round 5: with operands rotating through
       // 640 MB they take 10 % off the step — C = 32, N = 16384: 47.5 -> 42.9 us, counters 174 -> 117 MB read where 83 are
@@ -183,7 +190,7 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
     for (int k = 0; k < L; ++k) {
       V4 x;
       if (k < KN) x = (ABL & 32) ? dz : sV[((pl + chord_off(k)) << TGS) + g];
-      else x = farV[k - KN < NF ? k - KN : 0];
+      else x = (ABL & 256) ? sFarV[(k - KN < NF ? k - KN : 0) * NT + tid] : farV[k - KN < NF ? k - KN : 0];
       // the lane's four products as two packed multiplies, summed pairwise: (p0 + p2) + (p1 + p3) — four instructions. (Written
       // as a running sum, hipcc paired the sums of two LINKS into packed adds and paid four register moves per pair: eight
       // instructions per link. dW is held to 1e-5, not to the oracle's bits: its sum over a row's lanes is a tree already.)

@@ -138,6 +138,7 @@ hipError_t launch_fused(const BwdWinArgs& a) {
     return launch_fused<L, TGS, NT, X>(a);
       PSF_ABL(1) PSF_ABL(2) PSF_ABL(3) PSF_ABL(4) PSF_ABL(8) PSF_ABL(12) PSF_ABL(15) PSF_ABL(16) PSF_ABL(32) PSF_ABL(48)
       PSF_ABL(63) PSF_ABL(64) PSF_ABL(79) PSF_ABL(112) PSF_ABL(115) PSF_ABL(124) PSF_ABL(128) PSF_ABL(512) PSF_ABL(640)
+      PSF_ABL(256) PSF_ABL(258) PSF_ABL(320) PSF_ABL(368)
 #undef PSF_ABL
       default:
         break;
@@ -145,7 +146,7 @@ hipError_t launch_fused(const BwdWinArgs& a) {
   }
 #endif
   auto kern = chord_bwd_fused_k<L, TGS, NT, ABL>;
-  int lds = Cfg::lds_bytes;
+  int lds = Cfg::lds_bytes + ((ABL & 256) ? 2 * BwdWinCfg<float, L, TGS, 1, NT>::NF * NT * 16 : 0);
   if (a.wg_per_cu > 0) {  // occupancy limiter as in the forward launcher (fwd_window_inst.hip)
     const int floor_bytes = kLdsPerCu / (a.wg_per_cu + 1) + 256;
     if (floor_bytes > lds && floor_bytes <= 64 * 1024) lds = floor_bytes;

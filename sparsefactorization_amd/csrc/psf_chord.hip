@@ -63,6 +63,7 @@ std::atomic<int> g_fwd_wg_limit{0};
 std::atomic<int> g_bwd_fused_wg_limit{0};  // fused backward step: 0 = whatever fits (five of 256 threads at C = 8), n = at most n
 // Per-step launches of a chain: 1 = alternate the direction in which each XCD walks its tile range
 std::atomic<int> g_chain_zigzag{1};
+std::atomic<int> g_bwd_fronts{0};     // fused backward step: interleaved fronts per batch element, 0 = auto (2 from N = 8192 on), 1, 2, 4, 8
 std::atomic<int> g_bwd_ablate{0};      // fused backward step, -DPSF_BWD_ABLATE_LAB builds only (bwd_fused.h: ABL); ignored otherwise
 std::atomic<int> g_mixer_ablate{0};    // timing experiments on that kernel: bit 0 no MLP arithmetic, 1 no multiply-add chain, 2 no far rows, 3 no data rows
 std::atomic<int> g_mixer_lds{1};       // psf_mixer_fwd_*: 1 = short sequences take the single-launch LDS-resident mixer (mixer_lds.h)
@@ -97,6 +98,7 @@ Knob g_knobs[] = {
     {"mixer_lds", &g_mixer_lds, 0, 1},
     {"mixer_ablate", &g_mixer_ablate, 0, 15},
     {"bwd_ablate", &g_bwd_ablate, 0, 1023},
+    {"bwd_fronts", &g_bwd_fronts, 0, 8},
     {"chain_fused", &g_chain_fused, 0, 2},
     {"chain_cc", &g_chain_cc, 0, 1},
     {"mlp_variant", &psf_g_mlp_variant, 0, 3},
@@ -108,7 +110,7 @@ Knob g_knobs[] = {
 // odd steps) travels in it too instead of in thread-local state.
 struct Tuning {
   int fwd_variant, bwd_variant, xcd_remap, fwd_split, dv_threads, bwd_fused, dw_variant,
-      dw_tgs, chain_fused, chain_cc, fwd_wide, fwd_wg_limit, bwd_fused_wg_limit, chain_zigzag, mixer_wg_limit, mixer_ablate, mixer_lds, bwd_ablate;
+      dw_tgs, chain_fused, chain_cc, fwd_wide, fwd_wg_limit, bwd_fused_wg_limit, chain_zigzag, mixer_wg_limit, mixer_ablate, mixer_lds, bwd_ablate, bwd_fronts;
   bool walk_backwards;
 };
 
@@ -122,6 +124,7 @@ Tuning snapshot() {
   t.bwd_fused_wg_limit = g_bwd_fused_wg_limit.load(), t.chain_zigzag = g_chain_zigzag.load();
   t.mixer_wg_limit = g_mixer_wg_limit.load(), t.mixer_ablate = g_mixer_ablate.load(), t.mixer_lds = g_mixer_lds.load();
   t.bwd_ablate = g_bwd_ablate.load();
+  t.bwd_fronts = g_bwd_fronts.load();
   t.walk_backwards = false;
   return t;
 }
@@ -192,6 +195,7 @@ int make_geom(const Tuning& tn, int64_t B, int64_t N, int32_t L, int64_t C, int 
   gm->xr = gm->nblocks % kXcds;
   gm->remap = tn.xcd_remap ? (tn.walk_backwards && tn.chain_zigzag ? 2 : 1) : 0;
   gm->aligned = 0;  // window_launches sets it from the pick
+  gm->ileave = 0;
   gm->v_bstride = v_bstride;
   return PSF_OK;
 }
@@ -574,6 +578,18 @@ int bwd_impl(const Tuning& tn, const T* dZ, const T* W, const T* V, T* dW, T* dV
         a.wg_per_cu = tn.bwd_fused_wg_limit ? tn.bwd_fused_wg_limit : (B * (int64_t)pk.tiles_full >= 4096 ? 3 : 0);
         a.ablate = tn.bwd_ablate;
         if (int rc = make_geom(tn, B, N, L, C, 4, pk.tgs, pk.TR, false, v_batch_stride, 0, pk.tiles_full, &a.gm)) return rc;
+        // Two interleaved fronts per batch element (Geom::ileave, bwd_fused.h): tile t of the XCD's walk is row block
+        // (t mod 2) tiles / 2 + t / 2, so the rows N / 2 apart that the longest link joins are in flight together. Round 6,
+        // operands rotating as in the chain's backward (profiles/r06c_bwd_ileave2.log, us per step, one front / two): Order
+        // shape (N = 16384, C = 8, B = 40) 41.1 / 39.2, N = 4096 x 32 channels 22.1 / 21.6, genome (N = 16384 x 32) 46.5 / 47.0
+        // (noise); four and eight fronts equal two. In the training steps (r06c_step_ileave.log): Order 2.100 -> 2.074 ms,
+        // genome 1.764 -> 1.734, IMDb (edge kernel: not applicable) unchanged. Auto: two fronts from N = 8192 on.
+        {
+          const int fronts = tn.bwd_fronts ? tn.bwd_fronts : (N >= 8192 ? 2 : 1);
+          int sh = 0;
+          while ((2 << sh) <= fronts) ++sh;
+          if (sh > 0 && pk.tiles_full % (1 << sh) == 0) a.gm.ileave = sh;
+        }
         hipError_t e = launch_fused_step(pk.tgs, L, a);
         if (e != hipSuccess) return fail_hip(e, "chord_bwd_fused");
         dW = nullptr;

@@ -34,6 +34,8 @@ struct Geom {
   uint32_t per_b_inv, chunks_inv;  // floor(2^32 / per_b), floor(2^32 / chunks_c) (2^32 - 1 for a divisor of 1): udiv_inv
   uint32_t xq, xr;   // nblocks / 8, nblocks % 8 for the bijective XCD remap
   int32_t remap;     // 1: logical block order is contiguous per XCD group
+  int32_t ileave;    // fused backward step: s > 0 walks the tiles of a batch element as 2^s interleaved fronts (tile t ->
+                     // (t mod 2^s) tiles_n / 2^s + t / 2^s): rows N / 2^s apart are in flight together (knob "bwd_fronts")
   int32_t aligned;   // 1: N is a multiple of TR, so is every far offset, and a batch element's rows span < 2^31 bytes: every
                      //    row block a full tile touches is TR-aligned and never wraps inside (scalar block addresses)
   int64_t v_bstride; // elements between batch elements of the gathered operand (0 = broadcast)

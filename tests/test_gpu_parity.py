@@ -899,3 +899,28 @@ def test_fused_backward_step_general_instance(gpu, B, N, L, C):
     finally:
         sfa.set_tuning("bwd_fused", 1)
 
+
+
+@pytest.mark.parametrize("B,N,L,C", [(3, 16384, 15, 8), (2, 8192, 14, 32), (2, 8192 + 256, 14, 16)])
+def test_fused_backward_fronts_only_reorder_workgroups(gpu, B, N, L, C):
+    """Knob "bwd_fronts" (round 6): an XCD walks the tiles of a batch element as 1, 2, 4 or 8 interleaved fronts. Whatever
+    the walk, both gradients are the same bits, dV the oracle's (spmul_cuda.cu:75-84) and dW within 1e-5 (:102-111)."""
+    import sparsefactorization_amd as sfa
+    g = torch.Generator(device=gpu).manual_seed(N + C)
+    W = 0.3 * torch.randn(B, N, L, device=gpu, generator=g)
+    V = torch.randn(B, N, C, device=gpu, generator=g)
+    dZ = torch.randn(B, N, C, device=gpu, generator=g)
+    got = {}
+    try:
+        for fronts in (0, 1, 2, 4, 8):
+            sfa.set_tuning("bwd_fronts", fronts)
+            Wr, Vr = W.clone().requires_grad_(True), V.clone().requires_grad_(True)
+            sfa.chord_spmm(Wr, Vr).backward(dZ)
+            got[fronts] = (Wr.grad, Vr.grad)
+    finally:
+        sfa.set_tuning("bwd_fronts", 0)
+    for fronts in (0, 2, 4, 8):
+        assert torch.equal(got[fronts][0], got[1][0]) and torch.equal(got[fronts][1], got[1][1]), fronts
+    want_dW, want_dV = oc.spmul_bwd(dZ.cpu().numpy(), W.cpu().numpy(), V.cpu().numpy())
+    assert np.array_equal(got[0][1].cpu().numpy(), want_dV)
+    assert rel_inf(got[0][0].cpu().numpy(), want_dW) <= TOL
