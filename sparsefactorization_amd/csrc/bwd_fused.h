@@ -69,7 +69,6 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
 
   int b, tile, chunk;
   decode_block(gm, b, tile, chunk);  // chunks_c == 1
-  if (gm.ileave) tile = (tile & ((1 << gm.ileave) - 1)) * (gm.tiles_n >> gm.ileave) + (tile >> gm.ileave);
   const int tid = threadIdx.x, wave64 = tid & ~63;
   const int g = tid & (TG - 1), pl = tid >> TGS;  // one row per thread: row slot = local row
   const int q0 = tile * TR, N = gm.N, C = gm.C;

@@ -583,7 +583,9 @@ int bwd_impl(const Tuning& tn, const T* dZ, const T* W, const T* V, T* dW, T* dV
         // operands rotating as in the chain's backward (profiles/r06c_bwd_ileave2.log, us per step, one front / two): Order
         // shape (N = 16384, C = 8, B = 40) 41.1 / 39.2, N = 4096 x 32 channels 22.1 / 21.6, genome (N = 16384 x 32) 46.5 / 47.0
         // (noise); four and eight fronts equal two. In the training steps (r06c_step_ileave.log): Order 2.100 -> 2.074 ms,
-        // genome 1.764 -> 1.734, IMDb (edge kernel: not applicable) unchanged. Auto: two fronts from N = 8192 on.
+        // genome 1.764 -> 1.734, IMDb (edge kernel: not applicable) unchanged. Auto: two fronts from N = 8192 on. (The forward
+        // window kernel gains nothing from it at any shape — cfg2 25.8 / 26.0 us, genome 22.8 / 23.2 — and keeps one front:
+        // profiles/r06c_fwd_fronts.log.)
         {
           const int fronts = tn.bwd_fronts ? tn.bwd_fronts : (N >= 8192 ? 2 : 1);
           int sh = 0;

@@ -34,8 +34,9 @@ struct Geom {
   uint32_t per_b_inv, chunks_inv;  // floor(2^32 / per_b), floor(2^32 / chunks_c) (2^32 - 1 for a divisor of 1): udiv_inv
   uint32_t xq, xr;   // nblocks / 8, nblocks % 8 for the bijective XCD remap
   int32_t remap;     // 1: logical block order is contiguous per XCD group
-  int32_t ileave;    // fused backward step: s > 0 walks the tiles of a batch element as 2^s interleaved fronts (tile t ->
-                     // (t mod 2^s) tiles_n / 2^s + t / 2^s): rows N / 2^s apart are in flight together (knob "bwd_fronts")
+  int32_t ileave;    // s > 0: the tiles of a batch element are walked as 2^s interleaved fronts (position t of the walk is row
+                     // block (t mod 2^s) tiles_n / 2^s + t / 2^s): rows N / 2^s apart are in flight together. Needs 2^s | tiles_n.
+                     // Knob "bwd_fronts" (fused backward step; the forward kernels gain nothing from it: r06c_fwd_fronts.log)
   int32_t aligned;   // 1: N is a multiple of TR, so is every far offset, and a batch element's rows span < 2^31 bytes: every
                      //    row block a full tile touches is TR-aligned and never wraps inside (scalar block addresses)
   int64_t v_bstride; // elements between batch elements of the gathered operand (0 = broadcast)
@@ -73,7 +74,9 @@ __device__ __forceinline__ void decode_block(const Geom& gm, int& b, int& tile, 
   const uint32_t rem = lb - (uint32_t)b * (uint32_t)gm.per_b;
   const uint32_t t = udiv_inv(rem, (uint32_t)gm.chunks_c, gm.chunks_inv);
   chunk = (int)(rem - t * (uint32_t)gm.chunks_c);
-  tile = (int)t + gm.tile0;
+  // interleaved fronts (Geom::ileave): position t of the walk is row block (t mod 2^s) tiles_n / 2^s + t / 2^s
+  const uint32_t tt = gm.ileave ? (t & ((1u << gm.ileave) - 1u)) * ((uint32_t)gm.tiles_n >> gm.ileave) + (t >> gm.ileave) : t;
+  tile = (int)tt + gm.tile0;
 }
 
 // ---- exact (uncontracted) arithmetic: a rounded product followed by a rounded sum, like the CPU path ----
