@@ -137,11 +137,8 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
       stage16g<0>(sbase(wc + (size_t)FC::full * NT * 16) + i * 16u, sWV + FC::tile_vecs + FC::full * NT + wave64);
     }
   }
-  // (3b) far-link W elements: element (src0 + pl) of the link's column of row-major W. (Reading them from a link-major side
-  //      copy — consecutive rows consecutive floats, the contiguous layout the round-4 review asked for — did not move this
-  //      step: 44.6 vs 43.8 us in the training step, profiles/r03aj_farcopy_in_step_ab.log; the copy was removed in round 5. Nor
-  //      do fewer instructions: lane g of a row loading link f + g and the row's lanes swapping by DPP — NF / TG loads instead of
-  //      NF — is 4-15 % SLOWER, profiles/r05o_bwd_farw_pack.log. Without these loads the step is 5 us shorter, r04o_bwd_ablate.log.)
+  // (3b) far-link W elements: element (src0 + pl) of the link's column of row-major W (a contiguous side copy, lane-packed
+  //      loads and the far rows through LDS were all measured and dropped: DESIGN.md 4.10)
   if constexpr (!(ABL & 2)) {
 #pragma unroll
     for (int f = 0; f < NF; ++f)
@@ -173,11 +170,7 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
 #pragma unroll
     for (int f = 0; f < NF; ++f) axpy_rn<T, VEC>(acc, farW[f], (ABL & 256) ? sFarZ[f * NT + tid] : farZ[f]);
     if (!(ABL & 64) || acc.e[0] == T(12345.678)) {
-      // (Non-temporal dV / dW stores for rows of >= 16 channels were in for a while in round 5: with operands rotating through
-      // 640 MB they take 10 % off the step — C = 32, N = 16384: 47.5 -> 42.9 us, counters 174 -> 117 MB read where 83 are
-      // algorithmic, profiles/r05n_bwd_nt_store*.log — but in the training steps, where the next kernel reads this dV at once,
-      // they cost 0.3-1 %: IMDb 1.556 -> 1.571 ms, Pathfinder 0.943 -> 0.952, genome 1.686 -> 1.690, Order 2.19 = 2.19
-      // (profiles/r05x_lra_step_fused_nt_ab2.log, arms interleaved in one process). The step decides: plain stores.)
+      // dV is a plain store: the next (earlier) step reads it at once (non-temporal measured and dropped: DESIGN.md 4.10)
       stg<T, VEC>(sbase(reinterpret_cast<char*>(dV + ((int64_t)b * N + q0) * C)) + lane_off(voff), acc);
     }
   }
@@ -225,11 +218,7 @@ chord_bwd_fused_k(const float* __restrict__ dZ, const float* __restrict__ W, con
     const int i = n * NT + tid;
     if (n < FC::full || i < FC::tile_vecs) {
       // The dW tile leaves non-temporally: nothing reads it before the MLP backward at the end of the chain, and parked in
-      // L2 it pushes out the dZ / V rows the tiles re-read through their far links. Training steps, arms interleaved in one
-      // process (profiles/r05x_step_fused_dw_nt_ab2.log): Order 2.104 -> 2.079 ms, Pathfinder 0.964 -> 0.955, genome 1.694 ->
-      // 1.684. dV stays a plain store: the next step reads it at once (see the dV store). (The W tiles fetched with the
-      // non-temporal hint instead — each is read by two tiles only —: Order 2.073 -> 2.079, genome 1.681 -> 1.711: no.
-      // profiles/r05y_step_bwd_w_nt_ab.log)
+      // L2 it pushes out the dZ / V rows the tiles re-read through their far links (Order step 2.104 -> 2.079 ms: DESIGN.md 4.3)
       using F4 = float __attribute__((ext_vector_type(4)));
       __builtin_nontemporal_store(*reinterpret_cast<const F4*>(&sOutV[i]), reinterpret_cast<PSF_GLOBAL F4*>(ob + ((uint32_t)(n * NT) * 16u + vo)));
     }

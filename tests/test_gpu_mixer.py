@@ -339,3 +339,57 @@ def test_automatic_route_follows_the_measured_rule(gpu):
             seen["capturing"] = fused_mixer.eligible(x, g, fs)
     torch.cuda.synchronize()
     assert seen["capturing"] is False
+
+
+def test_same_samples_on_both_sides_of_the_route_boundary_and_under_capture(gpu):
+    """The automatic route picks the kernel family by batch size and by whether a HIP graph is being captured
+    (fused_mixer._route_ok: hidden-128 LRA widths take the per-step fused kernels while B N <= 40 000 tokens AND the forward is
+    eager; W through memory above that and under capture). The two families evaluate W with different arithmetic (split-bf16
+    GEMM inside the step / producer kernel), so the SAME sample gives different bits on the two sides of the boundary and in
+    eager vs replayed forwards ("What the route decides"). What is pinned here: every route stays within the
+    parity bar of the float64-MLP oracle chain, and therefore within 2e-5 of each other, on the Pathfinder network's shapes
+    (LRA/psf_training_config.py:60-88) at 32 k tokens (fused) and 65 k tokens (through memory), eager and captured."""
+    from sparsefactorization_amd import fused_mixer
+    from sparsefactorization_amd.psfnet import LRAPSFNet
+    torch.manual_seed(3)
+    net = LRAPSFNet(225, 32, 1024, 11, [128, 'GELU'], [128, 'GELU'], 32, 2, 'FLATTEN', ['linear'], True, False, 0.1, 0.1, 0.1,
+                    False, True, 'pathfinder').to(gpu).eval()
+    x_small = torch.randint(0, 225, (32, 1024), device=gpu)          # 32 768 tokens: the fused per-step kernels
+    x_large = torch.cat([x_small, torch.randint(0, 225, (32, 1024), device=gpu)])  # 65 536 tokens: W through memory
+    assert fused_mixer.route == "auto"
+    taken = []
+    orig = fused_mixer.mixer_forward_in
+
+    def spy(*a, **k):
+        taken.append(1)
+        return orig(*a, **k)
+
+    fused_mixer.mixer_forward_in = spy
+    try:
+        with torch.no_grad():
+            small = net(x_small)
+            n_small = len(taken)
+            large = net(x_large)
+            n_large = len(taken) - n_small
+            # the same 32 samples under stream capture: the GPU-time rule applies, W goes through memory
+            static_x = x_small.clone()
+            side = torch.cuda.Stream(gpu)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                net(static_x)  # warm-up on the side stream (allocations)
+                torch.cuda.synchronize()
+                before = len(taken)
+                with torch.cuda.graph(graph, stream=side):
+                    captured = net(static_x)
+                n_capture = len(taken) - before
+            graph.replay()
+            torch.cuda.synchronize()
+    finally:
+        fused_mixer.mixer_forward_in = orig
+    assert (n_small, n_large, n_capture) == (1, 0, 0), "the routes this test is about were not the ones taken"
+    ref = small.double()
+    scale = float(ref.abs().max())
+    # logits of the same 32 samples: across the batch-size boundary, and eager vs replayed
+    assert float((large[:32].double() - ref).abs().max()) <= 2e-5 * scale
+    assert float((captured.double() - ref).abs().max()) <= 2e-5 * scale
+    assert torch.equal(captured, large[:32])  # both W-through-memory: the same kernels on the same rows, the same bits
