@@ -749,6 +749,9 @@ def _with_roof(entry, counters):
         entry["bound"] = "l2"
         entry["l2_to_cu_GBps"] = counters["l2_to_cu_GBps"]
         entry["l2_roof_GBps"] = list(L2_ROOF_GBS)
+        # (every request priced at a full 128-byte line, so the rate is an upper estimate — 4-byte far-W loads and partial
+        # lines move less — and a fraction above 1 reads "at the roof"; the roof is the guide's range, low end .. high end)
+        entry["l2_request_bytes_assumed"] = L2_REQUEST_BYTES
         entry["frac_of_l2_roof"] = [counters["l2_to_cu_GBps"] / L2_ROOF_GBS[1], counters["l2_to_cu_GBps"] / L2_ROOF_GBS[0]]
     elif toa is not None and toa > 1.1:
         entry["bound"] = "hbm (re-reads: traffic over algorithmic %.2f)" % toa
