@@ -72,8 +72,8 @@ def _units():
 
 def _unit_table():
     """The units without the hash define (csrc_hash() folds their flags in). `lint`: the unit's gfx950 assembly is kept and
-    checked by isa_lint.py — since round 6 EVERY unit (R0-R2 hold everywhere; R3-pattern sites are counted everywhere and
-    are an error only in kernels that issue MFMAs themselves, isa_lint.py's docstring)."""
+    checked by isa_lint.py — since round 6 EVERY unit (R0-R2 are errors everywhere; R3-pattern sites are counted everywhere,
+    reported as warnings in their failing form, and errors only in R3_STRICT_UNITS: isa_lint.py's docstring)."""
     units = [(os.path.join(OBJ_DIR, "psf_chord.o"), os.path.join(CSRC, "psf_chord.hip"), []),
              (os.path.join(OBJ_DIR, "linear_wgrad.o"), os.path.join(CSRC, "linear_wgrad.hip"), []),
              # -fno-slp-vectorize: the LDS-resident chain's multiply-add loop is faster on scalar f32 instructions than on the
