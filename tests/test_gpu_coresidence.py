@@ -163,3 +163,73 @@ def test_backward_step_beside_the_mfma_mlp_backward_on_a_second_stream(gpu):
     want_dW, want_dV = oc.spmul_bwd(dZ[sel].cpu().numpy(), W[sel].cpu().numpy(), V[sel].cpu().numpy())
     assert np.array_equal(dV0[sel].cpu().numpy(), want_dV)
     assert float(np.abs(dW0[sel].cpu().numpy() - want_dW).max() / np.abs(want_dW).max()) <= 1e-5
+
+
+def test_wide_row_kernels_beside_the_wide_mfma_producer(gpu):
+    """The same for the LRA widths (reference ListOps: N = 2000, 128 channels, E = 512, hidden 128 —
+    LRA/psf_training_config.py:2-30): the per-step forward kernel, the one-launch chain (chord_chain_lds_k) and the two-kernel
+    backward step (chord_dv_win_k + chord_dw_chunk_k) on stream A while the wide producer GEMMs (x3_gemm_k, mlp_wide.hip:
+    split-bf16 MFMA, LDS-DMA ring) run on stream B. Every result bit-equal to its solo run; the chain bit-equal to the oracle."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import fused_mlp
+    from sparsefactorization_amd.psfnet import MLPBlock
+    B, N, L, C, E, M = 8, 2000, 12, 128, 512, 11
+    g = torch.Generator(device=gpu).manual_seed(21)
+    Ws = [0.2 * torch.randn(B, N, L, device=gpu, generator=g) for _ in range(M)]
+    V0 = torch.randn(B, N, C, device=gpu, generator=g)
+    dZ = torch.randn(B, N, C, device=gpu, generator=g)
+    torch.manual_seed(5)
+    blocks = [MLPBlock([128, 'GELU'], E, C).to(gpu)] + [MLPBlock([128, 'GELU'], E, L).to(gpu) for _ in range(M)]
+    x = torch.randn(16, N, E, device=gpu, generator=g)
+    assert fused_mlp.wide_ok(x, blocks)
+
+    def chord_work():
+        with torch.no_grad():
+            one_launch = sfa.chord_chain(Ws, V0, False)            # inference: chord_chain_lds_k
+            sfa.set_tuning("chain_fused", 0)
+            try:
+                per_step = sfa.chord_chain(Ws, V0, False)          # what training runs: M per-step kernels
+            finally:
+                sfa.set_tuning("chain_fused", 1)
+        Wr, Vr = Ws[0].clone().requires_grad_(True), V0.clone().requires_grad_(True)
+        sfa.chord_spmm(Wr, Vr).backward(dZ)                        # wide rows: dV and dW as two kernels
+        return one_launch, per_step, Wr.grad, Vr.grad
+
+    def producer_work():
+        with torch.no_grad():
+            return fused_mlp.wide_apply(x, blocks)
+
+    solo = chord_work()
+    solo_y = producer_work()
+    torch.cuda.synchronize()
+    assert torch.equal(solo[0], solo[1])  # the one-launch chain and the per-step kernels: the same bits
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    sA.wait_stream(torch.cuda.current_stream())
+    sB.wait_stream(torch.cuda.current_stream())
+    bad = {sA: torch.zeros((), dtype=torch.int64, device=gpu), sB: torch.zeros((), dtype=torch.int64, device=gpu)}
+    for r in range(ROUNDS + 1):
+        for s in ((sB, sA) if r % 2 == 0 else (sA, sB)):
+            with torch.cuda.stream(s):
+                if s is sB:
+                    for _ in range(2):
+                        ys = producer_work()
+                        for y, y0 in zip(ys, solo_y):
+                            bad[sB] += (y != y0).sum()
+                        del ys
+                else:
+                    for _ in range(4):
+                        got = chord_work()
+                        for a, b in zip(got, solo):
+                            bad[sA] += (a != b).sum()
+                        del got
+        da, db = torch.cuda.Event(), torch.cuda.Event()
+        da.record(sA)
+        db.record(sB)
+        sA.wait_event(db)
+        sB.wait_event(da)
+    torch.cuda.synchronize()
+    assert int(bad[sA]) == 0, f"{int(bad[sA])} elements of the wide-row chord kernels differ from the solo run"
+    assert int(bad[sB]) == 0, f"{int(bad[sB])} producer outputs differ from the solo run"
+    rows, cols = oc.chord_indices(N, L)
+    want = oc.chain(np.stack([rows, cols]), np.stack([w[:2].cpu().numpy() for w in Ws]), V0[:2].cpu().numpy(), False)[-1]
+    assert np.array_equal(solo[0][:2].cpu().numpy(), want)
