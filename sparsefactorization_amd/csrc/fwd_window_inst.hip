@@ -73,6 +73,9 @@ hipError_t launch_fwd_win(int rows, int L, const FwdWinArgs& a) {
   static_assert(kWinLmin == 4 && kWinLmax == 20, "keep the PSF_CASE list in step with kWinLmin/kWinLmax");
   static_assert(win_pair_compiled(TGS, NT), "not a compiled (TGS, NT) pair");
   if (rows == 2) return launch_L<TGS, 2, NT>(L, a);  // (the only compiled rows per thread: fwd_window_launch.h)
+  if constexpr (win_rows4_compiled(TGS, NT)) {
+    if (rows == 4) return launch_L<TGS, 4, NT>(L, a);
+  }
   return hipErrorInvalidValue;
 }
 

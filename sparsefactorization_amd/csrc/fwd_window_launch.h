@@ -50,5 +50,16 @@ hipError_t launch_fwd_win(int rows, int L, const FwdWinArgs& a);
 
 // window geometry for a (TGS, rows, NT) triple — mirrors FwdWinCfg
 inline int win_tile_rows(int tgs, int rows, int nt) { return (nt >> tgs) * rows; }
+// Four rows per thread (forward only): the (TGS, NT) pairs it is compiled for — rows of 16, 32 and 64 channels on 256-thread
+// workgroups (tiles of 256 / 128 / 64 rows: one far link fewer than with two rows per thread). Round 6, chains that keep every
+// step, W rotating beyond the Infinity Cache (profiles/r06j_fwd_rows_sweep.log, us per step, two rows / four): C = 16 x 16384:
+// 41.7 / 39.3; C = 32 x 16384 (genome): 22.6 / 21.9; x 4096: 11.0 / 10.8; x 1024 (Pathfinder): 6.34 / 6.20; C = 64 x 16384: 23.3 /
+// 22.2 — and the other way round at 8 channels (25.8 / 27.1: 62 KB of LDS per 512-row tile) and a wash at 128 (44.6 / 44.1): not
+// compiled there. (A lab build widens the range: PSF_HIPCC_EXTRA="-DPSF_ROWS4_TGS_MIN=1 -DPSF_ROWS4_TGS_MAX=5".)
+#ifndef PSF_ROWS4_TGS_MIN
+#define PSF_ROWS4_TGS_MIN 2
+#define PSF_ROWS4_TGS_MAX 4
+#endif
+constexpr bool win_rows4_compiled(int tgs, int nt) { return nt == 256 && tgs >= PSF_ROWS4_TGS_MIN && tgs <= PSF_ROWS4_TGS_MAX; }
 
 }  // namespace psf

@@ -64,6 +64,7 @@ std::atomic<int> g_bwd_fused_wg_limit{0};  // fused backward step: 0 = whatever 
 // Per-step launches of a chain: 1 = alternate the direction in which each XCD walks its tile range
 std::atomic<int> g_chain_zigzag{1};
 std::atomic<int> g_bwd_fronts{0};     // fused backward step: interleaved fronts per batch element, 0 = auto (2 from N = 8192 on), 1, 2, 4, 8
+std::atomic<int> g_fwd_rows{0};       // forward window kernel, rows per thread: 0 = auto, 2, 4 (4: where compiled, fwd_window_launch.h)
 std::atomic<int> g_bwd_ablate{0};      // fused backward step, -DPSF_BWD_ABLATE_LAB builds only (bwd_fused.h: ABL); ignored otherwise
 std::atomic<int> g_mixer_ablate{0};    // timing experiments on that kernel: bit 0 no MLP arithmetic, 1 no multiply-add chain, 2 no far rows, 3 no data rows
 std::atomic<int> g_mixer_lds{1};       // psf_mixer_fwd_*: 1 = short sequences take the single-launch LDS-resident mixer (mixer_lds.h)
@@ -99,6 +100,7 @@ Knob g_knobs[] = {
     {"mixer_ablate", &g_mixer_ablate, 0, 15},
     {"bwd_ablate", &g_bwd_ablate, 0, 1023},
     {"bwd_fronts", &g_bwd_fronts, 0, 8},
+    {"fwd_rows", &g_fwd_rows, 0, 4},
     {"chain_fused", &g_chain_fused, 0, 2},
     {"chain_cc", &g_chain_cc, 0, 1},
     {"mlp_variant", &psf_g_mlp_variant, 0, 3},
@@ -110,7 +112,7 @@ Knob g_knobs[] = {
 // odd steps) travels in it too instead of in thread-local state.
 struct Tuning {
   int fwd_variant, bwd_variant, xcd_remap, fwd_split, dv_threads, bwd_fused, dw_variant,
-      dw_tgs, chain_fused, chain_cc, fwd_wide, fwd_wg_limit, bwd_fused_wg_limit, chain_zigzag, mixer_wg_limit, mixer_ablate, mixer_lds, bwd_ablate, bwd_fronts;
+      dw_tgs, chain_fused, chain_cc, fwd_wide, fwd_wg_limit, bwd_fused_wg_limit, chain_zigzag, mixer_wg_limit, mixer_ablate, mixer_lds, bwd_ablate, bwd_fronts, fwd_rows;
   bool walk_backwards;
 };
 
@@ -125,6 +127,7 @@ Tuning snapshot() {
   t.mixer_wg_limit = g_mixer_wg_limit.load(), t.mixer_ablate = g_mixer_ablate.load(), t.mixer_lds = g_mixer_lds.load();
   t.bwd_ablate = g_bwd_ablate.load();
   t.bwd_fronts = g_bwd_fronts.load();
+  t.fwd_rows = g_fwd_rows.load();
   t.walk_backwards = false;
   return t;
 }
@@ -408,6 +411,13 @@ bool pick_window(const Tuning& tn, const void* W, int64_t B, int64_t N, int32_t 
   } else if (nt_pref == kDvMidThreads && tgs <= kDvMidTgsMax && N >= 2 * (int64_t)win_tile_rows(tgs, 1, kDvMidThreads)) {
     nt = kDvMidThreads;  // dV: 512 threads x 1 row
     rows = 1;
+  }
+  // Forward, rows of 16..64 channels: four rows per thread (fwd_window_launch.h: win_rows4_compiled) where the four-row tile
+  // divides N, i.e. where its launches take the aligned request form; the per-lane form of other lengths (2^k + 1: LRA's
+  // CLS-token column) is faster on the smaller tile (N = 4097 x 32: 11.3 / 12.1 us, N = 1025: 6.9 / 7.2, two rows / four:
+  // profiles/r06k_fwd_rows_product.log).
+  if (forward && win_rows4_compiled(tgs, nt) && tn.fwd_rows != 2 && N >= 2 * (int64_t)win_tile_rows(tgs, 4, nt)) {
+    if (tn.fwd_rows == 4 || N % win_tile_rows(tgs, 4, nt) == 0) rows = 4;
   }
   const int TR = win_tile_rows(tgs, rows, nt);
   if (N < 2 * (int64_t)TR) return false;  // the window may wrap at most once

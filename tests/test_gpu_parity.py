@@ -924,3 +924,28 @@ def test_fused_backward_fronts_only_reorder_workgroups(gpu, B, N, L, C):
     want_dW, want_dV = oc.spmul_bwd(dZ.cpu().numpy(), W.cpu().numpy(), V.cpu().numpy())
     assert np.array_equal(got[0][1].cpu().numpy(), want_dV)
     assert rel_inf(got[0][0].cpu().numpy(), want_dW) <= TOL
+
+
+@pytest.mark.parametrize("B,N,L,C,res", [(2, 16384, 15, 32, False), (3, 4096, 13, 16, True), (2, 2048, 12, 64, False),
+                                         (2, 4097, 13, 32, True), (3, 1024, 11, 16, False)])
+def test_forward_rows_per_thread_is_a_launch_choice_only(gpu, B, N, L, C, res):
+    """Knob "fwd_rows" (round 6): rows of 16..64 channels run four rows per thread where the four-row tile divides N. Two or
+    four rows per thread, forced or automatic, full tiles or the ragged 2^k + 1 length: the same bits, the oracle's
+    (forward_kernel, spmul_cuda.cu:20-27; residual SyntheticExperiments/psf.py:187-188)."""
+    import sparsefactorization_amd as sfa
+    g = torch.Generator(device=gpu).manual_seed(N + C)
+    W = 0.3 * torch.randn(B, N, L, device=gpu, generator=g)
+    V = torch.randn(B, N, C, device=gpu, generator=g)
+    R = torch.randn(B, N, C, device=gpu, generator=g) if res else None
+    got = {}
+    try:
+        for rows in (0, 2, 4):
+            sfa.set_tuning("fwd_rows", rows)
+            got[rows] = sfa.chord_spmm(W, V, R)
+    finally:
+        sfa.set_tuning("fwd_rows", 0)
+    assert torch.equal(got[2], got[0]) and torch.equal(got[4], got[0])
+    want = oc.spmul_fwd(W.cpu().numpy(), V.cpu().numpy())
+    if res:
+        want = want + R.cpu().numpy()
+    assert np.array_equal(got[0].cpu().numpy(), want)
