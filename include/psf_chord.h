@@ -442,8 +442,8 @@ int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float
  *                      Round-4 kernel, rotating operands: 42.3 (what fits) / 40.9 (three) us at Order B = 40, 12.6 / 13.5 on
  *                      2048 tiles
  *   key "fwd_rows"   : LDS-window forward kernel, rows per thread: 0 = automatic (default): four for rows of 16..64 channels on
- *                      256-thread workgroups where the four-row tile divides N (one far link fewer: 2-6 % per step), two
- *                      otherwise; 2 / 4 = that many where compiled
+ *                      256-thread workgroups from N = 4096 on where the four-row tile divides N (one far link fewer: 2-6 %
+ *                      per step), two otherwise; 2 / 4 = that many where compiled
  *   key "bwd_fronts" : fused backward step (full tiles): 0 = automatic (default): from N = 8192 on every XCD walks the tiles of
  *                      a batch element as TWO interleaved fronts half a sequence apart (the rows the longest link joins are
  *                      then in flight together: Order shape 41.1 -> 39.2 us per step); 1 = one front; 2, 4, 8 = that many

@@ -17,7 +17,7 @@ if len(sys.argv) > 1:
 for B, N, L, C in SHAPES:
     M = L - 1
     g = torch.Generator(device=dev).manual_seed(1)
-    sets = max(2, min(12, int(640e6 // (M * 4 * B * N * L))))
+    sets = 1 if os.environ.get("PSF_SWEEP_RESIDENT") else max(2, min(12, int(640e6 // (M * 4 * B * N * L))))  # PSF_SWEEP_RESIDENT=1: one operand set (cache-resident: what a small model's step sees)
     Wsets = [[0.1 * torch.randn(B, N, L, device=dev, generator=g) for _ in range(M)] for _ in range(sets)]
     V0 = torch.randn(B, N, C, device=dev, generator=g)
     res = C <= 8

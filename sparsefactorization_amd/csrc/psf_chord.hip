@@ -415,9 +415,12 @@ bool pick_window(const Tuning& tn, const void* W, int64_t B, int64_t N, int32_t 
   // Forward, rows of 16..64 channels: four rows per thread (fwd_window_launch.h: win_rows4_compiled) where the four-row tile
   // divides N, i.e. where its launches take the aligned request form; the per-lane form of other lengths (2^k + 1: LRA's
   // CLS-token column) is faster on the smaller tile (N = 4097 x 32: 11.3 / 12.1 us, N = 1025: 6.9 / 7.2, two rows / four:
-  // profiles/r06k_fwd_rows_product.log).
+  // profiles/r06k_fwd_rows_product.log). From N = 4096 on: below that the two forms are within 3 % of each other and the sign
+  // depends on how the step is driven (Pathfinder's shape, N = 1024 x 32: 6.32 / 6.13 us per step inside a chain, but 5.82 /
+  // 6.39 us per launch for the same step launched alone again and again under rocprofv3: r06m_fwd_rows_resident.log,
+  // r06z_bwd_summary.md of both collections).
   if (forward && win_rows4_compiled(tgs, nt) && tn.fwd_rows != 2 && N >= 2 * (int64_t)win_tile_rows(tgs, 4, nt)) {
-    if (tn.fwd_rows == 4 || N % win_tile_rows(tgs, 4, nt) == 0) rows = 4;
+    if (tn.fwd_rows == 4 || (N >= 4096 && N % win_tile_rows(tgs, 4, nt) == 0)) rows = 4;
   }
   const int TR = win_tile_rows(tgs, rows, nt);
   if (N < 2 * (int64_t)TR) return false;  // the window may wrap at most once
