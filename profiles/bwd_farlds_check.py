@@ -1,4 +1,4 @@
-import sys, os, torch
+import sys, torch
 sys.path.insert(0, "/root/repo")
 import sparsefactorization_amd as sfa
 from sparsefactorization_amd import chord

@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .fused_mlp import _needs_grad, _params_of, _ptrs, _two_layer
+from .fused_mlp import _needs_grad, _ptrs, _two_layer
 
 enabled = True  # module-level switch (tests / A-B timing)
 #: "auto": take the fused path where it is measured faster than psf_mlp_fwd_f32 + psf_chord_chain_fwd_f32 end to end
