@@ -456,3 +456,18 @@ def test_fused_mixer_handoff_is_per_thread_and_uncovered_blocks_raise():
     with pytest.raises(ValueError, match="does not cover these blocks"):
         fused_mixer.mixer_forward(torch.zeros(1, 64, 32), g, odd, True)
     assert getattr(fused_mixer._handoff, "pending", None) is None
+
+
+def test_interleaved_fronts_visit_every_tile_once():
+    """Geom::ileave (csrc/psf_common.h: decode_block; knob "bwd_fronts"): position t of an XCD's walk through a batch element
+    is row block (t mod 2^s) * tiles / 2^s + t / 2^s. Restated here: for every tile count the host accepts (2^s | tiles) the
+    map is a bijection, consecutive positions are tiles / 2^s apart (the fronts) and each front advances one tile per 2^s
+    positions — speed only, never correctness; the GPU test test_fused_backward_fronts_only_reorder_workgroups checks the bits."""
+    for s in (1, 2, 3):
+        for tiles in (1 << s, 2 << s, 6 << s, 64, 128, 512, 1000 << s):
+            if tiles % (1 << s):
+                continue
+            walk = [(t & ((1 << s) - 1)) * (tiles >> s) + (t >> s) for t in range(tiles)]
+            assert sorted(walk) == list(range(tiles))
+            assert walk[1] - walk[0] == tiles >> s
+            assert walk[1 << s] == 1
