@@ -870,7 +870,8 @@ def shapes_leg(device):
                     t_brot = timed(bwd_rot, max(40, 2 * bsets))
                     bwd_bytes = 4 * B * N * (2 * L + 3 * C)
                     entry["bwd_bytes_per_step"] = bwd_bytes
-                    bwd = {"kernel": "chord_bwd_fused_k" if C <= 32 else "chord_dv_win_k + chord_dw_chunk_k (two launches per step)",
+                    fused_bwd = C <= 64 or (C == 128 and N <= 4096)  # psf_chord.hip: fused_step_width
+                    bwd = {"kernel": "chord_bwd_fused_k" if fused_bwd else "chord_dv_win_k + chord_dw_chunk_k (two launches per step)",
                            "what": "one backward step, both gradients; rotating: W, V, dW new every launch, dZ = the dV of the launch before",
                            "us_per_step_cache_resident": t_bwd,
                            "frac_of_hbm_peak_cache_resident": bwd_bytes / (t_bwd * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -880,7 +881,7 @@ def shapes_leg(device):
                     bc = _counter_traffic(pmc, pkey, "chord_bwd_fused", bwd_bytes)
                     if bc is None:  # wide rows: two kernels per step — the dV kernel's counters, against its own bytes
                         bc = _counter_traffic(pmc, pkey, "chord_dv_", 4 * B * N * (L + 2 * C))
-                    if bc is not None and C <= 32:
+                    if bc is not None and fused_bwd and "fused" in bc["kernel"]:
                         bwd["kernel"] = bc["kernel"]
                     entry["bwd_step_kernel"] = _with_roof(bwd, bc)
                     del Vs, dWs, zz, flatW

@@ -411,8 +411,8 @@ int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float
  *                      kernel or PSF_E_TUNING where it does not apply
  *   key "dw_tgs"     : chunk-looping dW, lanes per row chunk: 0 = auto (8; 16 when that spares a ragged tile), 4 = 8, 5 = 16
  *   key "dv_threads" : dV window kernel: 0 = auto (512 threads x 1 row for C <= 8, else 256 threads x 2 rows), 1 = 256 threads
- *   key "bwd_fused"  : a backward step that wants both dW and dV: 1 (default) = ONE fused kernel for rows of C = 4, 8, 16 or
- *                      32 channels and sequences of at least two tiles — the dZ window staged once serves both gradients:
+ *   key "bwd_fused"  : a backward step that wants both dW and dV: 1 (default) = ONE fused kernel for rows of C = 4, 8, 16, 32 or
+ *                      64 channels (128 up to N = 4096) and sequences of at least two tiles — the dZ window staged once serves both gradients:
  *                      the aligned instance (N and the far offsets multiples of the tile, 16-byte-aligned chunk-clean
  *                      buffers: row-block addresses on the scalar unit) or else the general one (any N — N = 2^k + 1 with a
  *                      CLS token —, any far offsets, W / dW at any alignment); 2 = the aligned instance or the two kernels;

@@ -102,7 +102,7 @@ def _unit_table():
         units.append((os.path.join(OBJ_DIR, f"fwd_mlp_step_tgs{t}.o"), os.path.join(CSRC, "fwd_mlp_step_inst.hip"),
                       [f"-DPSF_TGS={t}", *os.environ.get("PSF_MLP_STEP_EXTRA", "").split()]))
     # dV at 512 threads x 1 row per thread for narrow rows (bwd_window_launch.h: kDvMidThreads, kDvMidTgsMax)
-    for t in range(4):
+    for t in range(6):
         units.append((os.path.join(OBJ_DIR, f"bwd_window_mid_tgs{t}.o"), os.path.join(CSRC, "bwd_window_inst.hip"),
                       [f"-DPSF_TGS={t}", "-DPSF_NT=512"]))
     # wide-row configuration (fwd_window_launch.h: kWideTgs, kWideThreads)

@@ -37,7 +37,7 @@ hipError_t launch_dw_chunk(int L, const BwdWinArgs& a);
 // (profiles/dvlab.hip): 28.65 vs 29.05 us at cfg2 next to the shipped kernel's 30.07.
 constexpr int kDvMidThreads = 512, kDvMidTgsMax = 1;  // rows of <= 8 channels, where it is the automatic choice (the instances
                                                        // for 16 and 32 channels were reachable by knob only: removed in round 5)
-constexpr int kFusedTgsMax = 3;                        // fused step: rows of <= 32 channels
+constexpr int kFusedTgsMax = 5;                        // fused step: rows of <= 128 channels (psf_chord.hip: fused_step_width)
 constexpr bool dv_pair_compiled(int tgs, int nt) {
   return win_pair_compiled(tgs, nt) || (nt == kDvMidThreads && tgs >= 0 && tgs <= kDvMidTgsMax);
 }

@@ -258,6 +258,8 @@ hipError_t launch_fused_step(int tgs, int L, const BwdWinArgs& a) {
     case 1: return launch_bwd_fused<1>(L, a);
     case 2: return launch_bwd_fused<2>(L, a);
     case 3: return launch_bwd_fused<3>(L, a);
+    case 4: return launch_bwd_fused<4>(L, a);
+    case 5: return launch_bwd_fused<5>(L, a);
     default: return hipErrorInvalidValue;
   }
 }
@@ -268,18 +270,28 @@ hipError_t launch_fused_edge_step(int tgs, int L, const BwdWinArgs& a) {
     case 1: return launch_bwd_fused_edge<1>(L, a);
     case 2: return launch_bwd_fused_edge<2>(L, a);
     case 3: return launch_bwd_fused_edge<3>(L, a);
+    case 4: return launch_bwd_fused_edge<4>(L, a);
+    case 5: return launch_bwd_fused_edge<5>(L, a);
     default: return hipErrorInvalidValue;
   }
 }
 
+// Row widths the fused backward step takes: exactly 4 << tgs channels with a whole row inside one workgroup. Rounds 3-5: up
+// to 32 channels. Round 6 (profiles/r06p_bwd_fused_wide*.log, us per step, two kernels / fused, operands rotating, dZ chained):
+// 64 channels at every length — N = 1024: 11.3 / 8.9; 2000: 20.2 / 15.3; 2048: 21.6 / 17.4; 2049 (edge instance): 23.6 / 18.8;
+// 4096: 42.8 / 38.3; 4097: 23.8 / 18.7; 8192: 43.7 / 42.9; 16384: 49.3 / 47.2 — and 128 channels up to N = 4096 — ListOps'
+// N = 2000: 39.3 / 35.4; 2001: 40.1 / 36.9; 1024, 4096, 4097 equal — but not beyond (N = 16384: 96.3 / 102.8: tiles of 8 rows).
+bool fused_step_width(int64_t C, int64_t N) {
+  return C == 4 || C == 8 || C == 16 || C == 32 || C == 64 || (C == 128 && N <= 4096);
+}
+
 // The EDGE instance of the fused step (bwd_fused.h: chord_bwd_fused_edge_k) takes what pick_fused_step turns away for its
-// geometry: any N >= two tiles (N = 2^k + 1 with a CLS token), any far offsets, W / dW at any alignment. Same rows (C = 4 << tgs,
-// tgs <= 3), chord near offsets, 16-byte aligned row operands. Knob bwd_fused = 2 keeps its meaning (the aligned instance or
+// geometry: any N >= two tiles (N = 2^k + 1 with a CLS token), any far offsets, W / dW at any alignment. Same rows (fused_step_width), chord near offsets, 16-byte aligned row operands. Knob bwd_fused = 2 keeps its meaning (the aligned instance or
 // nothing); 1 (default) lets this one in.
 bool pick_fused_edge_step(const Tuning& tn, const void* dZ, const void* V, const void* dV, int64_t N, int32_t L, int64_t C,
                           int64_t v_bstride, const Offsets& offs, WinPick* pk) {
-  if (tn.bwd_fused != 1 || L < kWinLmin || L > kWinLmax || (C != 4 && C != 8 && C != 16 && C != 32)) return false;
-  const int tgs = C == 4 ? 0 : C == 8 ? 1 : C == 16 ? 2 : 3;
+  if (tn.bwd_fused != 1 || L < kWinLmin || L > kWinLmax || !fused_step_width(C, N)) return false;
+  const int tgs = C == 4 ? 0 : C == 8 ? 1 : C == 16 ? 2 : C == 32 ? 3 : C == 64 ? 4 : 5;
   const int nt = 256;
   const int TR = nt >> tgs;
   if (N < 2 * (int64_t)TR) return false;
@@ -295,13 +307,13 @@ bool pick_fused_edge_step(const Tuning& tn, const void* dZ, const void* V, const
   return true;
 }
 
-// The fused dV + dW step (bwd_fused.h) applies to full tiles of narrow rows: C = 4 << tgs with tgs <= 3, N a multiple of
+// The fused dV + dW step (bwd_fused.h) applies to full tiles of rows of exactly 4 << tgs channels (fused_step_width), N a multiple of
 // the tile (256 >> tgs rows) and at least two tiles, chord near offsets, everything 16-byte aligned and chunk-clean.
 bool pick_fused_step(const Tuning& tn, const void* dZ, const void* W, const void* V, const void* dW, const void* dV, int64_t B, int64_t N,
                      int32_t L, int64_t C, int64_t v_bstride, const Offsets& offs, WinPick* pk) {
   const int knob = tn.bwd_fused;
-  if (!knob || L < kWinLmin || L > kWinLmax || (C != 4 && C != 8 && C != 16 && C != 32)) return false;
-  const int tgs = C == 4 ? 0 : C == 8 ? 1 : C == 16 ? 2 : 3;
+  if (!knob || L < kWinLmin || L > kWinLmax || !fused_step_width(C, N)) return false;
+  const int tgs = C == 4 ? 0 : C == 8 ? 1 : C == 16 ? 2 : C == 32 ? 3 : C == 64 ? 4 : 5;
   const int nt = 256;
   const int TR = nt >> tgs;
   if (N % TR != 0 || N < 2 * (int64_t)TR) return false;

@@ -148,7 +148,7 @@ def test_fused_mixer_stays_inside_its_outputs(gpu, case):
     buffers banded; the result against the oracle chain fed with float64-MLP W (test_gpu_mixer's reference)."""
     import ctypes
     import test_gpu_mixer as tm
-    from sparsefactorization_amd import _lib, fused_mixer
+    from sparsefactorization_amd import _lib, fused_mixer, fused_mlp
     _, B, N, E, h, C, L, M, residual = next(c for c in tm.CASES if c[0] == case)
     g, fs = tm._blocks(E, h, C, L, M, seed=11)
     x = torch.randn(B, N, E, generator=torch.Generator().manual_seed(5))
@@ -161,7 +161,7 @@ def test_fused_mixer_stays_inside_its_outputs(gpu, case):
     assert (Mh, C2, L2) == (M, C, L)
     lib = _lib.load()
     spec = _lib.MixerInput(_lib.MIXER_IN_DATA, 0, xd.data_ptr(), None, None, None)
-    params = [p.detach().contiguous() for p in fused_mixer._params_of([g, *fs])]
+    params = [p.detach().contiguous() for p in fused_mlp._params_of([g, *fs])]
     ws_bytes = lib.psf_mixer_fwd_workspace(N, E, M, htab, C, L)
     assert ws_bytes >= 0
     ws = torch.empty(ws_bytes // 4 + 4, device=gpu)

@@ -824,7 +824,10 @@ def test_random_shapes_forward_and_backward(gpu, seed):
 
 
 FUSED_SHAPES = [(3, 16384, 15, 8), (2, 1024, 12, 32), (2, 2048, 12, 16), (5, 512, 9, 4), (2, 256, 8, 8), (1, 1536, 20, 16),
-                (2, 128, 7, 32)]
+                (2, 128, 7, 32),
+                # round 6: rows of 64 channels at every length and of 128 up to N = 4096 (LRA/psf_training_config.py:2-30: ListOps
+                # N = 2000 x 128; BASELINE configs[2]: N = 2048 x 64) — aligned instance, and 128 channels beyond 4096 (two kernels)
+                (2, 2048, 12, 64), (2, 2000, 12, 128), (1, 16384, 15, 64), (2, 4096, 13, 128), (1, 8192, 14, 128), (3, 64, 6, 64)]
 
 
 @pytest.mark.parametrize("B,N,L,C", FUSED_SHAPES)
@@ -858,7 +861,8 @@ def test_fused_backward_step_kernel(gpu, B, N, L, C):
         sfa.set_tuning("bwd_fused", 1)
 
 
-FUSED_EDGE_SHAPES = [(2, 4097, 13, 32), (2, 1025, 11, 32), (1, 16385, 15, 8), (3, 777, 9, 16), (2, 643, 10, 4), (2, 1024, 12, 32)]
+FUSED_EDGE_SHAPES = [(2, 4097, 13, 32), (2, 1025, 11, 32), (1, 16385, 15, 8), (3, 777, 9, 16), (2, 643, 10, 4), (2, 1024, 12, 32),
+                     (2, 2049, 13, 64), (2, 2001, 12, 128), (2, 4097, 13, 64), (2, 1024, 11, 64), (3, 515, 9, 128)]  # round 6: wide rows
 
 
 @pytest.mark.parametrize("B,N,L,C", FUSED_EDGE_SHAPES)
@@ -873,7 +877,7 @@ def test_fused_backward_step_general_instance(gpu, B, N, L, C):
     off = None
     if N % 64 == 0:  # aligned length: make the far offsets odd so that only the general instance applies
         KN = 2
-        t = 256 >> {4: 0, 8: 1, 16: 2, 32: 3}[C]
+        t = 256 >> {4: 0, 8: 1, 16: 2, 32: 3, 64: 4, 128: 5}[C]
         while t > 1:
             KN, t = KN + 1, t >> 1
         KN = min(KN, L)
