@@ -9,7 +9,7 @@ import sparsefactorization_amd as sfa  # noqa: E402
 from sparsefactorization_amd import chord  # noqa: E402
 
 dev = torch.device("cuda:0")
-SHAPES = [(16, 16384, 15, 32), (32, 4096, 13, 32), (64, 1024, 12, 32), (64, 16384, 15, 16), (32, 1024, 11, 16), (64, 16384, 15, 32)]
+SHAPES = [(16, 16384, 15, 32), (32, 4096, 13, 32), (64, 1024, 12, 32), (64, 16384, 15, 16), (32, 1024, 11, 16), (64, 16384, 15, 32)]  # (wide rows: pass BxNxLxC)
 if len(sys.argv) > 1:
     SHAPES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
 for B, N, L, C in SHAPES:

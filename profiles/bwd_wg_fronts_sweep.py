@@ -9,7 +9,8 @@ import sparsefactorization_amd as sfa  # noqa: E402
 from sparsefactorization_amd import chord  # noqa: E402
 
 dev = torch.device("cuda:0")
-for B, N, L, C in ((40, 16384, 15, 8), (64, 16384, 15, 8), (16, 16384, 15, 32)):
+SHAPES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(40, 16384, 15, 8), (64, 16384, 15, 8), (16, 16384, 15, 32)]
+for B, N, L, C in SHAPES:
     g = torch.Generator(device=dev).manual_seed(0)
     sets = 10
     Ws = [0.1 * torch.randn(B, N, L, device=dev, generator=g) for _ in range(sets)]
@@ -32,7 +33,7 @@ for B, N, L, C in ((40, 16384, 15, 8), (64, 16384, 15, 8), (16, 16384, 15, 32)):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / steps * 1e3
 
-    arms = [(wg, fr) for wg in (2, 3, 4, 5) for fr in (1, 2)]
+    arms = [(wg, fr) for wg in (0, 2, 3, 4, 5) for fr in (1, 2)]  # wg 0 = the automatic rule
     reading(0, 0, 200)
     times = {a: [] for a in arms}
     for rnd in range(5):

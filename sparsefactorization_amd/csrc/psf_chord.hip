@@ -600,7 +600,11 @@ int bwd_impl(const Tuning& tn, const T* dZ, const T* W, const T* V, T* dW, T* dV
         // Workgroups per CU, re-measured on the round-4 kernel with rotating operands (profiles/r04am_bwd_fused_wg_sweep.log, us per
         // step, what fits / three): 5120 tiles (N = 16384, C = 8, B = 40) 42.3 / 40.9; 8192 tiles (C = 32, B = 16) 51.0 / 49.6; 4096
         // tiles (N = 4096, C = 16, B = 64) 26.6 / 25.4; 2048 tiles 12.6 / 13.5 and 14.7 / 15.0: three from 4096 tiles on.
-        a.wg_per_cu = tn.bwd_fused_wg_limit ? tn.bwd_fused_wg_limit : (B * (int64_t)pk.tiles_full >= 4096 ? 3 : 0);
+        // Rows of 64 / 128 channels (round 6, tiles of 16 / 8 rows; profiles/r06r_bwd_rows_wide.log, what fits / three / four):
+        // N = 2048 x 64, B = 32: 17.4 / 17.3 / 15.9; N = 4096 x 64, B = 16: 17.4 / 17.3 / 16.3; N = 2000 x 128: 35.5 / 35.6 / 34.8;
+        // N = 16384 x 64: 47.0 / 47.1 / 47.5 — four from 4096 tiles on.
+        a.wg_per_cu = tn.bwd_fused_wg_limit ? tn.bwd_fused_wg_limit
+                                            : (B * (int64_t)pk.tiles_full >= 4096 ? (pk.tgs >= 4 ? 4 : 3) : 0);
         a.ablate = tn.bwd_ablate;
         if (int rc = make_geom(tn, B, N, L, C, 4, pk.tgs, pk.TR, false, v_batch_stride, 0, pk.tiles_full, &a.gm)) return rc;
         // Two interleaved fronts per batch element (Geom::ileave, bwd_fused.h): tile t of the XCD's walk is row block
