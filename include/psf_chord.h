@@ -425,9 +425,9 @@ int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float
  *                      always
  *   key "chain_fused": 1 (default) = psf_chord_chain_fwd_f32 runs short sequences (N <= 2112, L <= 20, C % 4 == 0) as ONE
  *                      launch with the sequence resident in LDS: always when at most two step results are kept (inference
- *                      with alternating buffers), and when every step is kept (training) for sequences of at most 33792
- *                      elements shared by at most 8 workgroups; 0 = always M per-step launches; 2 = the single launch
- *                      wherever it fits
+ *                      with alternating buffers), and when every step is kept (training) for sequences of at most 65536
+ *                      elements (131072 for N <= 1024); 0 = always M per-step launches; 2 = the single launch wherever it
+ *                      fits. The workgroups of a sequence share an XCD (knob "xcd_remap").
  *   key "fwd_wg_limit": LDS-window forward kernel, workgroups per CU: 0 = auto (3 for rows of <= 8 channels on
  *                      launches of >= 4096 tiles, else unlimited), 1 = unlimited, 2..4 = that many
  *   key "chain_zigzag": per-step launches of psf_chord_chain_fwd_*: 1 = every XCD walks its tile range forwards on

@@ -31,6 +31,7 @@ struct ChainArgs {
   uint64_t store_mask;
   int64_t v0_bstride;
   int32_t M, N, C, CG, chunks;     // CG = C / 4 channel groups, chunks = ceil(CG / CC) workgroups per sequence
+  int32_t xcd_remap;               // 1: consecutive logical workgroups share an XCD (knob "xcd_remap")
 };
 
 template <int L>
@@ -57,8 +58,16 @@ chord_chain_lds_k(const ChainArgs a, const Offsets offs) {
   const int g = tid & (CC - 1);
   const int rs = tid / CC;
   const int RSN = blockDim.x / CC;
-  const int b = blockIdx.x / a.chunks;
-  const int chunk = blockIdx.x - b * a.chunks;
+  // The `chunks` workgroups of a sequence all stream the sequence's W: consecutive LOGICAL ids, which the XCD-aware map puts on
+  // ONE XCD (hardware deals blockIdx.x round-robin over the eight XCDs), so that W crosses the fabric once per sequence and the
+  // other chunks' reads hit that XCD's L2. Bijective for any grid (psf_common.h: logical_block).
+  uint32_t lb = blockIdx.x;
+  if (a.xcd_remap) {
+    const uint32_t nb = gridDim.x, xq = nb / kXcds, xr = nb % kXcds, xcd = lb % kXcds, idx = lb / kXcds;
+    lb = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + idx;
+  }
+  const int b = (int)(lb / (uint32_t)a.chunks);
+  const int chunk = (int)(lb - (uint32_t)b * (uint32_t)a.chunks);
   const int cg = chunk * CC + g;
   const bool cg_ok = cg < a.CG;
   const int cgc = cg_ok ? cg : a.CG - 1;

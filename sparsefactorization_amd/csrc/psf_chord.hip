@@ -722,6 +722,12 @@ int chain_impl(Tuning tn, const T* const* W_steps, const T* V0, T* const* out_st
     // included — N = 2000, C = 128: 18.6 / 15.1; N = 1024, C = 1024: 20.1 / 10.4; N = 2048, C = 64: 9.0 / 8.4 — and when every
     // step is kept (training) it loses from 65536 elements per sequence on — N = 2048, C = 32: 6.9 / 10.3; C = 64: 10.2 / 17.2 —
     // and wins below — N = 1024, C = 32: 7.1 / 5.6; N = 2048, C = 8: 6.9 / 4.3.
+    // Round 6: the workgroups of a sequence now share an XCD (fwd_chain_lds.h: W crosses the fabric once per sequence) — one
+    // launch, blockIdx order / XCD-aware, us per step-equivalent (profiles/r06u_chain_lds_xcd.log): N = 2000 x 128: 17.3 / 13.4;
+    // N = 2048 x 64: 9.5 / 6.8; Pathfinder 1024 x 32: 3.4 / 2.6; attention map 1024 x 1024: 9.8 / 8.9. With every step kept
+    // (training) it now wins up to 65 536 elements per sequence and, for N <= 1024, up to 131 072 (per step / one launch,
+    // r06u_chain_keep_sweep.log): 2048 x 32: 6.9 / 5.8; 1024 x 64: 6.7 / 4.0; 1024 x 128: 9.2 / 7.8; but 2048 x 64: 9.8 / 11.0;
+    // 2000 x 64: 10.5 / 10.8; 2000 x 128: 20.9 / 23.2.
     const int cf = tn.chain_fused;
     int kept = 0;  // step results that reach memory
     for (int m = 0; m < M; ++m) {
@@ -731,7 +737,7 @@ int chain_impl(Tuning tn, const T* const* W_steps, const T* V0, T* const* out_st
     }
     const bool few_kept = kept <= 2;
     bool ok = cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, tn.chain_cc) &&
-              (cf == 2 || few_kept || (plan.chunks <= 8 && N * C <= 33792)) &&
+              (cf == 2 || few_kept || N * C <= 65536 || (N <= 1024 && N * C <= 131072)) &&
               aligned_to(V0, 16) && B * (int64_t)plan.chunks <= 0x7fffffff;
     for (int m = 0; ok && m < M; ++m) ok = aligned_to(W_steps[m], 4) && aligned_to(out_steps[m], 16);
     if (ok) {
@@ -756,6 +762,7 @@ int chain_impl(Tuning tn, const T* const* W_steps, const T* V0, T* const* out_st
       a.C = (int32_t)C;
       a.CG = (int32_t)(C / 4);
       a.chunks = plan.chunks;
+      a.xcd_remap = tn.xcd_remap && plan.chunks > 1 ? 1 : 0;  // (one workgroup per sequence shares nothing with its neighbours)
       Offsets offs;
       make_offsets(N, L, offsets, &offs);
       hipError_t e = launch_chain_lds(plan, L, use_residual != 0, a, offs, (int)B, reinterpret_cast<hipStream_t>(stream));
