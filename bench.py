@@ -752,6 +752,7 @@ def _with_roof(entry, counters):
         # (every request priced at a full 128-byte line, so the rate is an upper estimate — 4-byte far-W loads and partial
         # lines move less — and a fraction above 1 reads "at the roof"; the roof is the guide's range, low end .. high end)
         entry["l2_request_bytes_assumed"] = L2_REQUEST_BYTES
+        entry["l2_to_cu_reading"] = "upper estimate: every request priced at a full line; > 1 of the roof reads 'at the roof'"
         entry["frac_of_l2_roof"] = [counters["l2_to_cu_GBps"] / L2_ROOF_GBS[1], counters["l2_to_cu_GBps"] / L2_ROOF_GBS[0]]
     elif toa is not None and toa > 1.1:
         entry["bound"] = "hbm (re-reads: traffic over algorithmic %.2f)" % toa
