@@ -426,14 +426,17 @@ int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float
  *   key "chain_fused": 1 (default) = psf_chord_chain_fwd_f32 runs short sequences (N <= 2112, L <= 20, C % 4 == 0) as ONE
  *                      launch with the sequence resident in LDS: always when at most two step results are kept (inference
  *                      with alternating buffers), and when every step is kept (training) for sequences of at most 65536
- *                      elements (131072 for N <= 1024); 0 = always M per-step launches; 2 = the single launch wherever it
- *                      fits. The workgroups of a sequence share an XCD (knob "xcd_remap").
+ *                      elements (131072 for N <= 1024; 524288 where the eight-channel instance of "chain_cc" runs);
+ *                      0 = always M per-step launches; 2 = the single launch wherever it fits. The workgroups of a
+ *                      sequence share an XCD (knob "xcd_remap").
  *   key "fwd_wg_limit": LDS-window forward kernel, workgroups per CU: 0 = auto (3 for rows of <= 8 channels on
  *                      launches of >= 4096 tiles, else unlimited), 1 = unlimited, 2..4 = that many
  *   key "chain_zigzag": per-step launches of psf_chord_chain_fwd_*: 1 = every XCD walks its tile range forwards on
  *                      even steps and backwards on odd ones, so a launch starts on the tiles whose inputs the
  *                      previous launch wrote last (default); 0 = always forwards
- *   key "chain_cc"   : fused chain: 0 = auto channel groups per workgroup (default), 1 = one
+ *   key "chain_cc"   : fused chain: channel groups (of 4 channels) per workgroup: 0 = automatic (default): two when the rows allow
+ *                      (N <= 1056; N <= 2048 on the one-workgroup-per-CU instance when the launch keeps >= 256 workgroups),
+ *                      1 = one, 2 = two wherever an instance exists
  *   key "mlp_variant": psf_mlp_fwd_f32: 0 = auto (default: the split-bf16 kernel for E <= 32, else the f32-MFMA
  *                      kernel), 1 = f32 MFMA with streamed weights, 2 = f32 MFMA with LDS-resident weights,
  *                      3 = split-bf16 (each f32 operand as three exact bf16 terms, six product terms: f32 accuracy)

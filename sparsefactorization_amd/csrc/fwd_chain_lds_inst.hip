@@ -21,8 +21,24 @@ hipError_t launch_one(const ChainArgs& a, const Offsets& offs, int B, int thread
   return hipGetLastError();
 }
 
+template <int L, bool RES>
+hipError_t launch_big(const ChainArgs& a, const Offsets& offs, int B, int threads, int lds_bytes, hipStream_t s) {
+  auto kern = chord_chain_lds8_k<L, RES>;
+  static std::atomic<int> raised{0};
+  if (!raised.load()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kChainBigBytes);
+    if (e != hipSuccess) return e;
+    raised.store(1);
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(B * a.chunks)), dim3(threads), lds_bytes, s, a, offs);
+  return hipGetLastError();
+}
+
 template <int L, int CC, bool RES>
 hipError_t launch_R(const ChainLdsPlan& p, const ChainArgs& a, const Offsets& offs, int B, hipStream_t s) {
+  if constexpr (CC == 2) {
+    if (p.big) return launch_big<L, RES>(a, offs, B, p.threads, p.lds_bytes, s);
+  }
   if (p.rows == 1) return launch_one<L, CC, 1, RES, 512>(a, offs, B, p.threads, p.lds_bytes, s);
   if (p.rows == 2 && p.threads <= 512) return launch_one<L, CC, 2, RES, 512>(a, offs, B, p.threads, p.lds_bytes, s);
   if (p.rows == 2) return launch_one<L, CC, 2, RES, 1024>(a, offs, B, p.threads, p.lds_bytes, s);
@@ -47,11 +63,22 @@ hipError_t launch_L(int L, bool res, const ChainLdsPlan& p, const ChainArgs& a, 
 
 }  // namespace
 
-bool plan_chain_lds(int64_t N, int64_t C, int32_t L, int32_t M, ChainLdsPlan* p, int cc_pref) {
+bool plan_chain_lds(int64_t N, int64_t C, int32_t L, int32_t M, ChainLdsPlan* p, int cc_pref, int64_t B) {
   if (L < kChainLdsLmin || L > kChainLdsLmax || M < 1 || M > kChainMaxSteps || C % 4 != 0 || N < 1) return false;
   const int64_t CG = C / 4;
   int cc = CG >= 2 ? 2 : 1;
   if (cc_pref == 1) cc = 1;
+  p->big = 0;
+  if (cc == 2 && N * 2 > kChainLdsMaxSlots && N * 2 <= kChainBigSlots &&
+      (cc_pref == 2 || (cc_pref == 0 && B * ((CG + 1) / 2) >= kChainBigMinWgs))) {
+    p->cc = 2;
+    p->rows = 2;  // a thread owns both channel groups of its two rows
+    p->threads = (int)(((N + 1) / 2 + 63) / 64 * 64);
+    p->chunks = (int)((CG + 1) / 2);
+    p->lds_bytes = kChainBigBytes;
+    p->big = 1;
+    return true;
+  }
   if (N * cc > kChainLdsMaxSlots) cc = 1;
   if (N * cc > kChainLdsMaxSlots) return false;
   const int64_t slots = N * cc;                 // (row, channel group) pairs a workgroup owns

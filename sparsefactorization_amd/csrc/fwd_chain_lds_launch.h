@@ -12,6 +12,13 @@ constexpr int kChainLdsLmin = 2, kChainLdsLmax = 20;  // compiled link counts
 constexpr int kChainLdsSlots2 = 2048;  // up to here 1 or 2 rows per thread
 constexpr int kChainLdsMaxSlots = 2112;
 constexpr int kChainLdsMaxBytes = 2 * kChainLdsMaxSlots * 16;  // two X buffers: 66 KiB, two workgroups per CU
+// The large instance (chord_chain_lds8_k): TWO channel groups per workgroup for 1057 <= N <= 2048 (128 KiB, ONE workgroup per
+// CU, a thread owns both groups of its two rows). Half as many workgroups stream a sequence's W, and that stream's L2
+// requests are what bounds the one-launch chain at these lengths (profiles/r06z_bwd_pmc.json: ListOps 124 G requests/s).
+// Taken when the launch still has >= kChainBigMinWgs workgroups.
+constexpr int kChainBigSlots = 2 * kChainBigRows;
+constexpr int kChainBigBytes = 2 * kChainBigSlots * 16;
+constexpr int kChainBigMinWgs = 256;
 
 struct ChainLdsPlan {
   int cc;       // channel groups (of 4 channels) per workgroup: 1 or 2
@@ -19,11 +26,13 @@ struct ChainLdsPlan {
   int threads;  // workgroup size (multiple of 64, <= 1024)
   int chunks;   // workgroups per sequence
   int lds_bytes;
+  int big;      // 1: chord_chain_lds8_k
 };
 
 // false when the shape does not fit the kernel (N * cc > 4096, L outside 2..20, C not a multiple of 4, ...)
-// cc_pref: 0 = automatic (2 channel groups per workgroup when the row count allows), 1 = force one
-bool plan_chain_lds(int64_t N, int64_t C, int32_t L, int32_t M, ChainLdsPlan* plan, int cc_pref = 0);
+// cc_pref: 0 = automatic (2 channel groups per workgroup when the row count allows; beyond 1056 rows when the launch
+// keeps >= kChainBigMinWgs workgroups: B sequences), 1 = force one, 2 = two wherever an instance exists
+bool plan_chain_lds(int64_t N, int64_t C, int32_t L, int32_t M, ChainLdsPlan* plan, int cc_pref = 0, int64_t B = 0);
 
 hipError_t launch_chain_lds(const ChainLdsPlan& plan, int L, bool res, const ChainArgs& args, const Offsets& offs,
                             int B, hipStream_t stream);

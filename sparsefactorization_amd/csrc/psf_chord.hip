@@ -52,7 +52,7 @@ std::atomic<int> g_bwd_fused{1};  // 0 = never, 1 = auto, 2 = wherever the fused
 std::atomic<int> g_dw_variant{0};   // dW: 0 = auto (chunk-looping kernel for C >= 32), 1 = whole-row window kernel, 2 = chunk forced
 std::atomic<int> g_dw_tgs{0};       // chunk-looping dW: 0 = auto, 4 = 8 lanes per row chunk, 5 = 16 lanes
 std::atomic<int> g_chain_fused{1};  // 1 = short sequences run the whole chain in one LDS-resident launch
-std::atomic<int> g_chain_cc{0};     // fused chain: 0 = auto channel groups per workgroup, 1 = one
+std::atomic<int> g_chain_cc{0};     // fused chain: 0 = auto channel groups per workgroup, 1 = one, 2 = two wherever it fits
 // Rows of >= 64 channels: 0 = one workgroup spans the whole row (default); 1 = 32-channel chunks on 1024-thread
 // workgroups (256-row tiles, far links 6 -> 2 at L=12); 2 = 32-channel chunks on 256-thread workgroups.
 // r01 sweep (us/launch): cfg3 C=128: 18.9 / 23.2 / 21.8; attention map C=1024: 19.2 / 20.5 / 20.9; C=64: 10.2 / 9.4 /
@@ -102,7 +102,7 @@ Knob g_knobs[] = {
     {"bwd_fronts", &g_bwd_fronts, 0, 8},
     {"fwd_rows", &g_fwd_rows, 0, 4},
     {"chain_fused", &g_chain_fused, 0, 2},
-    {"chain_cc", &g_chain_cc, 0, 1},
+    {"chain_cc", &g_chain_cc, 0, 2},
     {"mlp_variant", &psf_g_mlp_variant, 0, 3},
     {"wide_fuse", &psf_g_wide_fuse, 0, 1},
 };
@@ -728,6 +728,11 @@ int chain_impl(Tuning tn, const T* const* W_steps, const T* V0, T* const* out_st
     // (training) it now wins up to 65 536 elements per sequence and, for N <= 1024, up to 131 072 (per step / one launch,
     // r06u_chain_keep_sweep.log): 2048 x 32: 6.9 / 5.8; 1024 x 64: 6.7 / 4.0; 1024 x 128: 9.2 / 7.8; but 2048 x 64: 9.8 / 11.0;
     // 2000 x 64: 10.5 / 10.8; 2000 x 128: 20.9 / 23.2.
+    // Later in round 6: 1057 <= N <= 2048 on launches of >= 256 workgroups run chord_chain_lds8_k (two channel groups per
+    // workgroup: half the W streams). us per step, per-step launches / one group / two groups (profiles/r06v_chain_lds8_ab.log):
+    // last kept: 2000 x 128: 19.3 / 13.5 / 8.0; 2048 x 64: 8.9 / 6.8 / 4.3; every step kept: 2000 x 128: 20.9 / 23.6 / 17.2;
+    // 2048 x 64: 9.7 / 11.0 / 8.9; 2000 x 64: 10.6 / 10.8 / 8.2; 2000 x 256: 37.7 / 39.5 / 32.6 - so with that instance the one
+    // launch also takes training chains (up to the 524 288 elements per sequence measured); ListOps training step 2.507 -> 2.476 ms.
     const int cf = tn.chain_fused;
     int kept = 0;  // step results that reach memory
     for (int m = 0; m < M; ++m) {
@@ -736,8 +741,8 @@ int chain_impl(Tuning tn, const T* const* W_steps, const T* V0, T* const* out_st
       kept += later ? 0 : 1;
     }
     const bool few_kept = kept <= 2;
-    bool ok = cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, tn.chain_cc) &&
-              (cf == 2 || few_kept || N * C <= 65536 || (N <= 1024 && N * C <= 131072)) &&
+    bool ok = cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, tn.chain_cc, B) &&
+              (cf == 2 || few_kept || N * C <= 65536 || (N <= 1024 && N * C <= 131072) || (plan.big && N * C <= 524288)) &&
               aligned_to(V0, 16) && B * (int64_t)plan.chunks <= 0x7fffffff;
     for (int m = 0; ok && m < M; ++m) ok = aligned_to(W_steps[m], 4) && aligned_to(out_steps[m], 16);
     if (ok) {
@@ -863,7 +868,7 @@ const char* psf_last_error(void) { return g_err; }
 
 const char* psf_build_info(void) {
   return "libpsf_chord: gfx950 (CDNA4, wave64) | hipcc " __VERSION__
-         " | fwd: generic<f32,f64> + LDS-window<f32, L=4..20, LDS-DMA staging> + LDS-resident chain<f32, N<=2112>"
+         " | fwd: generic<f32,f64> + LDS-window<f32, L=4..20, LDS-DMA staging> + LDS-resident chain<f32, N<=2112; 8 channels per workgroup N<=2048>"
          " | bwd: generic dV/dW<f32,f64> + LDS-window dV/dW<f32> + fused dV+dW step<f32, C<=32>"
          " | producers: fused MLP fwd (split-bf16 MFMA at f32 accuracy, f32 MFMA) + fused MLP bwd (split-bf16 MFMA on dual-use LDS planes, f32 MFMA),"
          " tall-skinny weight gradients (f32 MFMA), token embedding + positional add"
@@ -1148,9 +1153,13 @@ int psf_describe_chain_fwd(int64_t B, int64_t N, int32_t L, int64_t C, int32_t M
   const Tuning tn = snapshot();
   const int cf = tn.chain_fused;
   // (as an inference chain is run: only the last result kept)
-  if (cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, tn.chain_cc)) {
-    snprintf(buf, cap, "chord_chain_lds_k<f32,L=%d,CC=%d,R=%d> one launch for all %d steps, %d threads, %d workgroup(s) per sequence",
-             (int)L, plan.cc, plan.rows, (int)M, plan.threads, plan.chunks);
+  if (cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, tn.chain_cc, B)) {
+    if (plan.big)
+      snprintf(buf, cap, "chord_chain_lds8_k<f32,L=%d> one launch for all %d steps, %d threads x 2 rows x 8 channels, %d workgroup(s) per sequence",
+               (int)L, (int)M, plan.threads, plan.chunks);
+    else
+      snprintf(buf, cap, "chord_chain_lds_k<f32,L=%d,CC=%d,R=%d> one launch for all %d steps, %d threads, %d workgroup(s) per sequence",
+               (int)L, plan.cc, plan.rows, (int)M, plan.threads, plan.chunks);
     return PSF_OK;
   }
   return psf_describe_fwd(B, N, L, C, 4, buf, cap);

@@ -526,6 +526,52 @@ def test_fused_lds_chain_matches_oracle_and_per_step(gpu, B, N, M, L, C, residua
     assert np.array_equal(got[0], want[-1])
 
 
+BIG_CHAIN_SHAPES = [  # (B, N, M, L, C, residual): 1057 <= N <= 2048, two channel groups per workgroup, a thread owns both
+    (2, 2000, 11, 12, 128, True), (3, 2048, 5, 12, 8, True), (2, 1057, 4, 11, 16, False), (2, 2001, 3, 12, 12, True),
+    (1, 1500, 6, 20, 24, True), (2, 2047, 3, 2, 8, False), (2, 1999, 4, 15, 20, True),
+]
+
+
+@pytest.mark.parametrize("B,N,M,L,C,residual", BIG_CHAIN_SHAPES)
+def test_fused_lds_chain_large_instance(gpu, B, N, M, L, C, residual):
+    """chord_chain_lds8_k (knob chain_cc = 2 forces it; automatic from 256 workgroups per launch on): bit-equal to the oracle
+    and to the one-group-per-workgroup launch, with every step kept and with ping-pong storage; an odd number of channel
+    groups (C = 12, 20) leaves the last workgroup one group."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import _lib
+    W = _mk((M, B, N, L), 71, 0.4)
+    V0 = _mk((B, N, C), 72)
+    rows, cols = oc.chord_indices(N, L)
+    want = oc.chain(np.stack([rows, cols]), W, V0, residual)
+    Ws = [_t(W[m], gpu) for m in range(M)]
+    got = {}
+    sfa.set_tuning("chain_fused", 2)
+    try:
+        for cc in (2, 1):
+            sfa.set_tuning("chain_cc", cc)
+            assert ("lds8" in _lib.describe_chain_fwd(B, N, L, C, M)) == (cc == 2)
+            with torch.no_grad():
+                got[cc] = sfa.chord_chain(Ws, _t(V0, gpu), residual).cpu().numpy()
+            Wg = [w.clone().requires_grad_(True) for w in Ws]
+            out = sfa.chord_chain(Wg, _t(V0, gpu), residual)
+            steps = [t for t in out.grad_fn.saved_tensors][1 + M:2 * M]
+            for m, t in enumerate(steps):
+                assert np.array_equal(t.cpu().numpy(), want[m]), f"chain_cc={cc} stored step {m}"
+            assert np.array_equal(out.detach().cpu().numpy(), want[-1])
+    finally:
+        sfa.set_tuning("chain_cc", 0)
+        sfa.set_tuning("chain_fused", 1)
+    assert np.array_equal(got[2], want[-1]) and np.array_equal(got[1], want[-1])
+
+
+def test_fused_lds_chain_large_instance_rule(gpu):
+    """Automatic: the large instance only when the launch keeps at least 256 workgroups (one per CU)."""
+    from sparsefactorization_amd import _lib
+    assert "lds8" in _lib.describe_chain_fwd(32, 2000, 12, 128, 11)       # ListOps: 32 x 16 workgroups
+    assert "lds8" not in _lib.describe_chain_fwd(40, 2048, 12, 8, 11)     # 40 workgroups: two per sequence stay
+    assert "lds8" not in _lib.describe_chain_fwd(32, 1024, 11, 32, 10)    # N <= 1056: the two-group instance of old
+
+
 def test_fused_lds_chain_custom_offsets_and_broadcast(gpu):
     import sparsefactorization_amd as sfa
     B, N, M, L = 3, 256, 4, 6
