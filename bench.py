@@ -34,7 +34,7 @@ shapes = the other timed shapes of SURVEY.md §8(d) (cfg1, cfg3 reference and BA
   sits in the 256 MB Infinity Cache — NOT an HBM rate) and `*_rotating` (operand sets spanning 2.5 x the Infinity Cache: the
   fraction of the HBM roofline). One entry PER KERNEL, each with the time of that kernel and the counters of that kernel:
   `fwd_step_kernel` (the per-step chord_fwd_win_k: what training runs, every step kept), `fwd_chain_kernel` (what a no-grad
-  chord_chain call runs: chord_chain_lds_k / chord_chain_lds8_k, one launch for all steps, where it applies — else "same_as"), `bwd_step_kernel`
+  chord_chain call runs: chord_chain_lds_k / chord_chain_rows_k, one launch for all steps, where it applies — else "same_as"), `bwd_step_kernel`
   (the fused backward step). `counters`: memory-side bytes and L2 requests per launch of THAT kernel from the committed
   per-shape counter summary, only when it was collected on these kernel sources. `bound`: "hbm", or "l2" when the counters say
   traffic / algorithmic <= 1.1 and the kernel is under 0.6 of HBM — then `l2_to_cu_GBps` (L2 requests x 128 B / rocprof time)
@@ -843,10 +843,10 @@ def shapes_leg(device):
                 entry["fwd_step_kernel"] = _with_roof(step, _counter_traffic(pmc, pkey, "chord_fwd_", 4 * B * N * (L + 2 * C)))
                 # (b) what a no-grad chord_chain call runs by itself: the single LDS-resident launch where the library takes it
                 chain_desc = _lib.describe_chain_fwd(B, N, L, N if amap else C, M)
-                if "chord_chain_lds" in chain_desc:  # chord_chain_lds_k or chord_chain_lds8_k
+                if "chord_chain_" in chain_desc:  # chord_chain_lds_k or chord_chain_rows_k
                     chain = fwd_entry(chain_desc, "ONE launch for all M steps, only the last result kept: what a no-grad "
                                       "chord_chain (inference) runs", 1)
-                    cc = _counter_traffic(pmc, pkey, "chord_chain_lds", M * 4 * B * N * (L + 2 * C))
+                    cc = _counter_traffic(pmc, pkey, "chord_chain_", M * 4 * B * N * (L + 2 * C))
                     if cc is not None and cc.get("l2_requests_per_row"):
                         cc["l2_requests_per_row_per_step"] = cc["l2_requests_per_row"] / M
                     entry["fwd_chain_kernel"] = _with_roof(chain, cc)

@@ -423,7 +423,7 @@ int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float
  *                      wherever they fit (forward and dV); 2 = 32-channel chunks on 256-thread workgroups; 4 (and 3, whose
  *                      512-thread instance for rows of 32 channels was removed in round 5) = one workgroup per whole row
  *                      always
- *   key "chain_fused": 1 (default) = psf_chord_chain_fwd_f32 runs short sequences (N <= 2112, L <= 20, C % 4 == 0) as ONE
+ *   key "chain_fused": 1 (default) = psf_chord_chain_fwd_f32 runs short sequences (N <= 2112, or 4160: see "chain_cc"; L <= 20, C % 4 == 0) as ONE
  *                      launch with the sequence resident in LDS: always when at most two step results are kept (inference
  *                      with alternating buffers), and when every step is kept (training) for sequences of at most 65536
  *                      elements (131072 for N <= 1024; 524288 where the eight-channel instance of "chain_cc" runs);
@@ -435,8 +435,10 @@ int psf_stream_mix_bwd_f32(const float* w, const float* v, const float* z, float
  *                      even steps and backwards on odd ones, so a launch starts on the tiles whose inputs the
  *                      previous launch wrote last (default); 0 = always forwards
  *   key "chain_cc"   : fused chain: channel groups (of 4 channels) per workgroup: 0 = automatic (default): two when the rows allow
- *                      (N <= 1056; N <= 2048 on the one-workgroup-per-CU instance when the launch keeps >= 256 workgroups),
- *                      1 = one, 2 = two wherever an instance exists
+ *                      (N <= 1056; N <= 2048 on the one-workgroup-per-CU instance when the launch keeps >= 256 workgroups;
+ *                      that instance with one group also runs 2113 <= N <= 4160, the LRA text task, under the same
+ *                      condition when only the last result is kept), 1 = one and no instance beyond N = 2112, 2 = the
+ *                      one-workgroup-per-CU instances wherever they fit
  *   key "mlp_variant": psf_mlp_fwd_f32: 0 = auto (default: the split-bf16 kernel for E <= 32, else the f32-MFMA
  *                      kernel), 1 = f32 MFMA with streamed weights, 2 = f32 MFMA with LDS-resident weights,
  *                      3 = split-bf16 (each f32 operand as three exact bf16 terms, six product terms: f32 accuracy)

@@ -40,7 +40,7 @@ def main():
     torch.cuda.synchronize()
     from sparsefactorization_amd import _lib
     M = L - 1
-    if "chord_chain_lds" in _lib.describe_chain_fwd(B, N, L, C, M):  # the one-launch chain: bench.py's `fwd_chain_kernel`
+    if "chord_chain_" in _lib.describe_chain_fwd(B, N, L, C, M):  # the one-launch chain: bench.py's `fwd_chain_kernel`
         Ws = [0.1 * torch.randn(B, N, L, device=dev, generator=g) for _ in range(M)]
         with torch.no_grad():
             for _ in range(iters):

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""The one-launch chain for 1057 <= N <= 2048 with TWO channel groups per workgroup (chord_chain_rows_k, knob chain_cc = 2)
-against one group per workgroup (chain_cc = 1, what ran there before) and against M per-step launches (chain_fused = 0);
-every step kept (training) and last kept (inference), W rotating; us per step, arms interleaved, results compared bit for
-bit.   python profiles/chain_lds8_ab.py [BxNxLxC ...]"""
+"""The one-launch chain for 2113 <= N <= 4160 (chord_chain_rows_k with one channel group and five rows per thread; knob
+chain_cc = 2 forces it) against M per-step launches (chain_fused = 0); every step kept (training) and last kept (inference),
+W rotating; us per step, arms interleaved, results compared bit for bit.   python profiles/chain_long_ab.py [BxNxLxC ...]"""
 import os, statistics, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,18 +9,17 @@ import sparsefactorization_amd as sfa  # noqa: E402
 from sparsefactorization_amd import chord, _lib  # noqa: E402
 
 dev = torch.device("cuda:0")
-SHAPES = [(32, 2000, 12, 128), (32, 2048, 12, 64), (32, 2000, 12, 64), (32, 2048, 12, 32), (64, 2048, 12, 16), (64, 2048, 12, 8),
-          (128, 2048, 12, 8), (32, 2001, 12, 128), (32, 1500, 12, 32), (16, 2000, 12, 128), (8, 2000, 12, 128)]
+SHAPES = [(32, 4097, 14, 32), (32, 4096, 13, 32), (64, 4097, 14, 32), (32, 4097, 14, 64), (32, 4097, 14, 8), (16, 4097, 14, 32), (32, 3000, 13, 32), (64, 4096, 13, 8)]
 if len(sys.argv) > 1:
     SHAPES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
-ARMS = {"steps": (0, 0), "one group": (2, 1), "two groups": (2, 2)}
+ARMS = {"steps": (0, 0), "one launch": (2, 2)}
 for B, N, L, C in SHAPES:
-    M = L - 1
+    M = L - 2 if N == 4097 else L - 1
     g = torch.Generator(device=dev).manual_seed(1)
     sets = max(2, min(12, int(640e6 // (M * 4 * B * N * L))))
     Wsets = [[0.1 * torch.randn(B, N, L, device=dev, generator=g) for _ in range(M)] for _ in range(sets)]
     V0 = torch.randn(B, N, C, device=dev, generator=g)
-    res = C <= 8
+    res = True
     line = []
     sfa.set_tuning("chain_fused", 2)
     sfa.set_tuning("chain_cc", 0)
@@ -52,4 +50,4 @@ for B, N, L, C in SHAPES:
         line.append(("every step kept" if keep else "last kept") + ": " + " / ".join(f"{statistics.median(times[a]):.2f}" for a in ARMS))
     sfa.set_tuning("chain_fused", 1)
     sfa.set_tuning("chain_cc", 0)
-    print(f"B={B} N={N} L={L} C={C} (steps / one group / two groups, us per step; automatic: {'two' if auto else 'one'}): " + "   ".join(line), flush=True)
+    print(f"B={B} N={N} L={L} C={C} M={M} (per-step launches / one launch, us per step; automatic: {'one launch' if auto else 'steps'}): " + "   ".join(line), flush=True)

@@ -67,7 +67,7 @@ def main():
             row = [f"`{name}`", str(k.get("calls", "")), f"{k.get('avg_us', float('nan')):.2f}"]
             fused = "fused" in name
             fwd = "chord_fwd_" in name
-            chain = "chord_chain_lds" in name  # ONE launch for all L - 1 steps of a chain (round 6)
+            chain = "chord_chain_" in name  # ONE launch for all L - 1 steps of a chain (round 6)
             full = k.get("calls", 0) >= 50 and ("false>" in name or fused or fwd or chain)  # the main (full-tile) launch of the shape
             alg_k = 4 * B * N * (2 * L + 3 * C) if fused else ((L - 1) * alg if chain else alg)  # the fused step: 4BN(2L+3C)
             k["alg_bytes_per_launch"] = alg_k

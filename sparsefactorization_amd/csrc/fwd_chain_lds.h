@@ -23,7 +23,8 @@
 namespace psf {
 
 constexpr int kChainMaxSteps = 64;
-constexpr int kChainBigRows = 2048;  // chord_chain_lds8_k: rows a workgroup can hold (two channel groups each)
+constexpr int kChainBigRows = 2048;   // chord_chain_rows_k<G = 2>: rows a workgroup can hold (two channel groups each)
+constexpr int kChainLongRows = 4160;  // chord_chain_rows_k<G = 1>: rows a workgroup can hold (one channel group)
 
 struct ChainArgs {
   const float* W[kChainMaxSteps];  // W_m [B, N, L]
@@ -137,24 +138,26 @@ chord_chain_lds_k(const ChainArgs a, const Offsets offs) {
   }
 }
 
-// The large instance: 1057 <= N <= 2048 rows with TWO channel groups per workgroup (8 channels), one workgroup per CU.
-// Half as many workgroups stream a sequence's W as with one group each, and that stream's L2 requests are what bounds the
-// one-launch chain at these lengths (ListOps, N = 2000 x 128: 32 workgroups per sequence at 124 G requests/s,
-// profiles/r06z_bwd_pmc.json). A THREAD owns both groups of its rows (R = 2 rows on <= 1024 threads): one W row load
-// per row instead of one per (row, group), one LDS address per link (the second group sits N slots further: an immediate
-// offset), and the W rows are requested one ROW ahead — row 1's while row 0 accumulates, the next step's row 0 across the
-// barrier — instead of a step ahead (2*R*L registers), which is what fits 128 registers. LDS: [buffer][group][2048] vectors
-// of 16 bytes = 128 KiB. Arithmetic and summation order per channel are those of chord_chain_lds_k: bit-identical.
-template <int L, bool RES>
+// The large instances (one workgroup per CU): a THREAD owns whole rows — G channel groups of each of its R rows.
+//   G = 2, R = 2, 1057 <= N <= 2048: eight channels per workgroup. Half as many workgroups stream a sequence's W as with one
+//          group each, and that stream's L2 requests are what bounds the one-launch chain at these lengths (ListOps,
+//          N = 2000 x 128: 32 workgroups per sequence at 124 G requests/s, profiles/r06z_bwd_pmc.json).
+//   G = 1, R = 5, 2113 <= N <= 4160: four channels per workgroup, the lengths of the LRA text task (N = 4096 + 1).
+// One W row load per row instead of one per (row, group), one LDS address per link (group g sits CAP slots further: an
+// immediate offset), and the W rows are requested one ROW ahead — row j+1's while row j accumulates, the next step's
+// row 0 across the barrier — instead of a step ahead (2*R*L registers), which is what fits 128 registers on 1024
+// threads. LDS: [buffer][group][CAP] vectors of 16 bytes. Arithmetic and summation order per channel are those of
+// chord_chain_lds_k: bit-identical.
+template <int L, int G, int R, int CAP, bool RES>
 __global__ void __launch_bounds__(1024)
-chord_chain_lds8_k(const ChainArgs a, const Offsets offs) {
+chord_chain_rows_k(const ChainArgs a, const Offsets offs) {
   using V4 = Vec<float, 4>;
   using F4 = float __attribute__((ext_vector_type(4)));
-  constexpr int R = 2;
+  static_assert(G == 1 || G == 2, "channel groups per thread");
   extern __shared__ __attribute__((aligned(16))) F4 xlds[];
   const int N = a.N, C = a.C;
-  constexpr int GS = kChainBigRows;  // group stride in slots: a constant, so the second group is an immediate offset
-  constexpr int slots = 2 * GS;
+  constexpr int GS = CAP;  // group stride in slots: a constant, so the second group is an immediate offset
+  constexpr int slots = G * GS;
   int cur = 0;
   const int tid = threadIdx.x;
   const int RSN = blockDim.x;
@@ -165,8 +168,8 @@ chord_chain_lds8_k(const ChainArgs a, const Offsets offs) {
   }
   const int b = (int)(lb / (uint32_t)a.chunks);
   const int chunk = (int)(lb - (uint32_t)b * (uint32_t)a.chunks);
-  const int cg0 = chunk * 2;
-  const bool g1_ok = cg0 + 1 < a.CG;          // (an odd number of channel groups: the last workgroup owns one)
+  const int cg0 = chunk * G;
+  const bool g1_ok = G == 2 && cg0 + 1 < a.CG;          // (an odd number of channel groups: the last workgroup owns one)
   const int cg1 = g1_ok ? cg0 + 1 : cg0;
 
   int prow[R];
@@ -186,7 +189,7 @@ chord_chain_lds8_k(const ChainArgs a, const Offsets offs) {
     const V4 v1 = ld<float, 4>(V0b + (int64_t)prow[j] * C + (int64_t)cg1 * 4);
     if (pok[j]) {
       xlds[prow[j]] = F4{v0.e[0], v0.e[1], v0.e[2], v0.e[3]};
-      xlds[GS + prow[j]] = F4{v1.e[0], v1.e[1], v1.e[2], v1.e[3]};
+      if constexpr (G == 2) xlds[GS + prow[j]] = F4{v1.e[0], v1.e[1], v1.e[2], v1.e[3]};
     }
     resv[j][0] = v0;
     resv[j][1] = v1;
@@ -202,7 +205,8 @@ chord_chain_lds8_k(const ChainArgs a, const Offsets offs) {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       const WRow<L> wnx = j + 1 < R ? w_row(m, j + 1) : w_row(mn, 0);
-      const int p = prow[j];
+      int p = prow[j];
+      if constexpr (R > 2) asm volatile("" : "+v"(p));  // (five rows x L hoisted link addresses would not fit: recomputed per step)
       V4 acc0, acc1;
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc0.e[i] = acc1.e[i] = 0.f;
@@ -211,23 +215,27 @@ chord_chain_lds8_k(const ChainArgs a, const Offsets offs) {
         int src = p + offs.v[k];
         if (src >= N) src -= N;
         const F4 x0 = xlds[cur + src];
-        const F4 x1 = xlds[cur + GS + src];
         axpy_rn<float, 4>(acc0, wc.e[k], V4{{x0.x, x0.y, x0.z, x0.w}});
-        axpy_rn<float, 4>(acc1, wc.e[k], V4{{x1.x, x1.y, x1.z, x1.w}});
+        if constexpr (G == 2) {
+          const F4 x1 = xlds[cur + GS + src];
+          axpy_rn<float, 4>(acc1, wc.e[k], V4{{x1.x, x1.y, x1.z, x1.w}});
+        }
       }
       if constexpr (RES) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           acc0.e[i] = add_rn(acc0.e[i], resv[j][0].e[i]);
-          acc1.e[i] = add_rn(acc1.e[i], resv[j][1].e[i]);
+          if constexpr (G == 2) acc1.e[i] = add_rn(acc1.e[i], resv[j][1].e[i]);
         }
       }
       if (pok[j]) {
         xlds[(slots - cur) + p] = F4{acc0.e[0], acc0.e[1], acc0.e[2], acc0.e[3]};
-        xlds[(slots - cur) + GS + p] = F4{acc1.e[0], acc1.e[1], acc1.e[2], acc1.e[3]};
+        if constexpr (G == 2) xlds[(slots - cur) + GS + p] = F4{acc1.e[0], acc1.e[1], acc1.e[2], acc1.e[3]};
         if (store) {
           st<float, 4>(om + ((int64_t)b * N + p) * C + (int64_t)cg0 * 4, acc0);
-          if (g1_ok) st<float, 4>(om + ((int64_t)b * N + p) * C + (int64_t)cg1 * 4, acc1);
+          if constexpr (G == 2) {
+            if (g1_ok) st<float, 4>(om + ((int64_t)b * N + p) * C + (int64_t)cg1 * 4, acc1);
+          }
         }
       }
       wc = wnx;

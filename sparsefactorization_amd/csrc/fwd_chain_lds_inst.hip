@@ -21,12 +21,12 @@ hipError_t launch_one(const ChainArgs& a, const Offsets& offs, int B, int thread
   return hipGetLastError();
 }
 
-template <int L, bool RES>
-hipError_t launch_big(const ChainArgs& a, const Offsets& offs, int B, int threads, int lds_bytes, hipStream_t s) {
-  auto kern = chord_chain_lds8_k<L, RES>;
+template <int L, int G, int R, int CAP, bool RES>
+hipError_t launch_rows(const ChainArgs& a, const Offsets& offs, int B, int threads, int lds_bytes, hipStream_t s) {
+  auto kern = chord_chain_rows_k<L, G, R, CAP, RES>;
   static std::atomic<int> raised{0};
   if (!raised.load()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kChainBigBytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G * CAP * 16);
     if (e != hipSuccess) return e;
     raised.store(1);
   }
@@ -37,8 +37,11 @@ hipError_t launch_big(const ChainArgs& a, const Offsets& offs, int B, int thread
 template <int L, int CC, bool RES>
 hipError_t launch_R(const ChainLdsPlan& p, const ChainArgs& a, const Offsets& offs, int B, hipStream_t s) {
   if constexpr (CC == 2) {
-    if (p.big) return launch_big<L, RES>(a, offs, B, p.threads, p.lds_bytes, s);
+    if (p.big == 1) return launch_rows<L, 2, 2, kChainBigRows, RES>(a, offs, B, p.threads, p.lds_bytes, s);
+  } else {
+    if (p.big == 2) return launch_rows<L, 1, kChainLongRowsPerThread, kChainLongRows, RES>(a, offs, B, p.threads, p.lds_bytes, s);
   }
+  if (p.big) return hipErrorInvalidValue;
   if (p.rows == 1) return launch_one<L, CC, 1, RES, 512>(a, offs, B, p.threads, p.lds_bytes, s);
   if (p.rows == 2 && p.threads <= 512) return launch_one<L, CC, 2, RES, 512>(a, offs, B, p.threads, p.lds_bytes, s);
   if (p.rows == 2) return launch_one<L, CC, 2, RES, 1024>(a, offs, B, p.threads, p.lds_bytes, s);
@@ -77,6 +80,15 @@ bool plan_chain_lds(int64_t N, int64_t C, int32_t L, int32_t M, ChainLdsPlan* p,
     p->chunks = (int)((CG + 1) / 2);
     p->lds_bytes = kChainBigBytes;
     p->big = 1;
+    return true;
+  }
+  if (N > kChainLdsMaxSlots && N <= kChainLongRows && (cc_pref == 2 || (cc_pref == 0 && B * CG >= kChainBigMinWgs))) {
+    p->cc = 1;
+    p->rows = kChainLongRowsPerThread;
+    p->threads = (int)(((N + p->rows - 1) / p->rows + 63) / 64 * 64);
+    p->chunks = (int)CG;
+    p->lds_bytes = kChainLongBytes;
+    p->big = 2;
     return true;
   }
   if (N * cc > kChainLdsMaxSlots) cc = 1;

@@ -728,11 +728,15 @@ int chain_impl(Tuning tn, const T* const* W_steps, const T* V0, T* const* out_st
     // (training) it now wins up to 65 536 elements per sequence and, for N <= 1024, up to 131 072 (per step / one launch,
     // r06u_chain_keep_sweep.log): 2048 x 32: 6.9 / 5.8; 1024 x 64: 6.7 / 4.0; 1024 x 128: 9.2 / 7.8; but 2048 x 64: 9.8 / 11.0;
     // 2000 x 64: 10.5 / 10.8; 2000 x 128: 20.9 / 23.2.
-    // Later in round 6: 1057 <= N <= 2048 on launches of >= 256 workgroups run chord_chain_lds8_k (two channel groups per
-    // workgroup: half the W streams). us per step, per-step launches / one group / two groups (profiles/r06v_chain_lds8_ab.log):
+    // Later in round 6: 1057 <= N <= 2048 on launches of >= 256 workgroups run chord_chain_rows_k (two channel groups per
+    // workgroup: half the W streams). us per step, per-step launches / one group / two groups (profiles/r06v_chain_lds8_ab.log; lds8 = this kernel's first name):
     // last kept: 2000 x 128: 19.3 / 13.5 / 8.0; 2048 x 64: 8.9 / 6.8 / 4.3; every step kept: 2000 x 128: 20.9 / 23.6 / 17.2;
     // 2048 x 64: 9.7 / 11.0 / 8.9; 2000 x 64: 10.6 / 10.8 / 8.2; 2000 x 256: 37.7 / 39.5 / 32.6 - so with that instance the one
     // launch also takes training chains (up to the 524 288 elements per sequence measured); ListOps training step 2.507 -> 2.476 ms.
+    // 2113 <= N <= 4160 (the LRA text task, N = 4097 x 32, B = 32: 256 workgroups) run the same kernel with one channel group and
+    // five rows per thread when only the last result is kept (profiles/r06v_chain_long_ab2.log, per-step / one launch):
+    // 13.0 / 7.2 us per step; 4096 x 32: 11.8 / 6.5; 3000 x 32: 9.6 / 5.4; with every step kept the per-step kernels stay
+    // (13.5 / 14.5), and below 256 workgroups too (B = 16: 7.4 / 6.6 last kept but 8.3 / 11.3 kept; C = 8: 6.4 / 6.6).
     const int cf = tn.chain_fused;
     int kept = 0;  // step results that reach memory
     for (int m = 0; m < M; ++m) {
@@ -742,7 +746,7 @@ int chain_impl(Tuning tn, const T* const* W_steps, const T* V0, T* const* out_st
     }
     const bool few_kept = kept <= 2;
     bool ok = cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, tn.chain_cc, B) &&
-              (cf == 2 || few_kept || N * C <= 65536 || (N <= 1024 && N * C <= 131072) || (plan.big && N * C <= 524288)) &&
+              (cf == 2 || few_kept || N * C <= 65536 || (N <= 1024 && N * C <= 131072) || (plan.big == 1 && N * C <= 524288)) &&
               aligned_to(V0, 16) && B * (int64_t)plan.chunks <= 0x7fffffff;
     for (int m = 0; ok && m < M; ++m) ok = aligned_to(W_steps[m], 4) && aligned_to(out_steps[m], 16);
     if (ok) {
@@ -868,7 +872,7 @@ const char* psf_last_error(void) { return g_err; }
 
 const char* psf_build_info(void) {
   return "libpsf_chord: gfx950 (CDNA4, wave64) | hipcc " __VERSION__
-         " | fwd: generic<f32,f64> + LDS-window<f32, L=4..20, LDS-DMA staging> + LDS-resident chain<f32, N<=2112; 8 channels per workgroup N<=2048>"
+         " | fwd: generic<f32,f64> + LDS-window<f32, L=4..20, LDS-DMA staging> + LDS-resident chain<f32, N<=2112; whole rows per thread: 8 channels N<=2048, 4 channels N<=4160>"
          " | bwd: generic dV/dW<f32,f64> + LDS-window dV/dW<f32> + fused dV+dW step<f32, C<=32>"
          " | producers: fused MLP fwd (split-bf16 MFMA at f32 accuracy, f32 MFMA) + fused MLP bwd (split-bf16 MFMA on dual-use LDS planes, f32 MFMA),"
          " tall-skinny weight gradients (f32 MFMA), token embedding + positional add"
@@ -1155,8 +1159,8 @@ int psf_describe_chain_fwd(int64_t B, int64_t N, int32_t L, int64_t C, int32_t M
   // (as an inference chain is run: only the last result kept)
   if (cf && M >= 2 && M <= kChainMaxSteps && B >= 1 && plan_chain_lds(N, C, L, M, &plan, tn.chain_cc, B)) {
     if (plan.big)
-      snprintf(buf, cap, "chord_chain_lds8_k<f32,L=%d> one launch for all %d steps, %d threads x 2 rows x 8 channels, %d workgroup(s) per sequence",
-               (int)L, (int)M, plan.threads, plan.chunks);
+      snprintf(buf, cap, "chord_chain_rows_k<f32,L=%d,G=%d,R=%d> one launch for all %d steps, %d threads x %d rows x %d channels, %d workgroup(s) per sequence",
+               (int)L, plan.cc, plan.rows, (int)M, plan.threads, plan.rows, 4 * plan.cc, plan.chunks);
     else
       snprintf(buf, cap, "chord_chain_lds_k<f32,L=%d,CC=%d,R=%d> one launch for all %d steps, %d threads, %d workgroup(s) per sequence",
                (int)L, plan.cc, plan.rows, (int)M, plan.threads, plan.chunks);

@@ -534,7 +534,7 @@ BIG_CHAIN_SHAPES = [  # (B, N, M, L, C, residual): 1057 <= N <= 2048, two channe
 
 @pytest.mark.parametrize("B,N,M,L,C,residual", BIG_CHAIN_SHAPES)
 def test_fused_lds_chain_large_instance(gpu, B, N, M, L, C, residual):
-    """chord_chain_lds8_k (knob chain_cc = 2 forces it; automatic from 256 workgroups per launch on): bit-equal to the oracle
+    """chord_chain_rows_k with two channel groups per thread (knob chain_cc = 2 forces it; automatic from 256 workgroups per launch on): bit-equal to the oracle
     and to the one-group-per-workgroup launch, with every step kept and with ping-pong storage; an odd number of channel
     groups (C = 12, 20) leaves the last workgroup one group."""
     import sparsefactorization_amd as sfa
@@ -549,7 +549,7 @@ def test_fused_lds_chain_large_instance(gpu, B, N, M, L, C, residual):
     try:
         for cc in (2, 1):
             sfa.set_tuning("chain_cc", cc)
-            assert ("lds8" in _lib.describe_chain_fwd(B, N, L, C, M)) == (cc == 2)
+            assert ("chord_chain_rows_k" in _lib.describe_chain_fwd(B, N, L, C, M)) == (cc == 2)
             with torch.no_grad():
                 got[cc] = sfa.chord_chain(Ws, _t(V0, gpu), residual).cpu().numpy()
             Wg = [w.clone().requires_grad_(True) for w in Ws]
@@ -564,12 +564,51 @@ def test_fused_lds_chain_large_instance(gpu, B, N, M, L, C, residual):
     assert np.array_equal(got[2], want[-1]) and np.array_equal(got[1], want[-1])
 
 
+LONG_CHAIN_SHAPES = [  # (B, N, M, L, C, residual): 2113 <= N <= 4160, one channel group, five rows per thread
+    (2, 4097, 12, 14, 32, True), (2, 4096, 4, 13, 8, False), (1, 2113, 3, 12, 12, True), (2, 4160, 3, 13, 4, True), (2, 3000, 5, 20, 8, False),
+]
+
+
+@pytest.mark.parametrize("B,N,M,L,C,residual", LONG_CHAIN_SHAPES)
+def test_fused_lds_chain_long_instance(gpu, B, N, M, L, C, residual):
+    """chord_chain_rows_k with one channel group and five rows per thread (the LRA text task's N = 4096 + 1; knob chain_cc = 2
+    forces it; automatic from 256 workgroups per launch on): bit-equal to the oracle and to the per-step kernels, with every
+    step kept and with ping-pong storage."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import _lib
+    W = _mk((M, B, N, L), 73, 0.4)
+    V0 = _mk((B, N, C), 74)
+    rows, cols = oc.chord_indices(N, L)
+    want = oc.chain(np.stack([rows, cols]), W, V0, residual)
+    Ws = [_t(W[m], gpu) for m in range(M)]
+    sfa.set_tuning("chain_fused", 2)
+    sfa.set_tuning("chain_cc", 2)
+    try:
+        assert "chord_chain_rows_k<f32,L=%d,G=1,R=5>" % L in _lib.describe_chain_fwd(B, N, L, C, M)
+        with torch.no_grad():
+            got = sfa.chord_chain(Ws, _t(V0, gpu), residual).cpu().numpy()
+        Wg = [w.clone().requires_grad_(True) for w in Ws]
+        out = sfa.chord_chain(Wg, _t(V0, gpu), residual)
+        steps = [t for t in out.grad_fn.saved_tensors][1 + M:2 * M]
+        for m, t in enumerate(steps):
+            assert np.array_equal(t.cpu().numpy(), want[m]), f"stored step {m}"
+        assert np.array_equal(out.detach().cpu().numpy(), want[-1])
+    finally:
+        sfa.set_tuning("chain_cc", 0)
+        sfa.set_tuning("chain_fused", 1)
+    assert np.array_equal(got, want[-1])
+    with torch.no_grad():  # (few sequences: the automatic rule leaves these to the per-step kernels)
+        assert np.array_equal(sfa.chord_chain(Ws, _t(V0, gpu), residual).cpu().numpy(), want[-1])
+
+
 def test_fused_lds_chain_large_instance_rule(gpu):
     """Automatic: the large instance only when the launch keeps at least 256 workgroups (one per CU)."""
     from sparsefactorization_amd import _lib
-    assert "lds8" in _lib.describe_chain_fwd(32, 2000, 12, 128, 11)       # ListOps: 32 x 16 workgroups
-    assert "lds8" not in _lib.describe_chain_fwd(40, 2048, 12, 8, 11)     # 40 workgroups: two per sequence stay
-    assert "lds8" not in _lib.describe_chain_fwd(32, 1024, 11, 32, 10)    # N <= 1056: the two-group instance of old
+    assert "rows_k<f32,L=12,G=2" in _lib.describe_chain_fwd(32, 2000, 12, 128, 11)       # ListOps: 32 x 16 workgroups
+    assert "rows_k" not in _lib.describe_chain_fwd(40, 2048, 12, 8, 11)     # 40 workgroups: two per sequence stay
+    assert "rows_k" not in _lib.describe_chain_fwd(32, 1024, 11, 32, 10)    # N <= 1056: the two-group instance of old
+    assert "rows_k<f32,L=14,G=1,R=5>" in _lib.describe_chain_fwd(32, 4097, 14, 32, 12)   # the LRA text task: 32 x 8 workgroups
+    assert "rows_k" not in _lib.describe_chain_fwd(8, 4097, 14, 32, 12)
 
 
 def test_fused_lds_chain_custom_offsets_and_broadcast(gpu):
