@@ -141,7 +141,7 @@ chord_chain_lds_k(const ChainArgs a, const Offsets offs) {
 // The large instances (one workgroup per CU): a THREAD owns whole rows — G channel groups of each of its R rows.
 //   G = 2, R = 2, 1057 <= N <= 2048: eight channels per workgroup. Half as many workgroups stream a sequence's W as with one
 //          group each, and that stream's L2 requests are what bounds the one-launch chain at these lengths (ListOps,
-//          N = 2000 x 128: 32 workgroups per sequence at 124 G requests/s, profiles/r06z_bwd_pmc.json).
+//          N = 2000 x 128: 32 workgroups per sequence at 124 G requests/s, profiles/r06y_bwd_pmc.json).
 //   G = 1, R = 5, 2113 <= N <= 4160: four channels per workgroup, the lengths of the LRA text task (N = 4096 + 1).
 // One W row load per row instead of one per (row, group), one LDS address per link (group g sits CAP slots further: an
 // immediate offset), and the W rows are requested one ROW ahead — row j+1's while row j accumulates, the next step's

@@ -15,7 +15,7 @@ constexpr int kChainLdsMaxBytes = 2 * kChainLdsMaxSlots * 16;  // two X buffers:
 // The large instances (chord_chain_rows_k, ONE workgroup per CU, a thread owns whole rows of its channel groups), taken when
 // the launch still has >= kChainBigMinWgs workgroups:
 //   big = 1: TWO channel groups per workgroup for 1057 <= N <= 2048 (128 KiB). Half as many workgroups stream a sequence's W,
-//            and that stream's L2 requests are what bounds the one-launch chain at these lengths (profiles/r06z_bwd_pmc.json:
+//            and that stream's L2 requests are what bounds the one-launch chain at these lengths (profiles/r06y_bwd_pmc.json:
 //            ListOps 124 G requests/s).
 //   big = 2: one channel group, five rows per thread, for 2113 <= N <= 4160 (130 KiB): the LRA text task's N = 4096 + 1.
 constexpr int kChainBigSlots = 2 * kChainBigRows;
