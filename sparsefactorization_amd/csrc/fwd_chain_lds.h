@@ -10,8 +10,9 @@
 // the per-step V / residual / output traffic (100 of 156 B per row-step at cfg2's mix) and the M-1 kernel
 // boundaries, which dominate for short sequences (per-step kernels at N <= 2048 run 6-19 us of mostly launch and
 // fill/drain). Fits N * CC <= 2112 (row, channel-group) slots, i.e. N <= 2112: the LRA ListOps / Pathfinder /
-// CIFAR-10 configurations with or without a CLS-token column (N = 2^k + 1) and the synthetic tasks up to N = 2048; longer
-// sequences use the per-step kernels.
+// CIFAR-10 configurations with or without a CLS-token column (N = 2^k + 1) and the synthetic tasks up to N = 2048. Launches
+// of >= 256 workgroups at 1057 <= N <= 2048 (eight channels per workgroup) and 2113 <= N <= 4160 run chord_chain_rows_k
+// (below: a thread owns whole rows); other sequences use the per-step kernels.
 //
 // Thread (rs, g): channel group g < CC of rows rs + j*RSN, j < R (RSN = blockDim / CC row slots). The same thread
 // produces the same rows at every step, so the residual rows stay in registers. Summation order and arithmetic

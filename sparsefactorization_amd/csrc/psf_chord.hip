@@ -873,7 +873,7 @@ const char* psf_last_error(void) { return g_err; }
 const char* psf_build_info(void) {
   return "libpsf_chord: gfx950 (CDNA4, wave64) | hipcc " __VERSION__
          " | fwd: generic<f32,f64> + LDS-window<f32, L=4..20, LDS-DMA staging> + LDS-resident chain<f32, N<=2112; whole rows per thread: 8 channels N<=2048, 4 channels N<=4160>"
-         " | bwd: generic dV/dW<f32,f64> + LDS-window dV/dW<f32> + fused dV+dW step<f32, C<=32>"
+         " | bwd: generic dV/dW<f32,f64> + LDS-window dV/dW<f32> + fused dV+dW step<f32, C<=64; C=128 up to N=4096>"
          " | producers: fused MLP fwd (split-bf16 MFMA at f32 accuracy, f32 MFMA) + fused MLP bwd (split-bf16 MFMA on dual-use LDS planes, f32 MFMA),"
          " tall-skinny weight gradients (f32 MFMA), token embedding + positional add"
          ", wide producer MLPs (E <= 1024: stacked first layers as split-bf16 GEMMs from bf16 term planes, LDS-DMA ring)"
