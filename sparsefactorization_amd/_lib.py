@@ -34,6 +34,9 @@ SIGNATURES = {
     "psf_chord_spmm_bwd_f64": (_BWD, ctypes.c_int),
     "psf_chord_chain_fwd_f32": (_CHAIN, ctypes.c_int),
     "psf_chord_chain_fwd_f64": (_CHAIN, ctypes.c_int),
+    "psf_chord_chain_bwd_supported": ([c_i64, c_i32, c_i64, c_i32], ctypes.c_int),
+    "psf_chord_chain_bwd_f32": ([c_vp, ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp, c_i32, c_i32,
+                                 c_i64, c_i64, c_i32, c_i64, _I64P, c_vp], ctypes.c_int),
     "psf_linear_wgrad_workspace": ([c_i64, c_i32, c_i32], c_i64),
     "psf_linear_wgrad_f32": ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp], ctypes.c_int),
     "psf_linear_wgrad_strided_f32": ([c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp], ctypes.c_int),
@@ -164,6 +167,9 @@ def stream_ptr(dev) -> int:
         idx = dev.index
         return raw(cuda.current_device() if idx is None else idx)
     return cuda.current_stream(dev).cuda_stream
+
+
+PSF_E_UNSUPPORTED = -7  # psf_chord_chain_bwd_f32: no one-launch kernel for the shape (the caller runs the steps)
 
 
 def check(rc: int, what: str) -> None:

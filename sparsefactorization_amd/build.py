@@ -26,10 +26,10 @@ ARCH = "gfx950"
 WIN_TGS = list(range(7))
 
 HEADERS = ["psf_common.h", "fwd_kernels.h", "fwd_window.h", "fwd_window_launch.h", "bwd_kernels.h",
-           "bwd_window.h", "bwd_dw_chunk.h", "bwd_window_launch.h", "fwd_chain_lds.h", "fwd_chain_lds_launch.h", "fwd_mlp_step.h", "fwd_mlp_step_launch.h", "mixer_lds.h", "mixer_lds_launch.h", "mlp_x3_image.h", "mlp_fwd_x3.h", "mlp_x3_common.h", "mlp_planes.h", "x3_gemm.h",
+           "bwd_window.h", "bwd_dw_chunk.h", "bwd_window_launch.h", "fwd_chain_lds.h", "fwd_chain_lds_launch.h", "bwd_chain_lds.h", "fwd_mlp_step.h", "fwd_mlp_step_launch.h", "mixer_lds.h", "mixer_lds_launch.h", "mlp_x3_image.h", "mlp_fwd_x3.h", "mlp_x3_common.h", "mlp_planes.h", "x3_gemm.h",
            os.path.join("..", "..", "include", "psf_chord.h")]
 SOURCES = ["psf_chord.hip", "fwd_window_inst.hip", "bwd_window_inst.hip", "linear_wgrad.hip",
-           "fwd_chain_lds_inst.hip", "fwd_mlp_step_inst.hip", "mixer_lds_inst.hip", "embed.hip", "flat_head.hip", "sum_tensors.hip", "adam.hip", "mlp_fwd.hip", "mlp_fwd_x3.hip", "mlp_bwd.hip", "mlp_wide.hip", "stream_mix.hip"]
+           "fwd_chain_lds_inst.hip", "bwd_chain_lds_inst.hip", "fwd_mlp_step_inst.hip", "mixer_lds_inst.hip", "embed.hip", "flat_head.hip", "sum_tensors.hip", "adam.hip", "mlp_fwd.hip", "mlp_fwd_x3.hip", "mlp_bwd.hip", "mlp_wide.hip", "stream_mix.hip"]
 
 # -ffp-contract=off: products and sums stay separate roundings (bitwise parity with the CPU oracle).
 HIPCC_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
@@ -80,6 +80,7 @@ def _unit_table():
              # v_pk_* pairs hipcc builds from it (Pathfinder chain 41.4 -> 33.9 us, profiles/r04p_lib_ab_noslp.log; the
              # per-step window kernels are the other way round: 367 -> 386 us at cfg2)
              (os.path.join(OBJ_DIR, "fwd_chain_lds.o"), os.path.join(CSRC, "fwd_chain_lds_inst.hip"), ["-fno-slp-vectorize"]),
+             (os.path.join(OBJ_DIR, "bwd_chain_lds.o"), os.path.join(CSRC, "bwd_chain_lds_inst.hip"), ["-fno-slp-vectorize"]),
              (os.path.join(OBJ_DIR, "embed.o"), os.path.join(CSRC, "embed.hip"), []),
              (os.path.join(OBJ_DIR, "flat_head.o"), os.path.join(CSRC, "flat_head.hip"), []),
              (os.path.join(OBJ_DIR, "sum_tensors.o"), os.path.join(CSRC, "sum_tensors.hip"), []),

@@ -299,8 +299,25 @@ class _ChordChain(torch.autograd.Function):
         # everything that is the same for the M launches is looked up once: the small LRA models are bound by the host, and
         # the device guard, the stream object and the symbol look-up of _launch_bwd are most of what a launch costs it
         dev = _require_hip(g, V0, *Ws)
-        fn = getattr(_lib.load(), "psf_chord_spmm_bwd" + _suffix(g))
+        lib = _lib.load()
         off = _lib.offsets_array(ctx.offsets)
+        # short sequences of narrow rows (the synthetic tasks up to N = 1024): the whole backward chain in ONE launch, the
+        # running gradient resident in LDS (csrc/bwd_chain_lds.h); same dV0 bits as the loop below, dW bit-equal to the oracle
+        if (g.dtype == torch.float32 and stride0 == N * C and all(need_w) and M >= 1
+                and lib.psf_chord_chain_bwd_supported(N, L, C, M)):
+            dWs = [torch.empty_like(w) for w in Ws]
+            dV0 = torch.empty((B, N, C), dtype=g.dtype, device=dev)
+            w_tab = (ctypes.c_void_p * M)(*[w.data_ptr() for w in Ws])
+            x_tab = (ctypes.c_void_p * M)(V0.data_ptr(), *[s.data_ptr() for s in steps])
+            dw_tab = (ctypes.c_void_p * M)(*[d.data_ptr() for d in dWs])
+            with torch.cuda.device(dev):
+                rc = lib.psf_chord_chain_bwd_f32(g.data_ptr(), w_tab, V0.data_ptr(), x_tab, dw_tab, dV0.data_ptr(), M,
+                                                 1 if ctx.use_residual else 0, B, N, L, C, off, _stream_ptr(dev))
+            if rc != _lib.PSF_E_UNSUPPORTED:
+                _lib.check(rc, "psf_chord_chain_bwd_f32")
+                return (dV0.reshape(ctx.v_shape) if need_v0 else None, None, None, *dWs)
+            dWs = [None] * M
+        fn = getattr(lib, "psf_chord_spmm_bwd" + _suffix(g))
         rc = 0
         with torch.cuda.device(dev):
             stream = _stream_ptr(dev)

@@ -11,6 +11,7 @@
 
 #include "bwd_kernels.h"
 #include "bwd_window_launch.h"
+#include "bwd_chain_lds.h"
 #include "fwd_chain_lds_launch.h"
 #include "fwd_kernels.h"
 #include "fwd_mlp_step_launch.h"
@@ -52,6 +53,7 @@ std::atomic<int> g_bwd_fused{1};  // 0 = never, 1 = auto, 2 = wherever the fused
 std::atomic<int> g_dw_variant{0};   // dW: 0 = auto (chunk-looping kernel for C >= 32), 1 = whole-row window kernel, 2 = chunk forced
 std::atomic<int> g_dw_tgs{0};       // chunk-looping dW: 0 = auto, 4 = 8 lanes per row chunk, 5 = 16 lanes
 std::atomic<int> g_chain_fused{1};  // 1 = short sequences run the whole chain in one LDS-resident launch
+std::atomic<int> g_chain_bwd_fused{1};  // psf_chord_chain_bwd_f32: 1 = the one-launch kernel where it fits, 0 = never (PSF_E_UNSUPPORTED)
 std::atomic<int> g_chain_cc{0};     // fused chain: 0 = auto channel groups per workgroup, 1 = one, 2 = two wherever it fits
 // Rows of >= 64 channels: 0 = one workgroup spans the whole row (default); 1 = 32-channel chunks on 1024-thread
 // workgroups (256-row tiles, far links 6 -> 2 at L=12); 2 = 32-channel chunks on 256-thread workgroups.
@@ -103,6 +105,7 @@ Knob g_knobs[] = {
     {"fwd_rows", &g_fwd_rows, 0, 4},
     {"chain_fused", &g_chain_fused, 0, 2},
     {"chain_cc", &g_chain_cc, 0, 2},
+    {"chain_bwd_fused", &g_chain_bwd_fused, 0, 1},
     {"mlp_variant", &psf_g_mlp_variant, 0, 3},
     {"wide_fuse", &psf_g_wide_fuse, 0, 1},
 };
@@ -958,6 +961,38 @@ int psf_chord_chain_fwd_f64(const double* const* W_steps, const double* V0, doub
                             int32_t use_residual, int64_t B, int64_t N, int32_t L, int64_t C,
                             int64_t v0_batch_stride, const int64_t* offsets, void* stream) {
   return chain_impl<double>(snapshot(), W_steps, V0, out_steps, M, use_residual, B, N, L, C, v0_batch_stride, offsets, stream);
+}
+
+int psf_chord_chain_bwd_supported(int64_t N, int32_t L, int64_t C, int32_t M) {
+  return g_chain_bwd_fused.load() && chain_bwd_lds_fits(N, C, L, M) ? 1 : 0;
+}
+
+int psf_chord_chain_bwd_f32(const float* dOut, const float* const* W_steps, const float* V0, const float* const* X_steps,
+                            float* const* dW_steps, float* dV0, int32_t M, int32_t use_residual, int64_t B, int64_t N,
+                            int32_t L, int64_t C, const int64_t* offsets, void* stream) {
+  if (M < 1) return fail(PSF_E_SHAPE, "M must be >= 1");
+  if (!dOut || !W_steps || !V0 || !X_steps || !dW_steps || !dV0) return fail(PSF_E_NULL, "a required pointer is NULL");
+  if (int rc = check_dims(B, N, L, C, N * C)) return rc;
+  if (!psf_chord_chain_bwd_supported(N, L, C, M)) return PSF_E_UNSUPPORTED;  // (not an error: the caller runs the steps)
+  if (B == 0) return PSF_OK;
+  if (B > 0x7fffffff) return fail(PSF_E_SHAPE, "B too large");
+  ChainBwdArgs a;
+  for (int m = 0; m < M; ++m) {
+    const float* x = m == 0 ? V0 : X_steps[m];
+    if (!W_steps[m] || !x || !dW_steps[m]) return fail(PSF_E_NULL, "step %d: NULL pointer", m);
+    if (!aligned_to(W_steps[m], 4) || !aligned_to(dW_steps[m], 4) || !aligned_to(x, 16))
+      return fail(PSF_E_ALIGN, "step %d: W / dW must be 4-byte, X 16-byte aligned", m);
+    if (dW_steps[m] == W_steps[m]) return fail(PSF_E_ALIAS, "step %d: dW aliases W", m);
+    a.W[m] = W_steps[m], a.X[m] = x, a.dW[m] = dW_steps[m];
+  }
+  for (int m = M; m < kChainMaxSteps; ++m) a.W[m] = nullptr, a.X[m] = nullptr, a.dW[m] = nullptr;
+  if (!aligned_to(dOut, 16) || !aligned_to(dV0, 16)) return fail(PSF_E_ALIGN, "dOut and dV0 must be 16-byte aligned");
+  a.dOut = dOut, a.dV0 = dV0, a.M = M, a.N = (int32_t)N, a.C = (int32_t)C;
+  Offsets offs;
+  make_offsets(N, L, offsets, &offs);
+  hipError_t e = launch_chain_bwd_lds(L, (int)(C / 4), use_residual != 0, a, offs, (int)B, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail_hip(e, "chord_chain_bwd_lds launch");
+  return PSF_OK;
 }
 
 int64_t psf_mixer_fwd_workspace(int64_t N, int32_t E, int32_t M, const int32_t* h, int64_t C, int32_t L) {

@@ -611,6 +611,84 @@ def test_fused_lds_chain_large_instance_rule(gpu):
     assert "rows_k" not in _lib.describe_chain_fwd(8, 4097, 14, 32, 12)
 
 
+BWD_CHAIN_SHAPES = [  # (B, N, M, L, C, residual, explicit offsets): N <= 1024, C = 4 or 8 — the one-launch backward chain
+    (40, 128, 7, 8, 8, True, None), (3, 1024, 10, 11, 8, True, None), (2, 777, 4, 9, 4, False, None), (2, 64, 3, 7, 8, False, None),
+    (1, 1000, 5, 20, 8, True, None), (2, 300, 9, 3, 4, True, None), (2, 256, 4, 6, 8, True, [0, 5, 255, 300, -1, 128]), (3, 1, 2, 2, 8, True, None),
+]
+
+
+@pytest.mark.parametrize("B,N,M,L,C,residual,offsets", BWD_CHAIN_SHAPES)
+def test_backward_chain_in_one_launch(gpu, B, N, M, L, C, residual, offsets):
+    """chord_chain_bwd_lds_k behind psf_chord_chain_bwd_f32 (what _ChordChain.backward runs for short sequences of narrow rows):
+    dV0 and every dW_m bit-equal to the oracle's per-step backward (the residual terms summed left to right as the per-step
+    path does), and dV0 bit-equal / dW within 1e-6 of the per-step kernels (knob chain_bwd_fused = 0)."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import _lib
+    assert _lib.load().psf_chord_chain_bwd_supported(N, L, C, M) == 1
+    W = _mk((M, B, N, L), 81, 0.4)
+    V0 = _mk((B, N, C), 82)
+    gout = _mk((B, N, C), 83)
+    X = [V0]
+    for m in range(M):
+        nxt = oc.spmul_fwd(W[m], X[-1], offsets)
+        X.append((nxt + V0).astype(np.float32) if residual else nxt)
+    g, want_dW, terms = gout, [None] * M, []
+    for m in range(M - 1, -1, -1):
+        terms.append(g)
+        want_dW[m], g = oc.spmul_bwd(g, W[m], X[m], offsets)
+    want_dV0 = g
+    if residual:
+        acc = terms[0]
+        for t in terms[1:] + [g]:
+            acc = (acc + t).astype(np.float32)
+        want_dV0 = acc
+    got = {}
+    for knob in (1, 0):
+        sfa.set_tuning("chain_bwd_fused", knob)
+        try:
+            Wg = [_t(W[m], gpu).requires_grad_(True) for m in range(M)]
+            Vg = _t(V0, gpu).requires_grad_(True)
+            out = sfa.chord_chain(Wg, Vg, residual, offsets=offsets)
+            assert np.array_equal(out.detach().cpu().numpy(), X[-1])
+            out.backward(_t(gout, gpu))
+            got[knob] = (Vg.grad.cpu().numpy(), [w.grad.cpu().numpy() for w in Wg])
+        finally:
+            sfa.set_tuning("chain_bwd_fused", 1)
+    assert np.array_equal(got[1][0], want_dV0)
+    for m in range(M):
+        assert np.array_equal(got[1][1][m], want_dW[m]), f"dW_{m}"
+    assert np.array_equal(got[0][0], got[1][0])
+    for m in range(M):
+        scale = max(np.abs(want_dW[m]).max(), 1e-30)
+        assert np.abs(got[0][1][m] - got[1][1][m]).max() / scale <= 1e-6
+
+
+def test_backward_chain_in_one_launch_rule_and_partial_gradients(gpu):
+    """Beyond N = 1024 or C = 8 the library says PSF_E_UNSUPPORTED and the steps run; a chain in which only some W_m (or only V0)
+    need gradients takes the per-step path too — same results as with the knob off."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import _lib
+    lib = _lib.load()
+    assert lib.psf_chord_chain_bwd_supported(1024, 11, 8, 10) == 1 and lib.psf_chord_chain_bwd_supported(1025, 12, 8, 10) == 0
+    assert lib.psf_chord_chain_bwd_supported(128, 8, 16, 7) == 0 and lib.psf_chord_chain_bwd_supported(128, 21, 8, 7) == 0
+    B, N, M, L, C = 2, 256, 3, 9, 8
+    W = [_t(_mk((B, N, L), 84 + m, 0.4), gpu) for m in range(M)]
+    V0 = _t(_mk((B, N, C), 88), gpu)
+    res = {}
+    for knob in (1, 0):
+        sfa.set_tuning("chain_bwd_fused", knob)
+        try:
+            Wg = [w.clone().requires_grad_(m != 1) for m, w in enumerate(W)]
+            out = sfa.chord_chain(Wg, V0, True)
+            out.sum().backward()
+            res[knob] = [None if w.grad is None else w.grad.clone() for w in Wg]
+        finally:
+            sfa.set_tuning("chain_bwd_fused", 1)
+    assert res[1][1] is None and res[0][1] is None
+    for m in (0, 2):
+        assert torch.equal(res[1][m], res[0][m])
+
+
 def test_fused_lds_chain_custom_offsets_and_broadcast(gpu):
     import sparsefactorization_amd as sfa
     B, N, M, L = 3, 256, 4, 6
