@@ -304,7 +304,8 @@ class _ChordChain(torch.autograd.Function):
         # short sequences of narrow rows (the synthetic tasks up to N = 1024): the whole backward chain in ONE launch, the
         # running gradient resident in LDS (csrc/bwd_chain_lds.h); same dV0 bits as the loop below, dW bit-equal to the oracle
         if (g.dtype == torch.float32 and stride0 == N * C and all(need_w) and M >= 1
-                and lib.psf_chord_chain_bwd_supported(N, L, C, M)):
+                and lib.psf_chord_chain_bwd_supported(N, L, C, M)
+                and not any(t.data_ptr() % 16 for t in (g, V0, *steps))):  # (views at odd offsets: the per-step kernels take them)
             dWs = [torch.empty_like(w) for w in Ws]
             dV0 = torch.empty((B, N, C), dtype=g.dtype, device=dev)
             w_tab = (ctypes.c_void_p * M)(*[w.data_ptr() for w in Ws])
