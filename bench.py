@@ -35,7 +35,7 @@ shapes = the other timed shapes of SURVEY.md §8(d) (cfg1, cfg3 reference and BA
   fraction of the HBM roofline). One entry PER KERNEL, each with the time of that kernel and the counters of that kernel:
   `fwd_step_kernel` (the per-step chord_fwd_win_k: what training runs, every step kept), `fwd_chain_kernel` (what a no-grad
   chord_chain call runs: chord_chain_lds_k / chord_chain_rows_k, one launch for all steps, where it applies — else "same_as"), `bwd_step_kernel`
-  (the fused backward step). `counters`: memory-side bytes and L2 requests per launch of THAT kernel from the committed
+  (the fused backward step), `bwd_chain_kernel` (the whole backward chain in one launch where the library has it: cfg1). `counters`: memory-side bytes and L2 requests per launch of THAT kernel from the committed
   per-shape counter summary, only when it was collected on these kernel sources. `bound`: "hbm", or "l2" when the counters say
   traffic / algorithmic <= 1.1 and the kernel is under 0.6 of HBM — then `l2_to_cu_GBps` (L2 requests x 128 B / rocprof time)
   and `frac_of_l2_roof` (of the guide's 16.8-18.8 TB/s for rows served out of the XCDs' L2) say where it sits.
@@ -884,7 +884,29 @@ def shapes_leg(device):
                         bc = _counter_traffic(pmc, pkey, "chord_dv_", 4 * B * N * (L + 2 * C))
                     if bc is not None and fused_bwd and "fused" in bc["kernel"]:
                         bwd["kernel"] = bc["kernel"]
+                    if fused_bwd and N < 2 * (256 >> ((C // 4).bit_length() - 1)):  # psf_chord.hip: pick_fused_step wants two tiles of rows
+                        bwd["kernel"] = "chord_dv_generic_k + chord_dw_generic_k (two launches per step: under two tiles of rows)"
                     entry["bwd_step_kernel"] = _with_roof(bwd, bc)
+                    # (c) the whole backward chain in ONE launch where the library has it (N <= 1024, C <= 8: csrc/bwd_chain_lds.h) —
+                    # what chord_chain's autograd node runs there; every step's X kept by the forward, dW_m and dV0 written
+                    lib = _lib.load()
+                    if lib.psf_chord_chain_bwd_supported(N, L, C, M):
+                        import ctypes
+                        Xs = [torch.randn(B, N, C, device=device, generator=g) for _ in range(M)]
+                        dWc = [torch.empty(B, N, L, device=device) for _ in range(M)]
+                        gout, dv0 = torch.randn(B, N, C, device=device, generator=g), torch.empty(B, N, C, device=device)
+                        tabs = [(ctypes.c_void_p * M)(*[t.data_ptr() for t in ts]) for ts in (Wsets[0][:M], Xs, dWc)]
+                        stream = torch.cuda.current_stream(device).cuda_stream
+
+                        def bwd_chain():
+                            _lib.check(lib.psf_chord_chain_bwd_f32(gout.data_ptr(), tabs[0], Xs[0].data_ptr(), tabs[1], tabs[2], dv0.data_ptr(),
+                                                                   M, 1, B, N, L, C, None, stream), "psf_chord_chain_bwd_f32")
+                        t_chain = timed(bwd_chain, 40)
+                        entry["bwd_chain_kernel"] = {"kernel": "chord_chain_bwd_lds_k<L=%d,G=%d,residual>" % (L, C // 4),
+                                                     "what": "ONE launch for all M backward steps: what chord_chain's backward runs for short "
+                                                             "sequences of narrow rows (the per-step path: M x bwd_step_kernel)",
+                                                     "us_per_chain": t_chain, "us_per_step_equivalent": t_chain / M, "steps": M}
+                        del Xs, dWc, gout, dv0
                     del Vs, dWs, zz, flatW
             out[name] = entry
             del Wsets, V0, V0s
