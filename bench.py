@@ -900,7 +900,7 @@ def shapes_leg(device):
 
                         def bwd_chain():
                             _lib.check(lib.psf_chord_chain_bwd_f32(gout.data_ptr(), tabs[0], Xs[0].data_ptr(), tabs[1], tabs[2], dv0.data_ptr(),
-                                                                   M, 1, B, N, L, C, None, stream), "psf_chord_chain_bwd_f32")
+                                                                   None, M, 1, B, N, L, C, None, stream), "psf_chord_chain_bwd_f32")
                         t_chain = timed(bwd_chain, 40)
                         entry["bwd_chain_kernel"] = {"kernel": "chord_chain_bwd_lds_k<L=%d,G=%d,residual>" % (L, C // 4),
                                                      "what": "ONE launch for all M backward steps: what chord_chain's backward runs for short "

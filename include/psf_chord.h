@@ -163,21 +163,26 @@ int psf_chord_chain_fwd_f64(const double* const* W_steps, const double* V0, doub
                             const int64_t* offsets, void* stream);
 
 /*
- * Whole backward chain of the same loop in ONE launch, for short sequences of narrow rows (N <= 1024, C = 4 or 8, 2 <= L <= 20,
- * M <= 64: the synthetic tasks up to N = 1024). psf_chord_chain_bwd_supported says whether the shape is covered (1 / 0);
- * psf_chord_chain_bwd_f32 returns PSF_E_UNSUPPORTED otherwise and the caller runs psf_chord_spmm_bwd_f32 per step
- * (SyntheticExperiments/psf.py:172-188 differentiated; spmul/spmul_cuda.cu:75-84,102-111 per step).
+ * Whole backward chain of the same loop in one call (SyntheticExperiments/psf.py:172-188 differentiated;
+ * spmul/spmul_cuda.cu:75-84,102-111 per step):
+ *   - ONE launch for short sequences of narrow rows (N <= 1024, C = 4 or 8, 2 <= L <= 20, M <= 64: the synthetic tasks up to
+ *     N = 1024); psf_chord_chain_bwd_supported says whether the shape is covered (1 / 0); dX_steps may be NULL then;
+ *   - otherwise the M per-step launches of psf_chord_spmm_bwd_f32 and one psf_sum_tensors_f32 pass, issued by the library
+ *     (no trip through the caller's FFI per step): needs dX_steps, a host table of M device buffers [B,N,C] that receive
+ *     the gradient after each step (dX_steps[m] = gradient of X_m; dX_steps[0] is unused without the residual);
+ *   - PSF_E_UNSUPPORTED (not an error) when neither applies — dX_steps NULL for an uncovered shape, a residual chain of more
+ *     than 31 steps or B*N*C not a multiple of 4, knob "chain_bwd_fused" = 0 — and the caller runs the steps itself.
  *   dOut [B,N,C]  gradient of the chain's result X_M
  *   W_steps[m] -> W_m [B,N,L];   X_steps[m] -> X_m [B,N,C], the forward's input of step m: X_steps[0] is ignored (V0 is
  *   used), X_steps[m] = psf_chord_chain_fwd_f32's out_steps[m-1];   dW_steps[m] -> dW_m [B,N,L] (written)
  *   dV0 [B,N,C] (written): gradient of V0 through the chain and, with use_residual, through every step's "+ V0" as well,
  *   summed in the per-step path's order ((g_M + g_{M-1}) + ... + g_1) + g_0.
- * dV0 and dW are bit-identical to the CPU oracle (products and sums rounded separately, links / channels ascending).
- * Knob "chain_bwd_fused" = 0 turns it off.
+ * The one launch's dV0 and dW are bit-identical to the CPU oracle (products and sums rounded separately, links / channels
+ * ascending); the per-step path's are those of psf_chord_spmm_bwd_f32.
  */
 int psf_chord_chain_bwd_supported(int64_t N, int32_t L, int64_t C, int32_t M);
 int psf_chord_chain_bwd_f32(const float* dOut, const float* const* W_steps, const float* V0, const float* const* X_steps,
-                            float* const* dW_steps, float* dV0, int32_t M, int32_t use_residual,
+                            float* const* dW_steps, float* dV0, float* const* dX_steps, int32_t M, int32_t use_residual,
                             int64_t B, int64_t N, int32_t L, int64_t C, const int64_t* offsets, void* stream);
 
 /*

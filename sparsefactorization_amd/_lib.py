@@ -35,7 +35,7 @@ SIGNATURES = {
     "psf_chord_chain_fwd_f32": (_CHAIN, ctypes.c_int),
     "psf_chord_chain_fwd_f64": (_CHAIN, ctypes.c_int),
     "psf_chord_chain_bwd_supported": ([c_i64, c_i32, c_i64, c_i32], ctypes.c_int),
-    "psf_chord_chain_bwd_f32": ([c_vp, ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp, c_i32, c_i32,
+    "psf_chord_chain_bwd_f32": ([c_vp, ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(c_vp), c_i32, c_i32,
                                  c_i64, c_i64, c_i32, c_i64, _I64P, c_vp], ctypes.c_int),
     "psf_linear_wgrad_workspace": ([c_i64, c_i32, c_i32], c_i64),
     "psf_linear_wgrad_f32": ([c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp], ctypes.c_int),

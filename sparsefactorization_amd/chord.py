@@ -301,18 +301,25 @@ class _ChordChain(torch.autograd.Function):
         dev = _require_hip(g, V0, *Ws)
         lib = _lib.load()
         off = _lib.offsets_array(ctx.offsets)
-        # short sequences of narrow rows (the synthetic tasks up to N = 1024): the whole backward chain in ONE launch, the
-        # running gradient resident in LDS (csrc/bwd_chain_lds.h); same dV0 bits as the loop below, dW bit-equal to the oracle
+        # the whole backward chain in ONE library call (psf_chord_chain_bwd_f32): one launch with the running gradient resident in
+        # LDS for short sequences of narrow rows (the synthetic tasks up to N = 1024; csrc/bwd_chain_lds.h), the M per-step launches
+        # and the one-pass residual sum issued by the library otherwise — same kernels, same order and same bits as the loop
+        # below, without M trips through ctypes and 2 M allocations (the small LRA models are bound by the host)
         if (g.dtype == torch.float32 and stride0 == N * C and all(need_w) and M >= 1
-                and lib.psf_chord_chain_bwd_supported(N, L, C, M)
-                and not any(t.data_ptr() % 16 for t in (g, V0, *steps))):  # (views at odd offsets: the per-step kernels take them)
-            dWs = [torch.empty_like(w) for w in Ws]
+                and not any(t.data_ptr() % 16 for t in (g, V0, *steps))):  # (views at odd offsets: the loop's kernels take them)
+            one_launch = bool(lib.psf_chord_chain_bwd_supported(N, L, C, M))
+            dWb = torch.empty((M, B, N, L), dtype=g.dtype, device=dev)
+            dWs = list(dWb.unbind(0))
             dV0 = torch.empty((B, N, C), dtype=g.dtype, device=dev)
             w_tab = (ctypes.c_void_p * M)(*[w.data_ptr() for w in Ws])
             x_tab = (ctypes.c_void_p * M)(V0.data_ptr(), *[s.data_ptr() for s in steps])
             dw_tab = (ctypes.c_void_p * M)(*[d.data_ptr() for d in dWs])
+            dx_tab = None
+            if not one_launch:
+                dXb = torch.empty((M, B, N, C), dtype=g.dtype, device=dev)
+                dx_tab = (ctypes.c_void_p * M)(*[dXb[m].data_ptr() for m in range(M)])
             with torch.cuda.device(dev):
-                rc = lib.psf_chord_chain_bwd_f32(g.data_ptr(), w_tab, V0.data_ptr(), x_tab, dw_tab, dV0.data_ptr(), M,
+                rc = lib.psf_chord_chain_bwd_f32(g.data_ptr(), w_tab, V0.data_ptr(), x_tab, dw_tab, dV0.data_ptr(), dx_tab, M,
                                                  1 if ctx.use_residual else 0, B, N, L, C, off, _stream_ptr(dev))
             if rc != _lib.PSF_E_UNSUPPORTED:
                 _lib.check(rc, "psf_chord_chain_bwd_f32")

@@ -968,30 +968,57 @@ int psf_chord_chain_bwd_supported(int64_t N, int32_t L, int64_t C, int32_t M) {
 }
 
 int psf_chord_chain_bwd_f32(const float* dOut, const float* const* W_steps, const float* V0, const float* const* X_steps,
-                            float* const* dW_steps, float* dV0, int32_t M, int32_t use_residual, int64_t B, int64_t N,
-                            int32_t L, int64_t C, const int64_t* offsets, void* stream) {
+                            float* const* dW_steps, float* dV0, float* const* dX_steps, int32_t M, int32_t use_residual,
+                            int64_t B, int64_t N, int32_t L, int64_t C, const int64_t* offsets, void* stream) {
   if (M < 1) return fail(PSF_E_SHAPE, "M must be >= 1");
   if (!dOut || !W_steps || !V0 || !X_steps || !dW_steps || !dV0) return fail(PSF_E_NULL, "a required pointer is NULL");
   if (int rc = check_dims(B, N, L, C, N * C)) return rc;
-  if (!psf_chord_chain_bwd_supported(N, L, C, M)) return PSF_E_UNSUPPORTED;  // (not an error: the caller runs the steps)
+  if (!g_chain_bwd_fused.load()) return PSF_E_UNSUPPORTED;  // (knob off: the caller runs the steps itself)
+  const bool one_launch = chain_bwd_lds_fits(N, C, L, M);
+  // the per-step path inside the library needs the M gradient buffers and, with the residual, psf_sum_tensors_f32's limits
+  if (!one_launch && (!dX_steps || (use_residual && (M + 1 > 32 || (B * N * C) % 4 != 0)))) return PSF_E_UNSUPPORTED;
   if (B == 0) return PSF_OK;
-  if (B > 0x7fffffff) return fail(PSF_E_SHAPE, "B too large");
-  ChainBwdArgs a;
   for (int m = 0; m < M; ++m) {
     const float* x = m == 0 ? V0 : X_steps[m];
     if (!W_steps[m] || !x || !dW_steps[m]) return fail(PSF_E_NULL, "step %d: NULL pointer", m);
-    if (!aligned_to(W_steps[m], 4) || !aligned_to(dW_steps[m], 4) || !aligned_to(x, 16))
-      return fail(PSF_E_ALIGN, "step %d: W / dW must be 4-byte, X 16-byte aligned", m);
     if (dW_steps[m] == W_steps[m]) return fail(PSF_E_ALIAS, "step %d: dW aliases W", m);
-    a.W[m] = W_steps[m], a.X[m] = x, a.dW[m] = dW_steps[m];
+    if (!one_launch && !dX_steps[m]) return fail(PSF_E_NULL, "step %d: dX_steps[m] is NULL", m);
   }
-  for (int m = M; m < kChainMaxSteps; ++m) a.W[m] = nullptr, a.X[m] = nullptr, a.dW[m] = nullptr;
-  if (!aligned_to(dOut, 16) || !aligned_to(dV0, 16)) return fail(PSF_E_ALIGN, "dOut and dV0 must be 16-byte aligned");
-  a.dOut = dOut, a.dV0 = dV0, a.M = M, a.N = (int32_t)N, a.C = (int32_t)C;
-  Offsets offs;
-  make_offsets(N, L, offsets, &offs);
-  hipError_t e = launch_chain_bwd_lds(L, (int)(C / 4), use_residual != 0, a, offs, (int)B, reinterpret_cast<hipStream_t>(stream));
-  if (e != hipSuccess) return fail_hip(e, "chord_chain_bwd_lds launch");
+  if (one_launch) {
+    if (B > 0x7fffffff) return fail(PSF_E_SHAPE, "B too large");
+    ChainBwdArgs a;
+    for (int m = 0; m < M; ++m) {
+      const float* x = m == 0 ? V0 : X_steps[m];
+      if (!aligned_to(W_steps[m], 4) || !aligned_to(dW_steps[m], 4) || !aligned_to(x, 16))
+        return fail(PSF_E_ALIGN, "step %d: W / dW must be 4-byte, X 16-byte aligned", m);
+      a.W[m] = W_steps[m], a.X[m] = x, a.dW[m] = dW_steps[m];
+    }
+    for (int m = M; m < kChainMaxSteps; ++m) a.W[m] = nullptr, a.X[m] = nullptr, a.dW[m] = nullptr;
+    if (!aligned_to(dOut, 16) || !aligned_to(dV0, 16)) return fail(PSF_E_ALIGN, "dOut and dV0 must be 16-byte aligned");
+    a.dOut = dOut, a.dV0 = dV0, a.M = M, a.N = (int32_t)N, a.C = (int32_t)C;
+    Offsets offs;
+    make_offsets(N, L, offsets, &offs);
+    hipError_t e = launch_chain_bwd_lds(L, (int)(C / 4), use_residual != 0, a, offs, (int)B, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "chord_chain_bwd_lds launch");
+    return PSF_OK;
+  }
+  // M per-step launches (the kernels psf_chord_spmm_bwd_f32 runs), the gradient handed from buffer to buffer, and ONE pass
+  // over the residual terms at the end: what the caller's loop did, without M trips through its language's FFI
+  const Tuning tn = snapshot();
+  const float* g = dOut;
+  const float* terms[kChainMaxSteps + 1];
+  int nterms = 0;
+  for (int m = M - 1; m >= 0; --m) {
+    if (use_residual) terms[nterms++] = g;
+    float* dx = (m == 0 && !use_residual) ? dV0 : dX_steps[m];
+    if (int rc = bwd_impl<float>(tn, g, W_steps[m], m == 0 ? V0 : X_steps[m], dW_steps[m], dx, B, N, L, C, N * C, offsets, stream))
+      return rc;
+    g = dx;
+  }
+  if (use_residual) {
+    terms[nterms++] = g;  // ((g_M + g_{M-1}) + ... + g_1) + g_0
+    return psf_sum_tensors_f32(terms, nterms, B * N * C, dV0, stream);
+  }
   return PSF_OK;
 }
 

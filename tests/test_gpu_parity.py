@@ -689,6 +689,38 @@ def test_backward_chain_in_one_launch_rule_and_partial_gradients(gpu):
         assert torch.equal(res[1][m], res[0][m])
 
 
+@pytest.mark.parametrize("B,N,M,L,C,residual", [(2, 2000, 5, 12, 16, True), (2, 1025, 4, 11, 32, False), (1, 4097, 3, 13, 8, True),
+                                                 (2, 300, 33, 9, 8, True), (2, 300, 33, 9, 12, False), (2, 300, 33, 9, 12, True)])
+def test_backward_chain_steps_issued_by_the_library(gpu, B, N, M, L, C, residual):
+    """Shapes the one-launch kernel does not cover: psf_chord_chain_bwd_f32 issues the per-step kernels and the residual sum itself.
+    Same kernels in the same order as the Python loop (knob chain_bwd_fused = 0): every gradient bit-equal. A residual chain
+    of more than 31 steps is beyond psf_sum_tensors_f32 and comes back PSF_E_UNSUPPORTED: the loop runs, same result."""
+    import sparsefactorization_amd as sfa
+    from sparsefactorization_amd import _lib
+    if not (N <= 1024 and C <= 8):
+        assert _lib.load().psf_chord_chain_bwd_supported(N, L, C, M) == 0
+    W = [_t(_mk((B, N, L), 90 + m, 0.2), gpu) for m in range(M)]
+    V0 = _t(_mk((B, N, C), 89), gpu)
+    gout = _t(_mk((B, N, C), 88), gpu)
+    res = {}
+    for knob in (1, 0):
+        sfa.set_tuning("chain_bwd_fused", knob)
+        try:
+            Wg = [w.clone().requires_grad_(True) for w in W]
+            Vg = V0.clone().requires_grad_(True)
+            sfa.chord_chain(Wg, Vg, residual).backward(gout)
+            res[knob] = [Vg.grad.clone()] + [w.grad.clone() for w in Wg]
+        finally:
+            sfa.set_tuning("chain_bwd_fused", 1)
+    if N <= 1024 and C <= 8:   # (the one-launch kernel: dV0 the same bits, dW the oracle's bits — within 1e-6 of the step kernels')
+        assert torch.equal(res[1][0], res[0][0])
+        for a, b in zip(res[1][1:], res[0][1:]):
+            assert float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) <= 1e-6
+    else:
+        for a, b in zip(res[1], res[0]):
+            assert torch.equal(a, b)
+
+
 def test_fused_lds_chain_custom_offsets_and_broadcast(gpu):
     import sparsefactorization_amd as sfa
     B, N, M, L = 3, 256, 4, 6
